@@ -1,0 +1,168 @@
+"""ctypes/numpy front-end of the CPU oracle (oracle/sks_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+The product package (skelsplat_amd/) never imports this module.
+
+Mirrors the call structure of the reference host code:
+  forward()  ~ CudaRasterizer::Rasterizer::forward   (DGR/cuda_rasterizer/rasterizer_impl.cu:198-341)
+  backward() ~ CudaRasterizer::Rasterizer::backward  (DGR/cuda_rasterizer/rasterizer_impl.cu:345-450)
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libsks_oracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("sks_oracle.c", "sks_oracle_aux.c")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.orc_expf.restype = C.c_float
+        _LIB.orc_expf.argtypes = [C.c_float]
+        _LIB.orc_bin.restype = C.c_int
+    return _LIB
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+
+
+class Cam:
+    """Camera in the layout GaussianRasterizationSettings carries (DGR/.../__init__.py:143-156):
+    viewmatrix / projmatrix are the *transposed* 4x4 (row-major memory == column-major matrix)."""
+
+    def __init__(self, W, H, tanfovx, tanfovy, viewmatrix, projmatrix, campos=None):
+        self.W, self.H = int(W), int(H)
+        self.tanfovx, self.tanfovy = float(tanfovx), float(tanfovy)
+        self.view = _f32(np.asarray(viewmatrix).reshape(16))
+        self.proj = _f32(np.asarray(projmatrix).reshape(16))
+        self.campos = _f32(np.zeros(3) if campos is None else campos)
+
+    @property
+    def grid(self):
+        return (self.W + 15) // 16, (self.H + 15) // 16
+
+
+def expf(x):
+    x = np.asarray(x, dtype=np.float32)
+    out = np.empty_like(x)
+    L = lib()
+    for i, v in np.ndenumerate(x):
+        out[i] = L.orc_expf(float(v))
+    return out
+
+
+def preprocess(means3D, opacities, scales, rotations, cov3D_precomp, cam, scale_modifier=1.0, antialiasing=False):
+    means3D = _f32(means3D)
+    P = means3D.shape[0]
+    out = dict(
+        radii=np.zeros(P, np.int32), xy=np.zeros((P, 2), np.float32), depths=np.zeros(P, np.float32),
+        cov3D=np.zeros((P, 6), np.float32), conic_opacity=np.zeros((P, 4), np.float32),
+        tiles_touched=np.zeros(P, np.uint32))
+    scales, rotations, cov3D_precomp = _f32(scales), _f32(rotations), _f32(cov3D_precomp)
+    if cov3D_precomp is not None:
+        out["cov3D"][:] = cov3D_precomp.reshape(P, 6)
+    lib().orc_preprocess(
+        C.c_int(P), _p(means3D), _p(scales), C.c_float(scale_modifier), _p(rotations), _p(_f32(opacities).reshape(-1)),
+        _p(cov3D_precomp), _p(cam.view), _p(cam.proj), C.c_int(cam.W), C.c_int(cam.H),
+        C.c_float(cam.tanfovx), C.c_float(cam.tanfovy), C.c_int(int(antialiasing)),
+        _p(out["radii"]), _p(out["xy"]), _p(out["depths"]), _p(out["cov3D"]), _p(out["conic_opacity"]),
+        _p(out["tiles_touched"]))
+    return out
+
+
+def bin_tiles(geom, cam):
+    P = geom["radii"].shape[0]
+    gx, gy = cam.grid
+    cap = int(geom["tiles_touched"].astype(np.int64).sum())
+    offs = np.zeros(P, np.uint32)
+    keys = np.zeros(max(cap, 1), np.uint64)
+    plist = np.zeros(max(cap, 1), np.uint32)
+    ranges = np.zeros((gx * gy, 2), np.uint32)
+    R = lib().orc_bin(C.c_int(P), C.c_int(cam.W), C.c_int(cam.H), _p(geom["xy"]), _p(geom["depths"]),
+                      _p(geom["radii"]), _p(geom["tiles_touched"]), _p(offs), _p(keys), _p(plist), _p(ranges),
+                      C.c_int(cap))
+    assert R == cap, (R, cap)
+    return dict(point_offsets=offs, keys=keys[:R], point_list=plist[:R], ranges=ranges, R=R)
+
+
+def forward(means3D, features, opacities, scales, rotations, cov3D_precomp, cam, scale_modifier=1.0,
+            antialiasing=False):
+    """features: (P, C) fp32 (the reference reads them from `shs` with M == 1)."""
+    features = _f32(features)
+    P, Cn = features.shape
+    g = preprocess(means3D, opacities, scales, rotations, cov3D_precomp, cam, scale_modifier, antialiasing)
+    b = bin_tiles(g, cam)
+    W, H = cam.W, cam.H
+    color = np.zeros((Cn, H, W), np.float32)
+    final_T = np.zeros((H, W), np.float32)
+    n_contrib = np.zeros((H, W), np.uint32)
+    invdepth = np.zeros((1, H, W), np.float32)
+    plist = b["point_list"] if b["R"] else np.zeros(1, np.uint32)
+    lib().orc_render_fwd(C.c_int(W), C.c_int(H), C.c_int(Cn), _p(b["ranges"]), _p(plist), _p(g["xy"]),
+                         _p(features), _p(g["conic_opacity"]), _p(g["depths"]), _p(color), _p(final_T),
+                         _p(n_contrib), _p(invdepth))
+    out = dict(color=color, final_T=final_T, n_contrib=n_contrib, invdepth=invdepth)
+    out.update(g)
+    out.update(b)
+    return out
+
+
+def backward(fwd, means3D, features, opacities, scales, rotations, cov3D_precomp, cam, dL_dcolor, dL_dinvdepth=None,
+             bg=None, scale_modifier=1.0, antialiasing=False):
+    means3D, features = _f32(means3D), _f32(features)
+    P, Cn = features.shape
+    W, H = cam.W, cam.H
+    bgC = np.zeros(Cn, np.float32)
+    if bg is not None:
+        b = np.asarray(bg, np.float32).reshape(-1)
+        bgC[:min(Cn, b.size)] = b[:Cn]
+    dL_dcolor = _f32(dL_dcolor)
+    dL_dinvdepth = _f32(dL_dinvdepth)
+    dm2 = np.zeros((P, 3), np.float32)
+    dcon = np.zeros((P, 4), np.float32)
+    dop = np.zeros((P, 1), np.float32)
+    dcol = np.zeros((P, Cn), np.float32)
+    dinv = np.zeros(P, np.float32) if dL_dinvdepth is not None else None
+    plist = fwd["point_list"] if fwd["R"] else np.zeros(1, np.uint32)
+    lib().orc_render_bwd(C.c_int(P), C.c_int(W), C.c_int(H), C.c_int(Cn), _p(fwd["ranges"]), _p(plist), _p(bgC),
+                         _p(fwd["xy"]), _p(fwd["conic_opacity"]), _p(features), _p(fwd["depths"]),
+                         _p(fwd["final_T"]), _p(fwd["n_contrib"]), _p(dL_dcolor), _p(dL_dinvdepth),
+                         _p(dm2), _p(dcon), _p(dop), _p(dcol), _p(dinv))
+    dmeans = np.zeros((P, 3), np.float32)
+    dcov = np.zeros((P, 6), np.float32)
+    scales, rotations = _f32(scales), _f32(rotations)
+    dsc = np.zeros((P, 3), np.float32) if scales is not None else None
+    drot = np.zeros((P, 4), np.float32) if scales is not None else None
+    dop_geo = dop.copy()
+    lib().orc_preprocess_bwd(
+        C.c_int(P), _p(means3D), _p(fwd["radii"]), _p(scales), _p(rotations), C.c_float(scale_modifier),
+        _p(fwd["cov3D"]), _p(cam.view), _p(cam.proj), C.c_int(W), C.c_int(H), C.c_float(cam.tanfovx),
+        C.c_float(cam.tanfovy), _p(_f32(opacities).reshape(-1)), C.c_int(int(antialiasing)), _p(dm2), _p(dcon),
+        _p(dinv), _p(dop_geo), _p(dmeans), _p(dcov), _p(dsc), _p(drot))
+    return dict(dL_dmeans2D=dm2, dL_dconic=dcon, dL_dopacity=dop_geo, dL_dcolors=dcol, dL_dinvdepths=dinv,
+                dL_dmeans3D=dmeans, dL_dcov3D=dcov, dL_dscales=dsc, dL_drotations=drot)
+
+
+def mark_visible(means3D, cam):
+    means3D = _f32(means3D)
+    P = means3D.shape[0]
+    out = np.zeros(P, np.uint8)
+    lib().orc_mark_visible(C.c_int(P), _p(means3D), _p(cam.view), _p(out))
+    return out.astype(bool)

@@ -1,0 +1,293 @@
+"""Host-side scene pieces that feed the hot path: cameras, skeleton Gaussians, synthetic scenes.
+
+These are the inputs of SURVEY.md §8a (the reference builds them in scene/cameras.py, utils/graphics_utils.py,
+scene/gaussian_model.py and scene/dataset_readers.py).  Only what the rasterizer / multi-view loop consume is
+restated; dataset walkers, ply IO and densification are out of scope.
+"""
+import math
+
+import numpy as np
+import torch
+
+# ------------------------------------------------------------------------------------------------------------
+# camera math  (reference: utils/graphics_utils.py:38-49, 74-95, 101-102; scene/cameras.py:88-100)
+# ------------------------------------------------------------------------------------------------------------
+
+
+def focal2fov(focal, pixels):
+    return 2 * math.atan(pixels / (2 * focal))
+
+
+def fov2focal(fov, pixels):
+    return pixels / (2 * math.tan(fov / 2))
+
+
+def world2view2(R, t, translate=np.array([0.0, 0.0, 0.0]), scale=1.0):
+    """utils/graphics_utils.py:38-49.  R is the camera-to-world rotation (the reference stores R transposed)."""
+    Rt = np.zeros((4, 4))
+    Rt[:3, :3] = R.transpose()
+    Rt[:3, 3] = t
+    Rt[3, 3] = 1.0
+    C2W = np.linalg.inv(Rt)
+    cam_center = C2W[:3, 3]
+    cam_center = (cam_center + translate) * scale
+    C2W[:3, 3] = cam_center
+    Rt = np.linalg.inv(C2W)
+    return np.float32(Rt)
+
+
+def projection_matrix2(znear, zfar, K, W, H):
+    """utils/graphics_utils.py:74-95 (off-centre projection from intrinsics)."""
+    fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
+    top = znear * cy / fy
+    bottom = -znear * (H - cy) / fy
+    right = znear * (W - cx) / fx
+    left = -znear * cx / fx
+    P = torch.zeros(4, 4)
+    z_sign = 1.0
+    P[0, 0] = 2.0 * znear / (right - left)
+    P[1, 1] = 2.0 * znear / (top - bottom)
+    P[0, 2] = -(right + left) / (right - left)
+    P[1, 2] = (top + bottom) / (top - bottom)
+    P[3, 2] = z_sign
+    P[2, 2] = z_sign * zfar / (zfar - znear)
+    P[2, 3] = -(zfar * znear) / (zfar - znear)
+    return P
+
+
+class Camera:
+    """Attribute-compatible subset of scene/cameras.py:Camera used by render_* and the loop."""
+
+    def __init__(self, uid, R, T, K, width, height, device="cpu", znear=0.01, zfar=100.0):
+        self.uid = uid
+        self.R = np.asarray(R, dtype=np.float64)
+        self.T = np.asarray(T, dtype=np.float64)
+        self.K = np.asarray(K, dtype=np.float64)
+        self.image_width = int(width)
+        self.image_height = int(height)
+        self.FoVx = focal2fov(self.K[0, 0], width)
+        self.FoVy = focal2fov(self.K[1, 1], height)
+        self.znear, self.zfar = znear, zfar
+        wvt = torch.tensor(world2view2(self.R, self.T)).transpose(0, 1)
+        proj = projection_matrix2(znear, zfar, self.K, self.image_width, self.image_height).transpose(0, 1)
+        full = wvt.unsqueeze(0).bmm(proj.unsqueeze(0)).squeeze(0)
+        center = wvt.inverse()[3, :3]
+        self.world_view_transform = wvt.contiguous().to(device)
+        self.projection_matrix = proj.contiguous().to(device)
+        self.full_proj_transform = full.contiguous().to(device)
+        self.camera_center = center.contiguous().to(device)
+
+    def to(self, device):
+        for k in ("world_view_transform", "projection_matrix", "full_proj_transform", "camera_center"):
+            setattr(self, k, getattr(self, k).to(device))
+        return self
+
+
+def look_at_camera(uid, position, target, fx, fy, cx, cy, width, height, device="cpu"):
+    """OpenCV-style camera (x right, y down, z forward) at `position` looking at `target`, world z up."""
+    position = np.asarray(position, dtype=np.float64)
+    fwd = np.asarray(target, dtype=np.float64) - position
+    fwd /= np.linalg.norm(fwd)
+    right = np.cross(fwd, np.array([0.0, 0.0, 1.0]))
+    right /= np.linalg.norm(right)
+    down = np.cross(fwd, right)
+    R_w2c = np.stack([right, down, fwd], 0)
+    t = -R_w2c @ position
+    K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1.0]])
+    return Camera(uid, R_w2c.T, t, K, width, height, device=device)
+
+
+def cameras_extent(cams):
+    """scene/dataset_readers.py:482-503 (getNerfppNorm radius): 1.1 * max distance of a camera centre to their mean."""
+    centers = []
+    for c in cams:
+        W2C = world2view2(c.R, c.T)
+        centers.append(np.linalg.inv(W2C)[:3, 3:4])
+    centers = np.hstack(centers)
+    avg = np.mean(centers, axis=1, keepdims=True)
+    return float(np.max(np.linalg.norm(centers - avg, axis=0, keepdims=True)) * 1.1)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# skeleton templates (mm, z up, pelvis at z=900) and dataset conventions
+# ------------------------------------------------------------------------------------------------------------
+
+_H36M = [  # 0 pelvis 1-3 R leg 4-6 L leg 7 spine 8 thorax 9 neck 10 head 11-13 L arm 14-16 R arm
+    (0, 0, 900), (-130, 0, 900), (-130, 0, 480), (-130, 0, 60), (130, 0, 900), (130, 0, 480), (130, 0, 60),
+    (0, 0, 1150), (0, 0, 1400), (0, 0, 1500), (0, 0, 1650), (180, 0, 1400), (460, 0, 1400), (720, 0, 1400),
+    (-180, 0, 1400), (-460, 0, 1400), (-720, 0, 1400)]
+_PANOPTIC = [  # 0 neck 1 nose 2 body centre 3-5 L arm 6-8 L leg 9-11 R arm 12-14 R leg 15-18 eyes/ears
+    (0, 0, 1450), (0, 60, 1580), (0, 0, 900), (180, 0, 1400), (460, 0, 1400), (720, 0, 1400), (130, 0, 900),
+    (130, 0, 480), (130, 0, 60), (-180, 0, 1400), (-460, 0, 1400), (-720, 0, 1400), (-130, 0, 900),
+    (-130, 0, 480), (-130, 0, 60), (35, 50, 1620), (75, 0, 1600), (-35, 50, 1620), (-75, 0, 1600)]
+_OP = [  # 0 pelvis 1-3 R leg 4-6 L leg 7 thorax 8 head 9-11 L arm 12-14 R arm
+    (0, 0, 900), (-130, 0, 900), (-130, 0, 480), (-130, 0, 60), (130, 0, 900), (130, 0, 480), (130, 0, 60),
+    (0, 0, 1400), (0, 0, 1650), (180, 0, 1400), (460, 0, 1400), (720, 0, 1400), (-180, 0, 1400),
+    (-460, 0, 1400), (-720, 0, 1400)]
+
+DATASETS = {
+    # name: (template, limb-end joints scaled by scaling_modifier (gaussian_model.py:173-178),
+    #        limb pairs of utils/loss_utils.py:226-250 as (l_arm, r_arm, l_leg, r_leg), W, H, rasterizer key)
+    "h36m": dict(template=_H36M, limb_ends=[3, 6, 12, 13, 15, 16],
+                 limbs=((12, 13), (15, 16), (5, 6), (2, 3)), W=1000, H=1000, fx=1145.0, ring=5000.0,
+                 rendering="diff-gaussian-rasterization-h36m"),
+    "panoptic": dict(template=_PANOPTIC, limb_ends=[8, 14, 4, 5, 10, 11],
+                     limbs=((4, 5), (10, 11), (7, 8), (13, 14)), W=1920, H=1080, fx=1400.0, ring=3000.0,
+                     rendering="diff-gaussian-rasterization-panoptic"),
+    "occlusion-person": dict(template=_OP, limb_ends=[3, 6, 10, 11, 13, 14],
+                             limbs=((10, 11), (13, 14), (5, 6), (2, 3)), W=1280, H=720, fx=1145.0, ring=5000.0,
+                             rendering="diff-gaussian-rasterization-op"),
+}
+
+
+def skeleton_template(dataset):
+    return np.asarray(DATASETS[dataset]["template"], dtype=np.float64)
+
+
+def ring_cameras(V, W, H, radius, fx, rng, height=1500.0, target=(0.0, 0.0, 900.0), device="cpu"):
+    """SURVEY §8d synthetic cameras: ring of V cameras looking at the pelvis, jittered azimuth and principal point."""
+    cams = []
+    for k in range(V):
+        az = 2 * math.pi * k / V + rng.uniform(-0.1, 0.1)
+        pos = (radius * math.cos(az) + target[0], radius * math.sin(az) + target[1], height)
+        cx = W / 2 + rng.uniform(-15, 15)
+        cy = H / 2 + rng.uniform(-15, 15)
+        cams.append(look_at_camera(k, pos, target, fx, fx, cx, cy, W, H, device=device))
+    return cams
+
+
+def project_points(cam, pts):
+    """Pixel coordinates (x, y) of world points through K[R|t] (as triangulation.py:59-67 builds it)."""
+    Rw2c = cam.R.T
+    pc = (Rw2c @ np.asarray(pts, dtype=np.float64).T).T + cam.T[None]
+    uv = (cam.K @ pc.T).T
+    return uv[:, :2] / uv[:, 2:3]
+
+
+class SyntheticScene:
+    """One synthetic frame: GT skeleton, noisy initial guess, cameras, noisy 2D keypoints (seed-reproducible)."""
+
+    def __init__(self, dataset="h36m", n_views=4, seed=0, device="cpu", W=None, H=None, n_skeletons=1,
+                 pitch=1500.0, ring=None, fx=None):
+        d = DATASETS[dataset]
+        rng = np.random.default_rng(seed)
+        self.dataset = dataset
+        self.W = int(W or d["W"])
+        self.H = int(H or d["H"])
+        tmpl = skeleton_template(dataset)
+        J = tmpl.shape[0]
+        gts = []
+        side = int(math.ceil(math.sqrt(n_skeletons)))
+        for s in range(n_skeletons):
+            off = np.array([((s % side) - (side - 1) / 2) * pitch, ((s // side) - (side - 1) / 2) * pitch, 0.0])
+            gts.append(tmpl + rng.normal(0.0, 50.0, tmpl.shape) + off)
+        self.pose_3d_gt = np.concatenate(gts, 0)
+        self.pose_3d_init = self.pose_3d_gt + rng.normal(0.0, 30.0, self.pose_3d_gt.shape)
+        self.n_joints = J
+        self.n_points = J * n_skeletons
+        fx = fx or d["fx"] * (self.W / d["W"])
+        self.cameras = ring_cameras(n_views, self.W, self.H, ring or d["ring"], fx, rng, device=device)
+        self.poses_2d = np.stack([project_points(c, self.pose_3d_gt) + rng.normal(0.0, 3.0, (self.n_points, 2))
+                                  for c in self.cameras], 0)
+        self.spatial_lr_scale = cameras_extent(self.cameras)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# Gaussian parameter container (reference: scene/gaussian_model.py:32-47, 102-131, 149-200, 203-248)
+# ------------------------------------------------------------------------------------------------------------
+
+
+def inverse_sigmoid(x):
+    return torch.log(x / (1 - x))
+
+
+def get_expon_lr_func(lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, max_steps=1000000):
+    """utils/general_utils.py:38-71."""
+
+    def helper(step):
+        if step < 0 or (lr_init == 0.0 and lr_final == 0.0):
+            return 0.0
+        if lr_delay_steps > 0:
+            delay_rate = lr_delay_mult + (1 - lr_delay_mult) * np.sin(0.5 * np.pi * np.clip(step / lr_delay_steps, 0, 1))
+        else:
+            delay_rate = 1.0
+        t = np.clip(step / max_steps, 0, 1)
+        log_lerp = np.exp(np.log(lr_init) * (1 - t) + np.log(lr_final) * t)
+        return delay_rate * log_lerp
+
+    return helper
+
+
+class OptimizationParams:
+    """Field names of configs/*.yaml `optimization:` (configs/h36m.yaml:50-75) so the YAMLs stay valid."""
+    iterations = 500
+    position_lr_init = 0.0005
+    position_lr_final = 0.000005
+    position_lr_delay_mult = 0.0
+    position_lr_max_steps = 4000
+    feature_lr = 0.0
+    opacity_lr = 0.0
+    scaling_lr = 0.005
+    rotation_lr = 0.001
+
+
+class GaussianModel:
+    """Skeleton Gaussians: one per joint, one-hot J-channel feature (gaussian_model.py:149-200)."""
+
+    def __init__(self, sh_degree=1, optimizer_type="default"):
+        self.active_sh_degree = 0
+        self.max_sh_degree = sh_degree
+        self.optimizer_type = optimizer_type
+        self.optimizer = None
+        self.spatial_lr_scale = 1.0
+
+    def create_from_points(self, points, spatial_lr_scale, n_joints, opacity_on=True, scaling=3.0,
+                           scaling_modifier=1.0, scene_type="h36m", device="cpu"):
+        self.spatial_lr_scale = spatial_lr_scale
+        pts = torch.tensor(np.asarray(points)).float().to(device)
+        P = pts.shape[0]
+        ch = torch.arange(P, device=device) % n_joints
+        features = torch.zeros(P, n_joints, device=device).scatter_(1, ch[:, None], 1.0)[:, None, :]  # (P,1,C)
+        scales = torch.ones_like(pts) * scaling
+        ends = torch.tensor(DATASETS[scene_type]["limb_ends"], device=device)
+        sel = (ch[:, None] == ends[None, :]).any(1)
+        scales[sel] *= scaling_modifier
+        rots = torch.zeros((P, 4), device=device)
+        rots[:, 0] = 1
+        opacities = inverse_sigmoid(1.0 * torch.ones((P, 1), dtype=torch.float, device=device))
+        self._xyz = torch.nn.Parameter(pts.requires_grad_(True))
+        self._features_dc = torch.nn.Parameter(features.contiguous().requires_grad_(False))
+        self._features_rest = torch.nn.Parameter(torch.zeros(P, 0, n_joints, device=device).requires_grad_(False))
+        self._scaling = torch.nn.Parameter(scales.requires_grad_(True))
+        self._rotation = torch.nn.Parameter(rots.requires_grad_(True))
+        self._opacity = torch.nn.Parameter(opacities.requires_grad_(opacity_on))
+        return self
+
+    get_xyz = property(lambda self: self._xyz)
+    get_scaling = property(lambda self: torch.exp(self._scaling))
+    get_rotation = property(lambda self: torch.nn.functional.normalize(self._rotation))
+    get_opacity = property(lambda self: torch.sigmoid(self._opacity))
+    get_features = property(lambda self: self._features_dc)
+    get_features_dc = property(lambda self: self._features_dc)
+    get_features_rest = property(lambda self: self._features_rest)
+
+    def training_setup(self, opt=OptimizationParams):
+        groups = [
+            {"params": [self._xyz], "lr": opt.position_lr_init * self.spatial_lr_scale, "name": "xyz"},
+            {"params": [self._features_dc], "lr": opt.feature_lr, "name": "f_dc"},
+            {"params": [self._features_rest], "lr": opt.feature_lr / 20.0, "name": "f_rest"},
+            {"params": [self._opacity], "lr": opt.opacity_lr, "name": "opacity"},
+            {"params": [self._scaling], "lr": opt.scaling_lr, "name": "scaling"},
+            {"params": [self._rotation], "lr": opt.rotation_lr, "name": "rotation"},
+        ]
+        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+        self.xyz_scheduler_args = get_expon_lr_func(
+            lr_init=opt.position_lr_init * self.spatial_lr_scale, lr_final=opt.position_lr_final * self.spatial_lr_scale,
+            lr_delay_mult=opt.position_lr_delay_mult, max_steps=opt.position_lr_max_steps)
+
+    def update_learning_rate(self, iteration):
+        for g in self.optimizer.param_groups:
+            if g["name"] == "xyz":
+                lr = self.xyz_scheduler_args(iteration)
+                g["lr"] = lr
+                return lr
