@@ -1,0 +1,7 @@
+"""Drop-in for the reference package `diff_gaussian_rasterization_panoptic`
+(submodules/diff-gaussian-rasterization-panoptic, NUM_CHANNELS 19 at cuda_rasterizer/config.h:15), backed by the
+MI355X HIP library of skelsplat_amd.  Same names as the reference's __init__.py:143-207."""
+from skelsplat_amd.rasterizer import make_package, rasterize_gaussians  # noqa: F401
+
+NUM_CHANNELS = 19
+GaussianRasterizationSettings, GaussianRasterizer = make_package(NUM_CHANNELS)

@@ -1,0 +1,107 @@
+"""Drop-in for the reference's gaussian_renderer package (gaussian_renderer/__init__.py:28-371): the three
+render_* functions and the `render_functions` registry keyed by `pipeline.rendering` (configs/*.yaml:45).
+
+Differences that do not change results:
+  * `rendered_image.clamp(0, 1)` (reference :129) is folded into the rasterizer's store and its backward mask
+    (SKS_CLAMP01) instead of running as two extra dense passes;
+  * `(radii > 0).nonzero()` (reference :133) forces a host sync, so `visibility_filter` is computed on first access.
+"""
+import math
+
+import torch
+
+from diff_gaussian_rasterization_h36m import GaussianRasterizationSettings as GaussianRasterizationSettingsH36M
+from diff_gaussian_rasterization_h36m import GaussianRasterizer as GaussianRasterizerH36M
+from diff_gaussian_rasterization_panoptic import GaussianRasterizationSettings as GaussianRasterizationSettingsPanoptic
+from diff_gaussian_rasterization_panoptic import GaussianRasterizer as GaussianRasterizerPanoptic
+from diff_gaussian_rasterization_op import GaussianRasterizationSettings as GaussianRasterizationSettingsOp
+from diff_gaussian_rasterization_op import GaussianRasterizer as GaussianRasterizerOp
+
+
+class RenderPackage(dict):
+    """dict with the reference's keys; `visibility_filter` is materialised lazily (it needs a host sync)."""
+
+    def __getitem__(self, key):
+        if key == "visibility_filter" and not dict.__contains__(self, key):
+            dict.__setitem__(self, key, (dict.__getitem__(self, "radii") > 0).nonzero())
+        return dict.__getitem__(self, key)
+
+    def __contains__(self, key):
+        return key == "visibility_filter" or dict.__contains__(self, key)
+
+    def keys(self):
+        return list(dict.keys(self)) + ([] if dict.__contains__(self, "visibility_filter") else ["visibility_filter"])
+
+
+def _render(Settings, Rasterizer, viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, separate_sh=False,
+            override_color=None, use_trained_exp=False):
+    # zero tensor whose gradient receives the 2D (screen-space) mean gradients (reference :36-40)
+    screenspace_points = torch.zeros_like(pc.get_xyz, dtype=pc.get_xyz.dtype, requires_grad=True) + 0
+    try:
+        screenspace_points.retain_grad()
+    except Exception:
+        pass
+    tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
+    tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)
+    raster_settings = Settings(
+        image_height=int(viewpoint_camera.image_height),
+        image_width=int(viewpoint_camera.image_width),
+        tanfovx=tanfovx,
+        tanfovy=tanfovy,
+        bg=bg_color,
+        scale_modifier=scaling_modifier,
+        viewmatrix=viewpoint_camera.world_view_transform,
+        projmatrix=viewpoint_camera.full_proj_transform,
+        sh_degree=pc.active_sh_degree,
+        campos=viewpoint_camera.camera_center,
+        prefiltered=False,
+        debug=pipe.debug,
+        antialiasing=pipe.antialiasing,
+    )
+    rasterizer = Rasterizer(raster_settings=raster_settings)
+    means3D = pc.get_xyz
+    means2D = screenspace_points
+    opacity = pc.get_opacity
+    scales = rotations = cov3D_precomp = None
+    if pipe.compute_cov3D_python:
+        cov3D_precomp = pc.get_covariance(scaling_modifier)
+    else:
+        scales = pc.get_scaling
+        rotations = pc.get_rotation
+    shs = colors_precomp = None
+    if override_color is None:
+        if pipe.convert_SHs_python:
+            raise NotImplementedError("convert_SHs_python: the skeleton features are not RGB SH (every shipped "
+                                      "config sets it to false, configs/h36m.yaml:46)")
+        shs = pc.get_features  # with separate_sh the reference passes dc + empty rest; same (P,1,C) features
+    else:
+        colors_precomp = override_color
+    rendered_image, radii, depth_image = rasterizer(
+        means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, opacities=opacity,
+        scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp, clamp01=True)
+    return RenderPackage(render=rendered_image, viewspace_points=screenspace_points, radii=radii, depth=depth_image)
+
+
+def render_h36m(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, separate_sh=False, override_color=None,
+                use_trained_exp=False):
+    return _render(GaussianRasterizationSettingsH36M, GaussianRasterizerH36M, viewpoint_camera, pc, pipe, bg_color,
+                   scaling_modifier, separate_sh, override_color, use_trained_exp)
+
+
+def render_panoptic(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, separate_sh=False, override_color=None,
+                    use_trained_exp=False):
+    return _render(GaussianRasterizationSettingsPanoptic, GaussianRasterizerPanoptic, viewpoint_camera, pc, pipe,
+                   bg_color, scaling_modifier, separate_sh, override_color, use_trained_exp)
+
+
+def render_op(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, separate_sh=False, override_color=None,
+              use_trained_exp=False):
+    return _render(GaussianRasterizationSettingsOp, GaussianRasterizerOp, viewpoint_camera, pc, pipe, bg_color,
+                   scaling_modifier, separate_sh, override_color, use_trained_exp)
+
+
+render_functions = {
+    "diff-gaussian-rasterization-h36m": render_h36m,
+    "diff-gaussian-rasterization-panoptic": render_panoptic,
+    "diff-gaussian-rasterization-op": render_op,
+}

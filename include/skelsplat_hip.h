@@ -1,0 +1,104 @@
+/*
+ * skelsplat_hip.h -- C ABI of libskelsplat_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the hot path of laurabragagnolo/SkelSplat: everything the reference binds through
+ * pybind11 in submodules/diff-gaussian-rasterization-{h36m,panoptic,op}/ext.cpp:14-18
+ * (rasterize_gaussians, rasterize_gaussians_backward, mark_visible; signatures rasterize_points.h:18-71),
+ * submodules/fused-ssim/ext.cpp (fusedssim, fusedssim_backward) and submodules/simple-knn/ext.cpp (distCUDA2).
+ * "DGR/" = submodules/diff-gaussian-rasterization-h36m/.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer into caller-owned, contiguous fp32 / int32 storage unless marked HOST;
+ *    NULL means "not provided" (the reference uses data<float>() of an empty CPU tensor for that,
+ *    DGR/diff_gaussian_rasterization_h36m/__init__.py:184-194);
+ *  - the library never allocates, frees or synchronises; all work is enqueued on `stream`
+ *    (a hipStream_t passed as void*), so calls are capturable into hipGraphs;
+ *  - V views that share the Gaussian parameters and the image size are processed by ONE launch sequence
+ *    (the reference renders one view per call; its loop, train.py:130-222, keeps the parameters fixed for
+ *    `accumulation_steps` consecutive views, which is what makes the batch legal);
+ *  - matrices are the reference's transposed 4x4 (row-major memory == column-major matrix), 16 floats per view;
+ *  - return value: 0 ok, <0 invalid argument, >0 hipError_t; text via sks_last_error() (thread-local).
+ */
+#ifndef SKELSPLAT_HIP_H
+#define SKELSPLAT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SKS_MAX_VIEWS 64      /* views per call */
+#define SKS_MAX_CHANNELS 32   /* feature channels (reference: NUM_CHANNELS 15 / 17 / 19, config.h:15) */
+#define SKS_SMALL_P 256       /* P <= SKS_SMALL_P: fused per-band path, no global binning */
+
+/* flags */
+#define SKS_ANTIALIASING 1u   /* raster_settings.antialiasing */
+#define SKS_CLAMP01      2u   /* fold gaussian_renderer's rendered_image.clamp(0,1) (gaussian_renderer/__init__.py:129)
+                                 into the forward store and its pass-through mask into the backward */
+#define SKS_FORCE_BINNED 4u   /* use the binned (large-P) path even when P <= SKS_SMALL_P (tests) */
+#define SKS_DEBUG_SYNC   8u   /* raster_settings.debug: hipStreamSynchronize + error check after each stage
+                                 (CHECK_CUDA, DGR/cuda_rasterizer/auxiliary.h:178-185) */
+
+const char* sks_last_error(void);
+int sks_version(void);
+
+/* Scratch sizes in bytes for one call (replaces the resizeFunctional callbacks, DGR/rasterize_points.cu:27-33).
+ * geom: per-view per-Gaussian records kept for backward ("geomBuffer");
+ * binning: tile counters / ranges / sorted keys ("binningBuffer"+"imgBuffer" ranges), only used on the binned
+ *          path; bin_capacity = max (Gaussian,tile) pairs per view it must hold;
+ * accum:  backward accumulators, must be zero on entry to sks_backward and is left zero on return. */
+int sks_scratch_bytes(int V, int P, int C, int W, int H, size_t bin_capacity,
+                      size_t* geom_bytes, size_t* binning_bytes, size_t* accum_bytes);
+
+/* Replaces _C.rasterize_gaussians (DGR/rasterize_points.cu:35-124 -> rasterizer_impl.cu:198-341).
+ * features: (P,C) -- the reference reads them from `sh` with M == 1.
+ * Outputs: out_color (V,C,H,W), out_invdepth (V,1,H,W), radii (V,P); every element is written
+ * (no pre-zeroing needed).  Optional debug outputs final_T (V,H,W) / n_contrib (V,H,W) reproduce the
+ * reference's ImageState (rasterizer_impl.h:52-60) for parity tests; pass NULL on the fast path.
+ * num_rendered_dev (V ints, may be NULL): number of (Gaussian,tile) pairs, written on the binned path. */
+int sks_forward(int V, int P, int C, int W, int H,
+                const float* viewmatrix, const float* projmatrix,
+                const float* tanfovx /*HOST V*/, const float* tanfovy /*HOST V*/,
+                const float* means3D, const float* features, const float* opacities,
+                const float* scales, const float* rotations, const float* cov3D_precomp,
+                float scale_modifier, unsigned flags,
+                float* out_color, float* out_invdepth, int* radii,
+                void* geom, void* binning, size_t bin_capacity, int* num_rendered_dev,
+                float* final_T, uint32_t* n_contrib, void* stream);
+
+/* Replaces _C.rasterize_gaussians_backward (DGR/rasterize_points.cu:126-223 -> rasterizer_impl.cu:345-450).
+ * geom / binning are the buffers sks_forward filled for the same inputs.  bg: C floats or NULL (zeros).
+ * dL_dout_invdepth may be NULL (treated as zeros; the reference always receives a materialised zero grad, Q4).
+ * Per-view gradients (V,P,...): dL_dmeans3D 3, dL_dmeans2D 3 (z = 0), dL_dopacity 1, dL_dscales 3, dL_drotations 4,
+ * dL_dcov3D 6; dL_dfeatures (V,P,C) only when non-NULL (true dL/dfeature, SURVEY quirk Q5 is NOT reproduced).
+ * dL_dscales / dL_drotations may be NULL when cov3D_precomp is given. */
+int sks_backward(int V, int P, int C, int W, int H,
+                 const float* viewmatrix, const float* projmatrix,
+                 const float* tanfovx /*HOST V*/, const float* tanfovy /*HOST V*/,
+                 const float* bg,
+                 const float* means3D, const float* features, const float* opacities,
+                 const float* scales, const float* rotations, const float* cov3D_precomp,
+                 float scale_modifier, unsigned flags,
+                 const int* radii, const void* geom, const void* binning, size_t bin_capacity,
+                 const float* dL_dout_color, const float* dL_dout_invdepth,
+                 void* accum,
+                 float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dopacity,
+                 float* dL_dscales, float* dL_drotations, float* dL_dcov3D, float* dL_dfeatures,
+                 void* stream);
+
+/* Replaces _C.mark_visible (DGR/rasterize_points.cu:225-244; checkFrustum rasterizer_impl.cu:54-66).
+ * present: P bytes (bool). */
+int sks_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                     uint8_t* present, void* stream);
+
+/* Debug / parity: copies the binned path's per-view lists out of `binning` in the reference's layout:
+ * point_list (V,bin_capacity) uint32, ranges (V,Tx*Ty,2) uint32 (BinningState / ImageState::ranges). */
+int sks_export_lists(int V, int W, int H, const void* binning, size_t bin_capacity,
+                     uint32_t* point_list, uint32_t* ranges, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,81 @@
+"""ctypes binding of libskelsplat_hip.so (include/skelsplat_hip.h).
+
+The library is the product: there is NO CPU or PyTorch fallback.  Loading fails loudly if the shared object is
+missing and cannot be built, and every op raises if it is handed non-ROCm tensors.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libskelsplat_hip.so")
+_lib = None
+
+SKS_MAX_VIEWS = 64
+SKS_MAX_CHANNELS = 32
+SKS_SMALL_P = 256
+SKS_ANTIALIASING = 1
+SKS_CLAMP01 = 2
+SKS_FORCE_BINNED = 4
+SKS_DEBUG_SYNC = 8
+
+_vp, _i, _u, _f, _sz = C.c_void_p, C.c_int, C.c_uint, C.c_float, C.c_size_t
+
+# symbol -> (restype, argtypes); mirrors include/skelsplat_hip.h (tests check every declared symbol is exported)
+SIGNATURES = {
+    "sks_last_error": (C.c_char_p, []),
+    "sks_version": (_i, []),
+    "sks_scratch_bytes": (_i, [_i, _i, _i, _i, _i, _sz, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz)]),
+    "sks_forward": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _u,
+                         _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
+    "sks_backward": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _u,
+                          _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sks_mark_visible": (_i, [_i, _vp, _vp, _vp, _vp, _vp]),
+    "sks_export_lists": (_i, [_i, _i, _i, _vp, _sz, _vp, _vp, _vp]),
+}
+
+
+def load(build_if_missing=True):
+    """Returns the loaded CDLL; raises ImportError with the build error if it cannot be produced."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if build_if_missing:
+        try:
+            from . import build as _b
+            if _b._stale():
+                _b.build()
+        except Exception as e:  # no hipcc on this box: fall through to the prebuilt .so
+            if not os.path.exists(LIB_PATH):
+                raise ImportError(f"libskelsplat_hip.so is missing and could not be built: {e}") from e
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} not found; run `python -m skelsplat_amd.build`")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError = ABI drift, fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().sks_last_error().decode(errors="replace")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")
+
+
+def scratch_bytes(V, P, C_, W, H, bin_capacity=0):
+    g, b, a = _sz(0), _sz(0), _sz(0)
+    check(load().sks_scratch_bytes(V, P, C_, W, H, bin_capacity, C.byref(g), C.byref(b), C.byref(a)), "sks_scratch_bytes")
+    return g.value, b.value, a.value
+
+
+def ptr(t):
+    """Device pointer of a tensor, or None.  Empty tensors are the reference's "not provided" sentinel."""
+    if t is None or t.numel() == 0:
+        return None
+    return t.data_ptr()
+
+
+def farray(vals):
+    return (C.c_float * len(vals))(*[float(v) for v in vals])

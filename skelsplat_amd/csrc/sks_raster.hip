@@ -1,0 +1,1219 @@
+// sks_raster.hip -- skeletal-Gaussian rasterizer for MI355X (gfx950): geometry, binning, compositing, C ABI.
+//
+// Replaces DGR/cuda_rasterizer/{forward.cu,backward.cu,rasterizer_impl.cu} + DGR/rasterize_points.cu of the
+// reference ("DGR/" = submodules/diff-gaussian-rasterization-h36m/).  Design:
+//   * one launch sequence renders V views that share the Gaussian parameters (blockIdx.z = view);
+//   * P <= SKS_SMALL_P ("skeleton" regime, the reference's real configs have P = 15..19): NO global binning.
+//     Every workgroup owns a contiguous chunk of one 16-row tile band of the image, finds the Gaussians whose
+//     tile rect crosses the band, depth-sorts them in LDS (key = depth bits, index -- the order the reference
+//     gets from its stable radix sort of (tile | depth) keys with index-major emission) and composites /
+//     zero-fills its chunk with 16-byte-per-lane plane-contiguous stores;
+//   * larger P: tile-centric binning (count -> scan -> scatter -> per-tile LDS bitonic sort) and one workgroup per
+//     tile with LDS-staged batches;
+//   * backward never needs final_T / n_contrib from HBM: it re-composites its pixels first, then walks back to
+//     front exactly like backward.cu:531-637; per-Gaussian partial sums are reduced across the wavefront, then in
+//     LDS, and leave the workgroup as one atomic per value;
+//   * HBM-bound: no MFMA anywhere (there is no dense contraction in this path).
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/skelsplat_hip.h"
+#include "sks_math.h"
+
+using namespace sks;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) return fail((int)e_, "%s: %s", #expr, hipGetErrorString(e_));    \
+    } while (0)
+
+#define STAGE_CHECK(name)                                                                      \
+    do {                                                                                       \
+        HIP_TRY(hipGetLastError());                                                            \
+        if (flags & SKS_DEBUG_SYNC) {                                                          \
+            hipError_t e_ = hipStreamSynchronize(st);                                          \
+            if (e_ != hipSuccess) return fail((int)e_, "stage %s: %s", name, hipGetErrorString(e_)); \
+        }                                                                                      \
+    } while (0)
+
+constexpr int LCAP = 256;         // LDS list capacity == SKS_SMALL_P == binned batch size
+constexpr int NACC = 8;           // per-Gaussian accumulators before the feature block:
+                                  // 0,1 dL_dmean2D.xy  2,3,4 dL_dconic.{x,y,w}  5 dL_dopacity  6 dL_dinvdepth  7 pad
+constexpr int FWD_PASSES = 4;     // small path forward: 256 thr x 4 px x 4 passes = 4096 px per workgroup
+constexpr int BWD_PASSES = 16;    // small path backward: 256 thr x 1 px x 16 passes
+
+struct ViewTan {
+    float x[SKS_MAX_VIEWS];
+    float y[SKS_MAX_VIEWS];
+};
+
+struct Geom {  // per-(view, Gaussian) records kept for backward ("geomBuffer")
+    float4* co;    // conic.x, conic.y, conic.z, opacity * h_convolution_scaling   (forward.cu:269)
+    float4* xyd;   // pixel centre x, y, view depth, 1/depth
+    uint4* rect;   // tile rect xmin, ymin, xmax, ymax (all 0 when culled)
+};
+
+__host__ __device__ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+inline Geom geom_from(void* base, int V, int P)
+{
+    char* p = (char*)base;
+    Geom g;
+    size_t n = (size_t)V * P;
+    g.co = (float4*)p; p += align256(n * sizeof(float4));
+    g.xyd = (float4*)p; p += align256(n * sizeof(float4));
+    g.rect = (uint4*)p;
+    return g;
+}
+inline size_t geom_bytes(int V, int P) { return 3 * align256((size_t)V * P * 16); }
+
+struct Bin {  // binned path scratch ("binningBuffer" + ImageState::ranges)
+    uint32_t* count;   // V*NT
+    uint32_t* cursor;  // V*NT
+    uint2* ranges;     // V*NT
+    int* nrend;        // V (+ overflow flag at [V])
+    unsigned long long* keys;  // V*cap : (depth bits << 32) | Gaussian index, sorted per tile
+};
+inline Bin bin_from(void* base, int V, int NT, size_t cap)
+{
+    char* p = (char*)base;
+    Bin b;
+    b.count = (uint32_t*)p; p += align256((size_t)V * NT * 4);
+    b.cursor = (uint32_t*)p; p += align256((size_t)V * NT * 4);
+    b.ranges = (uint2*)p; p += align256((size_t)V * NT * 8);
+    b.nrend = (int*)p; p += align256((size_t)(V + 1) * 4);
+    b.keys = (unsigned long long*)p;
+    return b;
+}
+inline size_t bin_bytes(int V, int NT, size_t cap)
+{
+    return 2 * align256((size_t)V * NT * 4) + align256((size_t)V * NT * 8) + align256((size_t)(V + 1) * 4) +
+           align256((size_t)V * cap * 8);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// geometry forward: preprocessCUDA, DGR/cuda_rasterizer/forward.cu:153-273 (+ in_frustum auxiliary.h:151-176)
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_geom_fwd(int P, int W, int H, ViewTan vt, const float* __restrict__ vms,
+                                                   const float* __restrict__ pms, const float* __restrict__ means,
+                                                   const float* __restrict__ opac, const float* __restrict__ scales,
+                                                   const float* __restrict__ rots, const float* __restrict__ cov3Dp,
+                                                   float smod, unsigned flags, Geom g, int* __restrict__ radii)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int v = blockIdx.y;
+    if (idx >= P) return;
+    const size_t o = (size_t)v * P + idx;
+    const float* V = vms + 16 * v;
+    const float* PM = pms + 16 * v;
+    const float tan_fovx = vt.x[v], tan_fovy = vt.y[v];
+    const float focal_y = H / (2.0f * tan_fovy);  // rasterizer_impl.cu:224-225
+    const float focal_x = W / (2.0f * tan_fovx);
+    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+
+    int radius_out = 0;
+    uint4 rect = make_uint4(0, 0, 0, 0);
+    float4 co = make_float4(0, 0, 0, 0), xyd = make_float4(0, 0, 1.0f, 1.0f);
+
+    const float p_orig[3] = { means[3 * idx], means[3 * idx + 1], means[3 * idx + 2] };
+    float p_view[3];
+    transformPoint4x3(p_orig, V, p_view);
+    if (p_view[2] > 0.2f) {
+        float p_hom[4];
+        transformPoint4x4(p_orig, PM, p_hom);
+        const float p_w = 1.0f / (p_hom[3] + 0.0000001f);
+        const float p_proj[3] = { p_hom[0] * p_w, p_hom[1] * p_w, p_hom[2] * p_w };
+        float cov3D[6];
+        if (cov3Dp) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) cov3D[i] = cov3Dp[6 * idx + i];
+        } else {
+            const float s[3] = { scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2] };
+            const float q[4] = { rots[4 * idx], rots[4 * idx + 1], rots[4 * idx + 2], rots[4 * idx + 3] };
+            computeCov3D(s, smod, q, cov3D);
+        }
+        Cov2D c;
+        cov2d(p_orig, focal_x, focal_y, tan_fovx, tan_fovy, cov3D, V, c);
+        float cov_x = c.cov.m[0][0], cov_y = c.cov.m[0][1], cov_z = c.cov.m[1][1];
+        constexpr float h_var = 0.3f;
+        const float det_cov = cov_x * cov_z - cov_y * cov_y;
+        cov_x += h_var;
+        cov_z += h_var;
+        const float det_cov_plus_h_cov = cov_x * cov_z - cov_y * cov_y;
+        float h_convolution_scaling = 1.0f;
+        if (flags & SKS_ANTIALIASING) h_convolution_scaling = sqrtf(fmaxf(0.000025f, det_cov / det_cov_plus_h_cov));
+        const float det = det_cov_plus_h_cov;
+        if (det != 0.0f) {
+            const float det_inv = 1.f / det;
+            const float conic[3] = { cov_z * det_inv, -cov_y * det_inv, cov_x * det_inv };
+            const float mid = 0.5f * (cov_x + cov_z);
+            const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+            const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+            const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+            const float px = ndc2Pix(p_proj[0], W), py = ndc2Pix(p_proj[1], H);
+            int xmin, ymin, xmax, ymax;
+            getRect(px, py, (int)my_radius, gx, gy, xmin, ymin, xmax, ymax);
+            if ((xmax - xmin) * (ymax - ymin) != 0) {
+                radius_out = (int)my_radius;
+                rect = make_uint4(xmin, ymin, xmax, ymax);
+                co = make_float4(conic[0], conic[1], conic[2], opac[idx] * h_convolution_scaling);
+                xyd = make_float4(px, py, p_view[2], 1 / p_view[2]);
+            }
+        }
+    }
+    radii[o] = radius_out;
+    g.co[o] = co;
+    g.xyd[o] = xyd;
+    g.rect[o] = rect;
+}
+
+__global__ void k_mark_visible(int P, const float* __restrict__ means, const float* __restrict__ V,
+                               uint8_t* __restrict__ present)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P) return;
+    const float p[3] = { means[3 * idx], means[3 * idx + 1], means[3 * idx + 2] };
+    float pv[3];
+    transformPoint4x3(p, V, pv);
+    present[idx] = pv[2] > 0.2f;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// LDS-resident, depth-ordered list of Gaussians for a workgroup's pixels
+// ------------------------------------------------------------------------------------------------------------
+template <int CG>
+struct List {
+    float2 xy[LCAP];
+    float4 co[LCAP];
+    float invd[LCAP];
+    int xr[LCAP];    // xmin | xmax << 16 (tile units); the pixel's tile column must fall inside
+    int id[LCAP];
+    float feat[LCAP * CG];
+};
+
+// Small path: gather the Gaussians whose tile rect crosses `band`, order by (depth bits, index).
+// Returns n (uniform across the workgroup).  Contains barriers: call from uniform control flow.
+template <int CG>
+__device__ __forceinline__ int build_band_list(List<CG>& L, unsigned long long* s_key, int* s_n, int P, int C,
+                                               int band, const float4* __restrict__ gco,
+                                               const float4* __restrict__ gxyd, const uint4* __restrict__ grect,
+                                               const float* __restrict__ features)
+{
+    const int tid = threadIdx.x;
+    if (tid == 0) *s_n = 0;
+    __syncthreads();
+    if (tid < P) {
+        const uint4 r = grect[tid];
+        if ((int)r.y <= band && band < (int)r.w) {
+            const int slot = atomicAdd(s_n, 1);
+            s_key[slot] = ((unsigned long long)__float_as_uint(gxyd[tid].z) << 32) | (unsigned)tid;
+        }
+    }
+    __syncthreads();
+    const int n = *s_n;
+    if (n == 0) return 0;
+    if (tid < n) {
+        const unsigned long long key = s_key[tid];
+        int rank = 0;
+        for (int j = 0; j < n; j++) rank += (s_key[j] < key) ? 1 : 0;
+        const int id = (int)(unsigned)key;
+        const float4 xyd = gxyd[id];
+        const uint4 r = grect[id];
+        L.xy[rank] = make_float2(xyd.x, xyd.y);
+        L.co[rank] = gco[id];
+        L.invd[rank] = xyd.w;
+        L.xr[rank] = (int)(r.x | (r.z << 16));
+        L.id[rank] = id;
+#pragma unroll
+        for (int ch = 0; ch < CG; ch++) L.feat[rank * CG + ch] = ch < C ? features[id * C + ch] : 0.0f;
+    }
+    __syncthreads();
+    return n;
+}
+
+// Forward compositing of one pixel over n LDS entries (forward.cu:346-386), carrying state across batches.
+template <int CG, bool XF>
+__device__ __forceinline__ void composite_px(const List<CG>& L, int n, float pxf, float pyf, int tx, float& T,
+                                             float (&acc)[CG], float& inv, uint32_t& contributor, uint32_t& last,
+                                             bool& done)
+{
+    for (int k = 0; k < n && !done; k++) {
+        if (XF) {
+            const int xr = L.xr[k];
+            if (tx < (xr & 0xffff) || tx >= (xr >> 16)) continue;  // not in this pixel's tile list
+        }
+        contributor++;
+        const float2 xy = L.xy[k];
+        const float4 co = L.co[k];
+        const float dx = xy.x - pxf, dy = xy.y - pyf;
+        const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+        if (power > 0.0f) continue;
+        const float alpha = fminf(0.99f, co.w * expf_fixed(power));
+        if (alpha < 1.0f / 255.0f) continue;
+        const float test_T = T * (1 - alpha);
+        if (test_T < 0.0001f) {
+            done = true;
+            continue;
+        }
+#pragma unroll
+        for (int ch = 0; ch < CG; ch++) acc[ch] += L.feat[k * CG + ch] * alpha * T;
+        inv += L.invd[k] * alpha * T;
+        T = test_T;
+        last = contributor;
+    }
+}
+
+__device__ __forceinline__ float clamp01(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
+
+struct FwdArgs {
+    int P, C, W, H;
+    unsigned flags;
+    Geom g;
+    const float* features;
+    float* out_color;
+    float* out_invdepth;
+    float* final_T;
+    uint32_t* n_contrib;
+};
+
+// ------------------------------------------------------------------------------------------------------------
+// small path forward: grid (chunks, bands, V).  PPT = 4 -> W % 4 == 0, 16-byte stores; PPT = 1 -> any W.
+// ------------------------------------------------------------------------------------------------------------
+template <int CG, int PPT>
+__global__ __launch_bounds__(256) void k_render_fwd_small(FwdArgs a)
+{
+    __shared__ List<CG> L;
+    __shared__ unsigned long long s_key[LCAP];
+    __shared__ int s_n;
+    const int v = blockIdx.z, band = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    const int P = a.P, C = a.C, W = a.W, H = a.H;
+    const size_t HW = (size_t)H * W;
+    const size_t go = (size_t)v * P;
+    const int n = build_band_list<CG>(L, s_key, &s_n, P, C, band, a.g.co + go, a.g.xyd + go, a.g.rect + go, a.features);
+
+    const int rows = min(TILE, H - band * TILE);
+    const int Nb = rows * W;  // pixels of this band, contiguous in every plane
+    const size_t band0 = (size_t)band * TILE * W;
+    float* outc = a.out_color + (size_t)v * C * HW;
+    float* outi = a.out_invdepth + (size_t)v * HW;
+    const bool do_clamp = a.flags & SKS_CLAMP01;
+    constexpr int CH = FWD_PASSES * 256 * PPT;
+
+#pragma unroll 1
+    for (int pass = 0; pass < FWD_PASSES; pass++) {
+        const int base = chunk * CH + (pass * 256 + tid) * PPT;
+        if (base >= Nb) continue;
+        const size_t pix0 = band0 + base;
+        float T[PPT], inv[PPT], acc[PPT][CG];
+        uint32_t last[PPT];
+#pragma unroll
+        for (int p = 0; p < PPT; p++) {
+            T[p] = 1.0f;
+            inv[p] = 0.0f;
+            last[p] = 0;
+#pragma unroll
+            for (int ch = 0; ch < CG; ch++) acc[p][ch] = 0.0f;
+        }
+        if (n > 0) {
+            const int y = (int)(pix0 / W);
+            const int x0 = (int)(pix0 - (size_t)y * W);
+#pragma unroll
+            for (int p = 0; p < PPT; p++) {
+                uint32_t contributor = 0;
+                bool done = false;
+                composite_px<CG, true>(L, n, (float)(x0 + p), (float)y, (x0 + p) >> 4, T[p], acc[p], inv[p],
+                                       contributor, last[p], done);
+            }
+        }
+        if (PPT == 4) {
+#pragma unroll
+            for (int ch = 0; ch < CG; ch++) {
+                if (ch < C) {
+                    float4 o = make_float4(acc[0][ch], acc[1 % PPT][ch], acc[2 % PPT][ch], acc[3 % PPT][ch]);
+                    if (do_clamp) o = make_float4(clamp01(o.x), clamp01(o.y), clamp01(o.z), clamp01(o.w));
+                    *reinterpret_cast<float4*>(outc + (size_t)ch * HW + pix0) = o;
+                }
+            }
+            *reinterpret_cast<float4*>(outi + pix0) = make_float4(inv[0], inv[1 % PPT], inv[2 % PPT], inv[3 % PPT]);
+            if (a.final_T)
+                *reinterpret_cast<float4*>(a.final_T + (size_t)v * HW + pix0) =
+                    make_float4(T[0], T[1 % PPT], T[2 % PPT], T[3 % PPT]);
+            if (a.n_contrib)
+                *reinterpret_cast<uint4*>(a.n_contrib + (size_t)v * HW + pix0) =
+                    make_uint4(last[0], last[1 % PPT], last[2 % PPT], last[3 % PPT]);
+        } else {
+#pragma unroll
+            for (int ch = 0; ch < CG; ch++)
+                if (ch < C) outc[(size_t)ch * HW + pix0] = do_clamp ? clamp01(acc[0][ch]) : acc[0][ch];
+            outi[pix0] = inv[0];
+            if (a.final_T) a.final_T[(size_t)v * HW + pix0] = T[0];
+            if (a.n_contrib) a.n_contrib[(size_t)v * HW + pix0] = last[0];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// backward compositing core (backward.cu:531-637) for ONE pixel over one LDS batch, back to front.
+// All lanes run the k loop together; per-entry partial sums are reduced over the wavefront and added to the
+// workgroup's LDS accumulators s_acc[k][NVL].
+// ------------------------------------------------------------------------------------------------------------
+template <int CG>
+struct BwdPix {
+    float T, T_final, last_alpha, accum_inv, last_inv, dLi, bgdot;
+    float dL[CG], accum_rec[CG], last_color[CG];
+};
+
+template <int CG, bool XF, bool DFEAT>
+__device__ __forceinline__ void bwd_sweep(const List<CG>& L, int n, int klast /* last accepted LDS index or -1 */,
+                                          float pxf, float pyf, int tx, float ddelx_dx, float ddely_dy,
+                                          BwdPix<CG>& s, float* s_acc)
+{
+    constexpr int NVL = NACC + (DFEAT ? CG : 0);
+    const int lane = threadIdx.x & 63;
+    for (int k = n - 1; k >= 0; k--) {
+        bool act = k <= klast;
+        float dx = 0, dy = 0, G = 0, alpha = 0;
+        float4 co = make_float4(0, 0, 0, 0);
+        if (act) {
+            if (XF) {
+                const int xr = L.xr[k];
+                act = !(tx < (xr & 0xffff) || tx >= (xr >> 16));
+            }
+            if (act) {
+                const float2 xy = L.xy[k];
+                co = L.co[k];
+                dx = xy.x - pxf;
+                dy = xy.y - pyf;
+                const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+                act = !(power > 0.0f);
+                if (act) {
+                    G = expf_fixed(power);
+                    alpha = fminf(0.99f, co.w * G);
+                    act = !(alpha < 1.0f / 255.0f);
+                }
+            }
+        }
+        if (!__any(act)) continue;  // wave-uniform
+        float vals[NVL];
+#pragma unroll
+        for (int j = 0; j < NVL; j++) vals[j] = 0.0f;
+        if (act) {
+            s.T = s.T / (1.f - alpha);
+            const float dchannel_dcolor = alpha * s.T;
+            float dL_dalpha = 0.0f;
+#pragma unroll
+            for (int ch = 0; ch < CG; ch++) {
+                const float c = L.feat[k * CG + ch];
+                s.accum_rec[ch] = s.last_alpha * s.last_color[ch] + (1.f - s.last_alpha) * s.accum_rec[ch];
+                s.last_color[ch] = c;
+                const float dL_dchannel = s.dL[ch];
+                dL_dalpha += (c - s.accum_rec[ch]) * dL_dchannel;
+                if (DFEAT) vals[NACC + ch] = dchannel_dcolor * dL_dchannel;
+            }
+            const float invd = L.invd[k];
+            s.accum_inv = s.last_alpha * s.last_inv + (1.f - s.last_alpha) * s.accum_inv;
+            s.last_inv = invd;
+            dL_dalpha += (invd - s.accum_inv) * s.dLi;
+            vals[6] = dchannel_dcolor * s.dLi;
+            dL_dalpha *= s.T;
+            s.last_alpha = alpha;
+            dL_dalpha += (-s.T_final / (1.f - alpha)) * s.bgdot;
+            const float dL_dG = co.w * dL_dalpha;
+            const float gdx = G * dx, gdy = G * dy;
+            const float dG_ddelx = -gdx * co.x - gdy * co.y;
+            const float dG_ddely = -gdy * co.z - gdx * co.y;
+            vals[0] = dL_dG * dG_ddelx * ddelx_dx;
+            vals[1] = dL_dG * dG_ddely * ddely_dy;
+            vals[2] = -0.5f * gdx * dx * dL_dG;
+            vals[3] = -0.5f * gdx * dy * dL_dG;
+            vals[4] = -0.5f * gdy * dy * dL_dG;
+            vals[5] = G * dL_dalpha;
+        }
+#pragma unroll
+        for (int j = 0; j < NVL; j++) {
+            if (j == 7) continue;
+            const float r = wave_sum(vals[j]);
+            if (lane == 0) atomicAdd(&s_acc[k * NVL + j], r);
+        }
+    }
+}
+
+struct BwdArgs {
+    int P, C, W, H;
+    unsigned flags;
+    Geom g;
+    const float* features;
+    const float* bg;
+    const float* dL_color;
+    const float* dL_invdepth;
+    float* accum;  // (V,P,NACC+C)
+};
+
+// prepass of one pixel over an LDS batch: same walk as the forward; records the LDS index of the last accepted
+// entry (backward.cu:505-506 reads it from n_contrib instead).
+template <int CG, bool XF>
+__device__ __forceinline__ void bwd_prepass(const List<CG>& L, int n, float pxf, float pyf, int tx, float& T,
+                                            float (&acc)[CG], bool want_color, int& klast, bool& done)
+{
+    for (int k = 0; k < n && !done; k++) {
+        if (XF) {
+            const int xr = L.xr[k];
+            if (tx < (xr & 0xffff) || tx >= (xr >> 16)) continue;
+        }
+        const float2 xy = L.xy[k];
+        const float4 co = L.co[k];
+        const float dx = xy.x - pxf, dy = xy.y - pyf;
+        const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+        if (power > 0.0f) continue;
+        const float alpha = fminf(0.99f, co.w * expf_fixed(power));
+        if (alpha < 1.0f / 255.0f) continue;
+        const float test_T = T * (1 - alpha);
+        if (test_T < 0.0001f) {
+            done = true;
+            continue;
+        }
+        if (want_color) {
+#pragma unroll
+            for (int ch = 0; ch < CG; ch++) acc[ch] += L.feat[k * CG + ch] * alpha * T;
+        }
+        T = test_T;
+        klast = k;
+    }
+}
+
+template <int CG>
+__device__ __forceinline__ void bwd_load_pixel(BwdPix<CG>& s, const BwdArgs& a, int v, size_t pix, size_t HW,
+                                               const float (&col)[CG], bool do_clamp, float T_final)
+{
+    s.T = T_final;
+    s.T_final = T_final;
+    s.last_alpha = 0;
+    s.accum_inv = 0;
+    s.last_inv = 0;
+    s.bgdot = 0;
+    const float* dLc = a.dL_color + (size_t)v * a.C * HW + pix;
+#pragma unroll
+    for (int ch = 0; ch < CG; ch++) {
+        float d = ch < a.C ? dLc[(size_t)ch * HW] : 0.0f;
+        // torch.clamp backward passes the gradient where min <= x <= max
+        if (do_clamp && !(col[ch] >= 0.0f && col[ch] <= 1.0f)) d = 0.0f;
+        s.dL[ch] = d;
+        s.accum_rec[ch] = 0;
+        s.last_color[ch] = 0;
+        if (a.bg && ch < a.C) s.bgdot += a.bg[ch] * d;
+    }
+    s.dLi = a.dL_invdepth ? a.dL_invdepth[(size_t)v * HW + pix] : 0.0f;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// small path backward: grid (chunks, bands, V), one pixel per thread per pass
+// ------------------------------------------------------------------------------------------------------------
+template <int CG, bool DFEAT>
+__global__ __launch_bounds__(256) void k_render_bwd_small(BwdArgs a)
+{
+    constexpr int NVL = NACC + (DFEAT ? CG : 0);
+    __shared__ List<CG> L;
+    __shared__ unsigned long long s_key[LCAP];
+    __shared__ float s_acc[LCAP * NVL];
+    __shared__ int s_n;
+    const int v = blockIdx.z, band = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    const int P = a.P, C = a.C, W = a.W, H = a.H;
+    const size_t HW = (size_t)H * W;
+    const size_t go = (size_t)v * P;
+    const int n = build_band_list<CG>(L, s_key, &s_n, P, C, band, a.g.co + go, a.g.xyd + go, a.g.rect + go, a.features);
+    if (n == 0) return;
+    for (int i = tid; i < n * NVL; i += 256) s_acc[i] = 0.0f;
+    __syncthreads();
+
+    const int rows = min(TILE, H - band * TILE);
+    const int Nb = rows * W;
+    const size_t band0 = (size_t)band * TILE * W;
+    const bool do_clamp = a.flags & SKS_CLAMP01;
+    const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);  // backward.cu:527-528
+    constexpr int CH = BWD_PASSES * 256;
+
+#pragma unroll 1
+    for (int pass = 0; pass < BWD_PASSES; pass++) {
+        const int base = chunk * CH + pass * 256 + tid;
+        const bool valid = base < Nb;
+        const size_t pix = band0 + (valid ? base : 0);
+        const int y = (int)(pix / W);
+        const int x = (int)(pix - (size_t)y * W);
+        const int tx = x >> 4;
+        float T = 1.0f;
+        float col[CG];
+#pragma unroll
+        for (int ch = 0; ch < CG; ch++) col[ch] = 0.0f;
+        int klast = -1;
+        if (valid) {
+            bool done = false;
+            bwd_prepass<CG, true>(L, n, (float)x, (float)y, tx, T, col, do_clamp, klast, done);
+        }
+        if (!__any(klast >= 0)) continue;  // nothing composited by this wavefront in this pass
+        BwdPix<CG> s;
+        if (klast >= 0) bwd_load_pixel<CG>(s, a, v, pix, HW, col, do_clamp, T);
+        bwd_sweep<CG, true, DFEAT>(L, n, klast, (float)x, (float)y, tx, ddelx_dx, ddely_dy, s, s_acc);
+    }
+    __syncthreads();
+    const int NVS = NACC + C;
+    for (int i = tid; i < n * NVL; i += 256) {
+        const int k = i / NVL, j = i - k * NVL;
+        if (j >= NACC + C) continue;
+        const float val = s_acc[i];
+        if (val != 0.0f) atomicAdd(&a.accum[((size_t)v * P + L.id[k]) * NVS + j], val);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// geometry backward: computeCov2DCUDA (backward.cu:147-326) + preprocessCUDA (:398-449) + computeCov3D
+// (:330-393) fused; consumes and clears the accumulators.  SH backward (:443-444) intentionally not reproduced
+// (SURVEY quirk Q5): dL_dfeatures is the true dL_dcolors of backward.cu:593.
+// ------------------------------------------------------------------------------------------------------------
+struct GeomBwdArgs {
+    int P, C, W, H;
+    unsigned flags;
+    const float* vms;
+    const float* pms;
+    const float* means;
+    const float* opac;
+    const float* scales;
+    const float* rots;
+    const float* cov3Dp;
+    float smod;
+    const int* radii;
+    float* accum;
+    float* dmeans3D;
+    float* dmeans2D;
+    float* dopacity;
+    float* dscales;
+    float* drots;
+    float* dcov3D;
+    float* dfeat;
+};
+
+__device__ __forceinline__ float sq(float x) { return x * x; }
+
+__global__ __launch_bounds__(256) void k_geom_bwd(GeomBwdArgs a, ViewTan vt)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int v = blockIdx.y;
+    if (idx >= a.P) return;
+    const size_t o = (size_t)v * a.P + idx;
+    const int NVS = NACC + a.C;
+    float* acc = a.accum + o * NVS;
+    float g[NACC];
+#pragma unroll
+    for (int j = 0; j < NACC; j++) {
+        g[j] = acc[j];
+        acc[j] = 0.0f;
+    }
+    if (a.dfeat) {
+        for (int ch = 0; ch < a.C; ch++) {
+            a.dfeat[o * a.C + ch] = acc[NACC + ch];
+            acc[NACC + ch] = 0.0f;
+        }
+    }
+    float dmean[3] = { 0, 0, 0 }, dcov[6] = { 0, 0, 0, 0, 0, 0 }, dscale[3] = { 0, 0, 0 }, dq[4] = { 0, 0, 0, 0 };
+    float dop = g[5];
+    const float dm2x = g[0], dm2y = g[1];
+
+    if (a.radii[o] > 0) {
+        const float* V = a.vms + 16 * v;
+        const float* proj = a.pms + 16 * v;
+        const float tan_fovx = vt.x[v], tan_fovy = vt.y[v];
+        const float h_y = a.H / (2.0f * tan_fovy);
+        const float h_x = a.W / (2.0f * tan_fovx);
+        const float mean[3] = { a.means[3 * idx], a.means[3 * idx + 1], a.means[3 * idx + 2] };
+        float cov3D[6];
+        float sc[3] = { 0, 0, 0 }, q[4] = { 1, 0, 0, 0 };
+        if (a.cov3Dp) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) cov3D[i] = a.cov3Dp[6 * idx + i];
+        } else {
+            sc[0] = a.scales[3 * idx]; sc[1] = a.scales[3 * idx + 1]; sc[2] = a.scales[3 * idx + 2];
+            q[0] = a.rots[4 * idx]; q[1] = a.rots[4 * idx + 1]; q[2] = a.rots[4 * idx + 2]; q[3] = a.rots[4 * idx + 3];
+            computeCov3D(sc, a.smod, q, cov3D);
+        }
+        const float dL_dconic[3] = { g[2], g[3], g[4] };
+        Cov2D c;
+        cov2d(mean, h_x, h_y, tan_fovx, tan_fovy, cov3D, V, c);
+        const float* t = c.t;
+        const float x_grad_mul = (c.txtz < -c.limx || c.txtz > c.limx) ? 0 : 1;
+        const float y_grad_mul = (c.tytz < -c.limy || c.tytz > c.limy) ? 0 : 1;
+        const M3& T = c.T;
+        const M3& Wm = c.W;
+        const M3& Vrk = c.Vrk;
+        float c_xx = c.cov.m[0][0], c_xy = c.cov.m[0][1], c_yy = c.cov.m[1][1];
+        constexpr float h_var = 0.3f;
+        float d_inside_root = 0.f;
+        const bool aa = a.flags & SKS_ANTIALIASING;
+        if (aa) {
+            const float det_cov = c_xx * c_yy - c_xy * c_xy;
+            c_xx += h_var;
+            c_yy += h_var;
+            const float det_cov_plus_h_cov = c_xx * c_yy - c_xy * c_xy;
+            const float h_convolution_scaling = sqrtf(fmaxf(0.000025f, det_cov / det_cov_plus_h_cov));
+            const float dL_dopacity_v = dop;
+            const float d_h_convolution_scaling = dL_dopacity_v * a.opac[idx];
+            dop = dL_dopacity_v * h_convolution_scaling;
+            d_inside_root = (det_cov / det_cov_plus_h_cov) <= 0.000025f ? 0.f : d_h_convolution_scaling / (2 * h_convolution_scaling);
+        } else {
+            c_xx += h_var;
+            c_yy += h_var;
+        }
+        float dL_dc_xx = 0, dL_dc_xy = 0, dL_dc_yy = 0;
+        if (aa) {
+            const float x = c_xx, y = c_yy, z = c_xy, w = h_var;
+            const float denom_f = d_inside_root / sq(w * w + w * (x + y) + x * y - z * z);
+            dL_dc_xx = w * (w * y + y * y + z * z) * denom_f;
+            dL_dc_yy = w * (w * x + x * x + z * z) * denom_f;
+            dL_dc_xy = -2.f * w * z * (w + x + y) * denom_f;
+        }
+        const float denom = c_xx * c_yy - c_xy * c_xy;
+        const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+        if (denom2inv != 0) {
+            dL_dc_xx += denom2inv * (-c_yy * c_yy * dL_dconic[0] + 2 * c_xy * c_yy * dL_dconic[1] + (denom - c_xx * c_yy) * dL_dconic[2]);
+            dL_dc_yy += denom2inv * (-c_xx * c_xx * dL_dconic[2] + 2 * c_xx * c_xy * dL_dconic[1] + (denom - c_xx * c_yy) * dL_dconic[0]);
+            dL_dc_xy += denom2inv * 2 * (c_xy * c_yy * dL_dconic[0] - (denom + 2 * c_xy * c_xy) * dL_dconic[1] + c_xx * c_xy * dL_dconic[2]);
+            dcov[0] = (T.m[0][0] * T.m[0][0] * dL_dc_xx + T.m[0][0] * T.m[1][0] * dL_dc_xy + T.m[1][0] * T.m[1][0] * dL_dc_yy);
+            dcov[3] = (T.m[0][1] * T.m[0][1] * dL_dc_xx + T.m[0][1] * T.m[1][1] * dL_dc_xy + T.m[1][1] * T.m[1][1] * dL_dc_yy);
+            dcov[5] = (T.m[0][2] * T.m[0][2] * dL_dc_xx + T.m[0][2] * T.m[1][2] * dL_dc_xy + T.m[1][2] * T.m[1][2] * dL_dc_yy);
+            dcov[1] = 2 * T.m[0][0] * T.m[0][1] * dL_dc_xx + (T.m[0][0] * T.m[1][1] + T.m[0][1] * T.m[1][0]) * dL_dc_xy + 2 * T.m[1][0] * T.m[1][1] * dL_dc_yy;
+            dcov[2] = 2 * T.m[0][0] * T.m[0][2] * dL_dc_xx + (T.m[0][0] * T.m[1][2] + T.m[0][2] * T.m[1][0]) * dL_dc_xy + 2 * T.m[1][0] * T.m[1][2] * dL_dc_yy;
+            dcov[4] = 2 * T.m[0][2] * T.m[0][1] * dL_dc_xx + (T.m[0][1] * T.m[1][2] + T.m[0][2] * T.m[1][1]) * dL_dc_xy + 2 * T.m[1][1] * T.m[1][2] * dL_dc_yy;
+        }
+        const float dL_dT00 = 2 * (T.m[0][0] * Vrk.m[0][0] + T.m[0][1] * Vrk.m[0][1] + T.m[0][2] * Vrk.m[0][2]) * dL_dc_xx +
+                              (T.m[1][0] * Vrk.m[0][0] + T.m[1][1] * Vrk.m[0][1] + T.m[1][2] * Vrk.m[0][2]) * dL_dc_xy;
+        const float dL_dT01 = 2 * (T.m[0][0] * Vrk.m[1][0] + T.m[0][1] * Vrk.m[1][1] + T.m[0][2] * Vrk.m[1][2]) * dL_dc_xx +
+                              (T.m[1][0] * Vrk.m[1][0] + T.m[1][1] * Vrk.m[1][1] + T.m[1][2] * Vrk.m[1][2]) * dL_dc_xy;
+        const float dL_dT02 = 2 * (T.m[0][0] * Vrk.m[2][0] + T.m[0][1] * Vrk.m[2][1] + T.m[0][2] * Vrk.m[2][2]) * dL_dc_xx +
+                              (T.m[1][0] * Vrk.m[2][0] + T.m[1][1] * Vrk.m[2][1] + T.m[1][2] * Vrk.m[2][2]) * dL_dc_xy;
+        const float dL_dT10 = 2 * (T.m[1][0] * Vrk.m[0][0] + T.m[1][1] * Vrk.m[0][1] + T.m[1][2] * Vrk.m[0][2]) * dL_dc_yy +
+                              (T.m[0][0] * Vrk.m[0][0] + T.m[0][1] * Vrk.m[0][1] + T.m[0][2] * Vrk.m[0][2]) * dL_dc_xy;
+        const float dL_dT11 = 2 * (T.m[1][0] * Vrk.m[1][0] + T.m[1][1] * Vrk.m[1][1] + T.m[1][2] * Vrk.m[1][2]) * dL_dc_yy +
+                              (T.m[0][0] * Vrk.m[1][0] + T.m[0][1] * Vrk.m[1][1] + T.m[0][2] * Vrk.m[1][2]) * dL_dc_xy;
+        const float dL_dT12 = 2 * (T.m[1][0] * Vrk.m[2][0] + T.m[1][1] * Vrk.m[2][1] + T.m[1][2] * Vrk.m[2][2]) * dL_dc_yy +
+                              (T.m[0][0] * Vrk.m[2][0] + T.m[0][1] * Vrk.m[2][1] + T.m[0][2] * Vrk.m[2][2]) * dL_dc_xy;
+        const float dL_dJ00 = Wm.m[0][0] * dL_dT00 + Wm.m[0][1] * dL_dT01 + Wm.m[0][2] * dL_dT02;
+        const float dL_dJ02 = Wm.m[2][0] * dL_dT00 + Wm.m[2][1] * dL_dT01 + Wm.m[2][2] * dL_dT02;
+        const float dL_dJ11 = Wm.m[1][0] * dL_dT10 + Wm.m[1][1] * dL_dT11 + Wm.m[1][2] * dL_dT12;
+        const float dL_dJ12 = Wm.m[2][0] * dL_dT10 + Wm.m[2][1] * dL_dT11 + Wm.m[2][2] * dL_dT12;
+        const float tz = 1.f / t[2];
+        const float tz2 = tz * tz;
+        const float tz3 = tz2 * tz;
+        const float dL_dtx = x_grad_mul * -h_x * tz2 * dL_dJ02;
+        const float dL_dty = y_grad_mul * -h_y * tz2 * dL_dJ12;
+        float dL_dtz = -h_x * tz2 * dL_dJ00 - h_y * tz2 * dL_dJ11 + (2 * h_x * t[0]) * tz3 * dL_dJ02 + (2 * h_y * t[1]) * tz3 * dL_dJ12;
+        dL_dtz -= g[6] / (t[2] * t[2]);  // inverse-depth term, backward.cu:314-315 (always taken)
+        // transformVec4x3Transpose, auxiliary.h:101-109
+        dmean[0] = V[0] * dL_dtx + V[1] * dL_dty + V[2] * dL_dtz;
+        dmean[1] = V[4] * dL_dtx + V[5] * dL_dty + V[6] * dL_dtz;
+        dmean[2] = V[8] * dL_dtx + V[9] * dL_dty + V[10] * dL_dtz;
+        // preprocessCUDA backward, backward.cu:423-440
+        float m_hom[4];
+        transformPoint4x4(mean, proj, m_hom);
+        const float m_w = 1.0f / (m_hom[3] + 0.0000001f);
+        const float mul1 = (proj[0] * mean[0] + proj[4] * mean[1] + proj[8] * mean[2] + proj[12]) * m_w * m_w;
+        const float mul2 = (proj[1] * mean[0] + proj[5] * mean[1] + proj[9] * mean[2] + proj[13]) * m_w * m_w;
+        dmean[0] += (proj[0] * m_w - proj[3] * mul1) * dm2x + (proj[1] * m_w - proj[3] * mul2) * dm2y;
+        dmean[1] += (proj[4] * m_w - proj[7] * mul1) * dm2x + (proj[5] * m_w - proj[7] * mul2) * dm2y;
+        dmean[2] += (proj[8] * m_w - proj[11] * mul1) * dm2x + (proj[9] * m_w - proj[11] * mul2) * dm2y;
+        // computeCov3D backward, backward.cu:330-393
+        if (!a.cov3Dp) {
+            const float r = q[0], x = q[1], y = q[2], z = q[3];
+            const M3 R = quatR(q);
+            M3 S = {};
+            const float s[3] = { a.smod * sc[0], a.smod * sc[1], a.smod * sc[2] };
+            S.m[0][0] = s[0]; S.m[1][1] = s[1]; S.m[2][2] = s[2];
+            const M3 M = m3mul(S, R);
+            M3 dS;
+            dS.m[0][0] = dcov[0]; dS.m[0][1] = 0.5f * dcov[1]; dS.m[0][2] = 0.5f * dcov[2];
+            dS.m[1][0] = 0.5f * dcov[1]; dS.m[1][1] = dcov[3]; dS.m[1][2] = 0.5f * dcov[4];
+            dS.m[2][0] = 0.5f * dcov[2]; dS.m[2][1] = 0.5f * dcov[4]; dS.m[2][2] = dcov[5];
+            M3 M2;
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++)
+#pragma unroll
+                for (int rr = 0; rr < 3; rr++) M2.m[cc][rr] = 2.0f * M.m[cc][rr];
+            const M3 dL_dM = m3mul(M2, dS);
+            const M3 Rt = m3T(R);
+            M3 dMt = m3T(dL_dM);
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                dscale[k] = Rt.m[k][0] * dMt.m[k][0] + Rt.m[k][1] * dMt.m[k][1] + Rt.m[k][2] * dMt.m[k][2];
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+#pragma unroll
+                for (int rr = 0; rr < 3; rr++) dMt.m[k][rr] *= s[k];
+            dq[0] = 2 * z * (dMt.m[0][1] - dMt.m[1][0]) + 2 * y * (dMt.m[2][0] - dMt.m[0][2]) + 2 * x * (dMt.m[1][2] - dMt.m[2][1]);
+            dq[1] = 2 * y * (dMt.m[1][0] + dMt.m[0][1]) + 2 * z * (dMt.m[2][0] + dMt.m[0][2]) + 2 * r * (dMt.m[1][2] - dMt.m[2][1]) - 4 * x * (dMt.m[2][2] + dMt.m[1][1]);
+            dq[2] = 2 * x * (dMt.m[1][0] + dMt.m[0][1]) + 2 * r * (dMt.m[2][0] - dMt.m[0][2]) + 2 * z * (dMt.m[1][2] + dMt.m[2][1]) - 4 * y * (dMt.m[2][2] + dMt.m[0][0]);
+            dq[3] = 2 * r * (dMt.m[0][1] - dMt.m[1][0]) + 2 * x * (dMt.m[2][0] + dMt.m[0][2]) + 2 * y * (dMt.m[1][2] + dMt.m[2][1]) - 4 * z * (dMt.m[1][1] + dMt.m[0][0]);
+        }
+    }
+    a.dmeans3D[3 * o] = dmean[0]; a.dmeans3D[3 * o + 1] = dmean[1]; a.dmeans3D[3 * o + 2] = dmean[2];
+    a.dmeans2D[3 * o] = dm2x; a.dmeans2D[3 * o + 1] = dm2y; a.dmeans2D[3 * o + 2] = 0.0f;
+    a.dopacity[o] = dop;
+    if (a.dcov3D) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) a.dcov3D[6 * o + i] = dcov[i];
+    }
+    if (a.dscales) { a.dscales[3 * o] = dscale[0]; a.dscales[3 * o + 1] = dscale[1]; a.dscales[3 * o + 2] = dscale[2]; }
+    if (a.drots) { a.drots[4 * o] = dq[0]; a.drots[4 * o + 1] = dq[1]; a.drots[4 * o + 2] = dq[2]; a.drots[4 * o + 3] = dq[3]; }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// binned path: tile-centric replacement of InclusiveSum + duplicateWithKeys + DeviceRadixSort::SortPairs +
+// identifyTileRanges (rasterizer_impl.cu:70-138, 280-320).  Per tile the reference's sorted order is
+// (depth bits, Gaussian index) ascending (stable LSD sort, index-major emission), reproduced exactly.
+// ------------------------------------------------------------------------------------------------------------
+__global__ void k_bin_count(int P, int NT, int gx, const uint4* __restrict__ rect, uint32_t* __restrict__ count)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y;
+    if (idx >= P) return;
+    const uint4 r = rect[(size_t)v * P + idx];
+    for (unsigned y = r.y; y < r.w; y++)
+        for (unsigned x = r.x; x < r.z; x++) atomicAdd(&count[(size_t)v * NT + y * gx + x], 1u);
+}
+
+// one 1024-thread workgroup per view: exclusive scan over tiles in tile-id order
+__global__ __launch_bounds__(1024) void k_bin_scan(int NT, const uint32_t* __restrict__ count, uint32_t* __restrict__ cursor,
+                                                    uint2* __restrict__ ranges, int* __restrict__ nrend, int V,
+                                                    int* __restrict__ nrend_user)
+{
+    __shared__ uint32_t s_part[1024];
+    const int v = blockIdx.x, tid = threadIdx.x;
+    const uint32_t* cnt = count + (size_t)v * NT;
+    const int per = (NT + 1023) / 1024;
+    const int b = tid * per, e = min(NT, b + per);
+    uint32_t sum = 0;
+    for (int i = b; i < e; i++) sum += cnt[i];
+    s_part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+        uint32_t t = tid >= off ? s_part[tid - off] : 0;
+        __syncthreads();
+        s_part[tid] += t;
+        __syncthreads();
+    }
+    uint32_t run = tid ? s_part[tid - 1] : 0;
+    for (int i = b; i < e; i++) {
+        const uint32_t c = cnt[i];
+        cursor[(size_t)v * NT + i] = run;
+        ranges[(size_t)v * NT + i] = c ? make_uint2(run, run + c) : make_uint2(0, 0);  // memset-0 for empty tiles
+        run += c;
+    }
+    if (tid == 1023) {
+        nrend[v] = (int)s_part[1023];
+        if (nrend_user) nrend_user[v] = (int)s_part[1023];
+    }
+}
+
+__global__ void k_bin_scatter(int P, int NT, int gx, size_t cap, const uint4* __restrict__ rect,
+                              const float4* __restrict__ xyd, uint32_t* __restrict__ cursor,
+                              unsigned long long* __restrict__ keys, int* __restrict__ overflow)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y;
+    if (idx >= P) return;
+    const size_t o = (size_t)v * P + idx;
+    const uint4 r = rect[o];
+    const unsigned long long key = ((unsigned long long)__float_as_uint(xyd[o].z) << 32) | (unsigned)idx;
+    for (unsigned y = r.y; y < r.w; y++)
+        for (unsigned x = r.x; x < r.z; x++) {
+            const uint32_t slot = atomicAdd(&cursor[(size_t)v * NT + y * gx + x], 1u);
+            if (slot < cap) keys[(size_t)v * cap + slot] = key;
+            else *overflow = 1;
+        }
+}
+
+// per-tile ascending sort of 64-bit keys; all-ascending bitonic network with virtual +inf padding.
+constexpr int SORT_LDS = 2048;
+__global__ __launch_bounds__(256) void k_bin_sort(int NT, size_t cap, const uint2* __restrict__ ranges,
+                                                   unsigned long long* __restrict__ keys)
+{
+    __shared__ unsigned long long s[SORT_LDS];
+    const int t = blockIdx.x, v = blockIdx.y, tid = threadIdx.x;
+    const uint2 r = ranges[(size_t)v * NT + t];
+    if (r.y <= r.x + 1 || r.y > cap) return;
+    const int n = (int)(r.y - r.x);
+    unsigned long long* g = keys + (size_t)v * cap + r.x;
+    unsigned long long* a = g;
+    const bool in_lds = n <= SORT_LDS;
+    if (in_lds) {
+        for (int i = tid; i < n; i += 256) s[i] = g[i];
+        a = s;
+        __syncthreads();
+    }
+    int N = 1;
+    while (N < n) N <<= 1;
+    for (int k = 2; k <= N; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < N; i += 256) {
+                const int p = (j == (k >> 1)) ? (i ^ (k - 1)) : (i ^ j);  // flip on the first sub-step, then disperse
+                if (p > i && p < n) {
+                    const unsigned long long x = a[i], y = a[p];
+                    if (x > y) { a[i] = y; a[p] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (in_lds)
+        for (int i = tid; i < n; i += 256) g[i] = s[i];
+}
+
+__global__ void k_export_lists(int NT, size_t cap, const uint2* __restrict__ ranges, const unsigned long long* __restrict__ keys,
+                               const int* __restrict__ nrend, uint32_t* __restrict__ point_list, uint32_t* __restrict__ out_ranges)
+{
+    const int v = blockIdx.y;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < (size_t)NT) {
+        const uint2 r = ranges[(size_t)v * NT + i];
+        out_ranges[((size_t)v * NT + i) * 2] = r.x;
+        out_ranges[((size_t)v * NT + i) * 2 + 1] = r.y;
+    }
+    if (i < cap) point_list[(size_t)v * cap + i] = i < (size_t)nrend[v] ? (uint32_t)keys[(size_t)v * cap + i] : 0u;
+}
+
+// stage one batch of a tile's sorted entries into LDS (forward.cu:335-343 / backward.cu:536-548)
+template <int CG>
+__device__ __forceinline__ void stage_batch(List<CG>& L, int cnt, const unsigned long long* __restrict__ keys, int P, int C,
+                                            const float4* __restrict__ gco, const float4* __restrict__ gxyd,
+                                            const float* __restrict__ features)
+{
+    const int tid = threadIdx.x;
+    if (tid < cnt) {
+        const int id = (int)(unsigned)keys[tid];
+        const float4 xyd = gxyd[id];
+        L.xy[tid] = make_float2(xyd.x, xyd.y);
+        L.co[tid] = gco[id];
+        L.invd[tid] = xyd.w;
+        L.id[tid] = id;
+#pragma unroll
+        for (int ch = 0; ch < CG; ch++) L.feat[tid * CG + ch] = ch < C ? features[id * C + ch] : 0.0f;
+    }
+}
+
+struct BinView {
+    const uint2* ranges;
+    const unsigned long long* keys;
+    size_t cap;
+    int NT;
+};
+
+// binned forward: grid (Tx, Ty, V), thread = pixel (forward.cu:278-401)
+template <int CG>
+__global__ __launch_bounds__(256) void k_render_fwd_binned(FwdArgs a, BinView b)
+{
+    __shared__ List<CG> L;
+    const int v = blockIdx.z, tid = threadIdx.x;
+    const int P = a.P, C = a.C, W = a.W, H = a.H;
+    const size_t HW = (size_t)H * W;
+    const size_t go = (size_t)v * P;
+    const int gx = gridDim.x;
+    const int x = blockIdx.x * TILE + (tid & 15), y = blockIdx.y * TILE + (tid >> 4);
+    const bool inside = x < W && y < H;
+    const uint2 range = b.ranges[(size_t)v * b.NT + blockIdx.y * gx + blockIdx.x];
+    const unsigned long long* keys = b.keys + (size_t)v * b.cap;
+    const int total = (int)(min((size_t)range.y, b.cap) - min((size_t)range.x, b.cap));
+    float T = 1.0f, inv = 0.0f, acc[CG];
+#pragma unroll
+    for (int ch = 0; ch < CG; ch++) acc[ch] = 0.0f;
+    uint32_t contributor = 0, last = 0;
+    bool done = !inside;
+    for (int off = 0; off < total; off += LCAP) {
+        if (__syncthreads_count(done) == 256) break;
+        const int cnt = min(LCAP, total - off);
+        stage_batch<CG>(L, cnt, keys + range.x + off, P, C, a.g.co + go, a.g.xyd + go, a.features);
+        __syncthreads();
+        composite_px<CG, false>(L, cnt, (float)x, (float)y, 0, T, acc, inv, contributor, last, done);
+    }
+    if (inside) {
+        const size_t pix = (size_t)y * W + x;
+        const bool do_clamp = a.flags & SKS_CLAMP01;
+        float* outc = a.out_color + (size_t)v * C * HW + pix;
+#pragma unroll
+        for (int ch = 0; ch < CG; ch++)
+            if (ch < C) outc[(size_t)ch * HW] = do_clamp ? clamp01(acc[ch]) : acc[ch];
+        a.out_invdepth[(size_t)v * HW + pix] = inv;
+        if (a.final_T) a.final_T[(size_t)v * HW + pix] = T;
+        if (a.n_contrib) a.n_contrib[(size_t)v * HW + pix] = last;
+    }
+}
+
+// binned backward: grid (Tx, Ty, V), thread = pixel (backward.cu:452-638)
+template <int CG, bool DFEAT>
+__global__ __launch_bounds__(256) void k_render_bwd_binned(BwdArgs a, BinView b)
+{
+    constexpr int NVL = NACC + (DFEAT ? CG : 0);
+    __shared__ List<CG> L;
+    __shared__ float s_acc[LCAP * NVL];
+    const int v = blockIdx.z, tid = threadIdx.x;
+    const int P = a.P, C = a.C, W = a.W, H = a.H;
+    const size_t HW = (size_t)H * W;
+    const size_t go = (size_t)v * P;
+    const int gx = gridDim.x;
+    const uint2 range = b.ranges[(size_t)v * b.NT + blockIdx.y * gx + blockIdx.x];
+    const int total = (int)(min((size_t)range.y, b.cap) - min((size_t)range.x, b.cap));
+    if (total == 0) return;
+    const unsigned long long* keys = b.keys + (size_t)v * b.cap + range.x;
+    const int x = blockIdx.x * TILE + (tid & 15), y = blockIdx.y * TILE + (tid >> 4);
+    const bool inside = x < W && y < H;
+    const size_t pix = inside ? (size_t)y * W + x : 0;
+    const bool do_clamp = a.flags & SKS_CLAMP01;
+    const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);
+    const int NVS = NACC + C;
+
+    // pass 1: re-composite front to back to recover T_final and the last contributor
+    float T = 1.0f, col[CG];
+#pragma unroll
+    for (int ch = 0; ch < CG; ch++) col[ch] = 0.0f;
+    int glast = -1;  // global (tile-list) index of the last accepted entry
+    bool done = !inside;
+    for (int off = 0; off < total; off += LCAP) {
+        if (__syncthreads_count(done) == 256) break;
+        const int cnt = min(LCAP, total - off);
+        stage_batch<CG>(L, cnt, keys + off, P, C, a.g.co + go, a.g.xyd + go, a.features);
+        __syncthreads();
+        int klast = -1;
+        bwd_prepass<CG, false>(L, cnt, (float)x, (float)y, 0, T, col, do_clamp, klast, done);
+        if (klast >= 0) glast = off + klast;
+    }
+    __syncthreads();
+    BwdPix<CG> s;
+    if (glast >= 0) bwd_load_pixel<CG>(s, a, v, pix, HW, col, do_clamp, T);
+    // pass 2: back to front over the batches
+    const int nb = (total + LCAP - 1) / LCAP;
+    for (int bi = nb - 1; bi >= 0; bi--) {
+        const int off = bi * LCAP;
+        const int cnt = min(LCAP, total - off);
+        stage_batch<CG>(L, cnt, keys + off, P, C, a.g.co + go, a.g.xyd + go, a.features);
+        for (int i = tid; i < cnt * NVL; i += 256) s_acc[i] = 0.0f;
+        __syncthreads();
+        bwd_sweep<CG, false, DFEAT>(L, cnt, glast - off, (float)x, (float)y, 0, ddelx_dx, ddely_dy, s, s_acc);
+        __syncthreads();
+        for (int i = tid; i < cnt * NVL; i += 256) {
+            const int k = i / NVL, j = i - k * NVL;
+            if (j >= NACC + C) continue;
+            const float val = s_acc[i];
+            if (val != 0.0f) atomicAdd(&a.accum[((size_t)v * P + L.id[k]) * NVS + j], val);
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------------
+inline int pick_cg(int C) { return C <= 4 ? 4 : C <= 16 ? 16 : C <= 20 ? 20 : 32; }
+
+int check_common(int V, int P, int C, int W, int H)
+{
+    if (V < 1 || V > SKS_MAX_VIEWS) return fail(-1, "V=%d out of range [1,%d]", V, SKS_MAX_VIEWS);
+    if (P < 0) return fail(-1, "P=%d negative", P);
+    if (C < 1 || C > SKS_MAX_CHANNELS) return fail(-1, "C=%d out of range [1,%d]", C, SKS_MAX_CHANNELS);
+    if (W < 1 || H < 1 || W > 65535 * TILE || H > 65535 * TILE) return fail(-1, "image %dx%d out of range", W, H);
+    return 0;
+}
+
+template <int CG>
+void launch_fwd_small(const FwdArgs& a, int V, int gy, hipStream_t st)
+{
+    const int bandpx = TILE * a.W;
+    if (a.W % 4 == 0) {
+        dim3 grid((bandpx + FWD_PASSES * 1024 - 1) / (FWD_PASSES * 1024), gy, V);
+        hipLaunchKernelGGL((k_render_fwd_small<CG, 4>), grid, dim3(256), 0, st, a);
+    } else {
+        dim3 grid((bandpx + FWD_PASSES * 256 - 1) / (FWD_PASSES * 256), gy, V);
+        hipLaunchKernelGGL((k_render_fwd_small<CG, 1>), grid, dim3(256), 0, st, a);
+    }
+}
+
+template <int CG>
+void launch_bwd_small(const BwdArgs& a, int V, int gy, bool dfeat, hipStream_t st)
+{
+    const int bandpx = TILE * a.W;
+    dim3 grid((bandpx + BWD_PASSES * 256 - 1) / (BWD_PASSES * 256), gy, V);
+    if (dfeat) hipLaunchKernelGGL((k_render_bwd_small<CG, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_render_bwd_small<CG, false>), grid, dim3(256), 0, st, a);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* sks_last_error(void) { return g_err; }
+int sks_version(void) { return 1; }
+
+int sks_scratch_bytes(int V, int P, int C, int W, int H, size_t bin_capacity, size_t* geom, size_t* binning, size_t* accum)
+{
+    if (int rc = check_common(V, P, C, W, H)) return rc;
+    const int NT = ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
+    if (geom) *geom = geom_bytes(V, P > 0 ? P : 1);
+    if (binning) *binning = bin_bytes(V, NT, bin_capacity);
+    if (accum) *accum = (size_t)V * (P > 0 ? P : 1) * (NACC + C) * sizeof(float);
+    return 0;
+}
+
+int sks_forward(int V, int P, int C, int W, int H, const float* viewmatrix, const float* projmatrix,
+                const float* tanfovx, const float* tanfovy, const float* means3D, const float* features,
+                const float* opacities, const float* scales, const float* rotations, const float* cov3D_precomp,
+                float scale_modifier, unsigned flags, float* out_color, float* out_invdepth, int* radii, void* geom,
+                void* binning, size_t bin_capacity, int* num_rendered_dev, float* final_T, uint32_t* n_contrib,
+                void* stream)
+{
+    if (int rc = check_common(V, P, C, W, H)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (!out_color || !out_invdepth) return fail(-2, "out_color / out_invdepth must be provided");
+    const size_t HW = (size_t)H * W;
+    if (P == 0) {  // rasterize_points.cu:88: nothing rendered, outputs stay zero
+        HIP_TRY(hipMemsetAsync(out_color, 0, (size_t)V * C * HW * 4, st));
+        HIP_TRY(hipMemsetAsync(out_invdepth, 0, (size_t)V * HW * 4, st));
+        if (final_T) return fail(-2, "final_T not available for P == 0");
+        return 0;
+    }
+    if (!viewmatrix || !projmatrix || !tanfovx || !tanfovy || !means3D || !features || !opacities || !radii || !geom)
+        return fail(-2, "missing required pointer");
+    if (!cov3D_precomp && (!scales || !rotations)) return fail(-2, "need scales+rotations or cov3D_precomp");
+    ViewTan vt;
+    for (int v = 0; v < V; v++) { vt.x[v] = tanfovx[v]; vt.y[v] = tanfovy[v]; }
+    Geom g = geom_from(geom, V, P);
+    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE, NT = gx * gy;
+
+    hipLaunchKernelGGL(k_geom_fwd, dim3((P + 255) / 256, V), dim3(256), 0, st, P, W, H, vt, viewmatrix, projmatrix,
+                       means3D, opacities, scales, rotations, cov3D_precomp, scale_modifier, flags, g, radii);
+    STAGE_CHECK("geometry");
+
+    FwdArgs a{ P, C, W, H, flags, g, features, out_color, out_invdepth, final_T, n_contrib };
+    const int cg = pick_cg(C);
+    const bool small = P <= SKS_SMALL_P && !(flags & SKS_FORCE_BINNED);
+    if (small) {
+        switch (cg) {
+            case 4: launch_fwd_small<4>(a, V, gy, st); break;
+            case 16: launch_fwd_small<16>(a, V, gy, st); break;
+            case 20: launch_fwd_small<20>(a, V, gy, st); break;
+            default: launch_fwd_small<32>(a, V, gy, st); break;
+        }
+        STAGE_CHECK("render(small)");
+        return 0;
+    }
+    if (!binning) return fail(-2, "binned path needs a binning buffer");
+    Bin b = bin_from(binning, V, NT, bin_capacity);
+    HIP_TRY(hipMemsetAsync(b.count, 0, (size_t)V * NT * 4, st));
+    HIP_TRY(hipMemsetAsync(b.nrend + V, 0, 4, st));
+    hipLaunchKernelGGL(k_bin_count, dim3((P + 255) / 256, V), dim3(256), 0, st, P, NT, gx, g.rect, b.count);
+    hipLaunchKernelGGL(k_bin_scan, dim3(V), dim3(1024), 0, st, NT, b.count, b.cursor, b.ranges, b.nrend, V, num_rendered_dev);
+    hipLaunchKernelGGL(k_bin_scatter, dim3((P + 255) / 256, V), dim3(256), 0, st, P, NT, gx, bin_capacity, g.rect, g.xyd,
+                       b.cursor, b.keys, b.nrend + V);
+    hipLaunchKernelGGL(k_bin_sort, dim3(NT, V), dim3(256), 0, st, NT, bin_capacity, b.ranges, b.keys);
+    STAGE_CHECK("binning");
+    BinView bv{ b.ranges, b.keys, bin_capacity, NT };
+    dim3 grid(gx, gy, V);
+    switch (cg) {
+        case 4: hipLaunchKernelGGL((k_render_fwd_binned<4>), grid, dim3(256), 0, st, a, bv); break;
+        case 16: hipLaunchKernelGGL((k_render_fwd_binned<16>), grid, dim3(256), 0, st, a, bv); break;
+        case 20: hipLaunchKernelGGL((k_render_fwd_binned<20>), grid, dim3(256), 0, st, a, bv); break;
+        default: hipLaunchKernelGGL((k_render_fwd_binned<32>), grid, dim3(256), 0, st, a, bv); break;
+    }
+    STAGE_CHECK("render(binned)");
+    return 0;
+}
+
+int sks_backward(int V, int P, int C, int W, int H, const float* viewmatrix, const float* projmatrix,
+                 const float* tanfovx, const float* tanfovy, const float* bg, const float* means3D,
+                 const float* features, const float* opacities, const float* scales, const float* rotations,
+                 const float* cov3D_precomp, float scale_modifier, unsigned flags, const int* radii, const void* geom,
+                 const void* binning, size_t bin_capacity, const float* dL_dout_color, const float* dL_dout_invdepth,
+                 void* accum, float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dopacity, float* dL_dscales,
+                 float* dL_drotations, float* dL_dcov3D, float* dL_dfeatures, void* stream)
+{
+    if (int rc = check_common(V, P, C, W, H)) return rc;
+    if (P == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (!viewmatrix || !projmatrix || !tanfovx || !tanfovy || !means3D || !features || !opacities || !radii ||
+        !geom || !dL_dout_color || !accum || !dL_dmeans3D || !dL_dmeans2D || !dL_dopacity)
+        return fail(-2, "missing required pointer");
+    if (!cov3D_precomp && (!scales || !rotations)) return fail(-2, "need scales+rotations or cov3D_precomp");
+    ViewTan vt;
+    for (int v = 0; v < V; v++) { vt.x[v] = tanfovx[v]; vt.y[v] = tanfovy[v]; }
+    Geom g = geom_from(const_cast<void*>(geom), V, P);
+    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE, NT = gx * gy;
+    BwdArgs a{ P, C, W, H, flags, g, features, bg, dL_dout_color, dL_dout_invdepth, (float*)accum };
+    const int cg = pick_cg(C);
+    const bool dfeat = dL_dfeatures != nullptr;
+    const bool small = P <= SKS_SMALL_P && !(flags & SKS_FORCE_BINNED);
+    if (small) {
+        switch (cg) {
+            case 4: launch_bwd_small<4>(a, V, gy, dfeat, st); break;
+            case 16: launch_bwd_small<16>(a, V, gy, dfeat, st); break;
+            case 20: launch_bwd_small<20>(a, V, gy, dfeat, st); break;
+            default: launch_bwd_small<32>(a, V, gy, dfeat, st); break;
+        }
+        STAGE_CHECK("render-backward(small)");
+    } else {
+        if (!binning) return fail(-2, "binned path needs the forward's binning buffer");
+        Bin b = bin_from(const_cast<void*>(binning), V, NT, bin_capacity);
+        BinView bv{ b.ranges, b.keys, bin_capacity, NT };
+        dim3 grid(gx, gy, V);
+#define SKS_BWD_BINNED(CGV)                                                                                         \
+    if (dfeat) hipLaunchKernelGGL((k_render_bwd_binned<CGV, true>), grid, dim3(256), 0, st, a, bv);                 \
+    else hipLaunchKernelGGL((k_render_bwd_binned<CGV, false>), grid, dim3(256), 0, st, a, bv)
+        switch (cg) {
+            case 4: SKS_BWD_BINNED(4); break;
+            case 16: SKS_BWD_BINNED(16); break;
+            case 20: SKS_BWD_BINNED(20); break;
+            default: SKS_BWD_BINNED(32); break;
+        }
+#undef SKS_BWD_BINNED
+        STAGE_CHECK("render-backward(binned)");
+    }
+    GeomBwdArgs ga{ P, C, W, H, flags, viewmatrix, projmatrix, means3D, opacities, scales, rotations, cov3D_precomp,
+                    scale_modifier, radii, (float*)accum, dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dscales,
+                    dL_drotations, dL_dcov3D, dL_dfeatures };
+    hipLaunchKernelGGL(k_geom_bwd, dim3((P + 255) / 256, V), dim3(256), 0, st, ga, vt);
+    STAGE_CHECK("geometry-backward");
+    return 0;
+}
+
+int sks_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,
+                     void* stream)
+{
+    (void)projmatrix;  // in_frustum only uses the view-space depth (auxiliary.h:166)
+    if (P < 0) return fail(-1, "P negative");
+    if (P == 0) return 0;
+    if (!means3D || !viewmatrix || !present) return fail(-2, "missing required pointer");
+    hipLaunchKernelGGL(k_mark_visible, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, means3D, viewmatrix, present);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int sks_export_lists(int V, int W, int H, const void* binning, size_t bin_capacity, uint32_t* point_list,
+                     uint32_t* ranges, void* stream)
+{
+    if (!binning || !point_list || !ranges) return fail(-2, "missing required pointer");
+    const int NT = ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
+    Bin b = bin_from(const_cast<void*>(binning), V, NT, bin_capacity);
+    const size_t m = bin_capacity > (size_t)NT ? bin_capacity : (size_t)NT;
+    hipLaunchKernelGGL(k_export_lists, dim3((unsigned)((m + 255) / 256), V), dim3(256), 0, (hipStream_t)stream, NT,
+                       bin_capacity, b.ranges, b.keys, b.nrend, point_list, ranges);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,355 @@
+"""Python surface of the rasterizer: the reference's GaussianRasterizationSettings / GaussianRasterizer API
+(DGR/diff_gaussian_rasterization_h36m/__init__.py:21-207) on top of the C ABI in include/skelsplat_hip.h,
+plus the batched multi-view entry points the MI355X loop uses.
+
+"DGR/" = submodules/diff-gaussian-rasterization-h36m/ of the reference.
+"""
+from typing import NamedTuple, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    """Same 13 fields, same order as DGR/diff_gaussian_rasterization_h36m/__init__.py:143-156."""
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+    antialiasing: bool
+
+
+# ------------------------------------------------------------------------------------------------------------
+# scratch management (replaces resizeFunctional, DGR/rasterize_points.cu:27-33): torch owns every byte
+# ------------------------------------------------------------------------------------------------------------
+_accum_cache = {}
+
+
+def _accum(device, stream, V, P, C):
+    """Backward accumulators: zero on entry, left zero by sks_backward (consume-and-clear), so one zero-filled
+    buffer per (device, stream, shape) serves every call without a memset."""
+    key = (device.index, stream, V, P, C)
+    buf = _accum_cache.get(key)
+    if buf is None:
+        _, _, nbytes = _lib.scratch_bytes(V, max(P, 1), C, 16, 16)
+        buf = torch.zeros(nbytes // 4, dtype=torch.float32, device=device)
+        _accum_cache[key] = buf
+    return buf
+
+
+def reset_scratch():
+    """Drop cached accumulators (call after an aborted backward, e.g. an exception between kernels)."""
+    _accum_cache.clear()
+
+
+def _need_gpu(t, name):
+    if not t.is_cuda:
+        raise RuntimeError(f"skelsplat_amd: `{name}` must live on a ROCm device (got {t.device}); "
+                           "there is no CPU fallback")
+
+
+def _f32c(t, name):
+    if t is None or t.numel() == 0:
+        return None
+    _need_gpu(t, name)
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"skelsplat_amd: `{name}` must be float32 (got {t.dtype})")
+    return t.contiguous()
+
+
+class ViewBatch:
+    """V cameras that share one image size, packed for sks_forward / sks_backward."""
+
+    def __init__(self, viewmatrices, projmatrices, tanfovx, tanfovy, W, H):
+        self.viewmatrix = _f32c(viewmatrices, "viewmatrix").reshape(-1, 16)
+        self.projmatrix = _f32c(projmatrices, "projmatrix").reshape(-1, 16)
+        self.V = self.viewmatrix.shape[0]
+        if self.V > _lib.SKS_MAX_VIEWS:
+            raise RuntimeError(f"at most {_lib.SKS_MAX_VIEWS} views per call")
+        self.tanfovx = _lib.farray(tanfovx)
+        self.tanfovy = _lib.farray(tanfovy)
+        assert len(tanfovx) == self.V and len(tanfovy) == self.V
+        self.W, self.H = int(W), int(H)
+
+    @classmethod
+    def from_cameras(cls, cams):
+        import math
+        W, H = int(cams[0].image_width), int(cams[0].image_height)
+        for c in cams:
+            if int(c.image_width) != W or int(c.image_height) != H:
+                raise RuntimeError("all views of a batch must share the image size")
+        vm = torch.stack([c.world_view_transform.reshape(16) for c in cams])
+        pm = torch.stack([c.full_proj_transform.reshape(16) for c in cams])
+        return cls(vm, pm, [math.tan(c.FoVx * 0.5) for c in cams], [math.tan(c.FoVy * 0.5) for c in cams], W, H)
+
+    @classmethod
+    def from_settings(cls, rs):
+        return cls(rs.viewmatrix, rs.projmatrix, [rs.tanfovx], [rs.tanfovy], rs.image_width, rs.image_height)
+
+
+class ForwardState:
+    """What backward needs (the reference keeps geomBuffer / binningBuffer / imgBuffer + num_rendered,
+    DGR/diff_gaussian_rasterization_h36m/__init__.py:87-89)."""
+    __slots__ = ("views", "P", "C", "flags", "scale_modifier", "geom", "binning", "bin_capacity", "radii",
+                 "num_rendered_dev")
+
+
+def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotations, cov3D_precomp,
+                  scale_modifier=1.0, antialiasing=False, clamp01=False, debug=False, force_binned=False,
+                  bin_capacity=None, want_aux=False):
+    """Raw batched forward.  Returns (color (V,C,H,W), invdepth (V,1,H,W), radii (V,P) int32, state[, final_T, n_contrib])."""
+    lib = _lib.load()
+    means3D = _f32c(means3D, "means3D")
+    if means3D is None:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    if means3D.dim() != 2 or means3D.shape[1] != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")  # DGR/rasterize_points.cu:58-60
+    dev = means3D.device
+    P = means3D.shape[0]
+    features = _f32c(features, "features")
+    feat2 = features.reshape(P, -1)
+    C = feat2.shape[1]
+    opacities = _f32c(opacities, "opacities")
+    scales, rotations, cov3D_precomp = _f32c(scales, "scales"), _f32c(rotations, "rotations"), _f32c(cov3D_precomp, "cov3D_precomp")
+    V, W, H = views.V, views.W, views.H
+    flags = (_lib.SKS_ANTIALIASING if antialiasing else 0) | (_lib.SKS_CLAMP01 if clamp01 else 0) | \
+            (_lib.SKS_DEBUG_SYNC if debug else 0) | (_lib.SKS_FORCE_BINNED if force_binned else 0)
+    binned = force_binned or P > _lib.SKS_SMALL_P
+    if binned and bin_capacity is None:
+        bin_capacity = max(4096, 16 * P)
+    cap = int(bin_capacity or 0)
+    gbytes, bbytes, _ = _lib.scratch_bytes(V, max(P, 1), C, W, H, cap)
+    color = torch.empty((V, C, H, W), dtype=torch.float32, device=dev)
+    invdepth = torch.empty((V, 1, H, W), dtype=torch.float32, device=dev)
+    radii = torch.empty((V, P), dtype=torch.int32, device=dev)
+    geom = torch.empty(gbytes, dtype=torch.uint8, device=dev)
+    binning = torch.empty(bbytes, dtype=torch.uint8, device=dev) if binned else None
+    nrend = torch.zeros(V + 1, dtype=torch.int32, device=dev) if binned else None
+    final_T = torch.empty((V, H, W), dtype=torch.float32, device=dev) if want_aux else None
+    n_contrib = torch.empty((V, H, W), dtype=torch.int32, device=dev) if want_aux else None
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    with torch.cuda.device(dev):
+        rc = lib.sks_forward(V, P, C, W, H, views.viewmatrix.data_ptr(), views.projmatrix.data_ptr(), views.tanfovx,
+                             views.tanfovy, _lib.ptr(means3D), _lib.ptr(feat2), _lib.ptr(opacities), _lib.ptr(scales),
+                             _lib.ptr(rotations), _lib.ptr(cov3D_precomp), float(scale_modifier), flags,
+                             color.data_ptr(), invdepth.data_ptr(), _lib.ptr(radii), geom.data_ptr(),
+                             _lib.ptr(binning), cap, _lib.ptr(nrend), _lib.ptr(final_T), _lib.ptr(n_contrib), stream)
+    _lib.check(rc, "sks_forward")
+    st = ForwardState()
+    st.views, st.P, st.C, st.flags, st.scale_modifier = views, P, C, flags, float(scale_modifier)
+    st.geom, st.binning, st.bin_capacity, st.radii, st.num_rendered_dev = geom, binning, cap, radii, nrend
+    if want_aux:
+        return color, invdepth, radii, st, final_T, n_contrib
+    return color, invdepth, radii, st
+
+
+def backward_views(st: ForwardState, means3D, features, opacities, scales, rotations, cov3D_precomp, dL_dcolor,
+                   dL_dinvdepth=None, bg=None, want_dfeatures=False):
+    """Raw batched backward: per-view gradients, dict of (V,P,...) tensors."""
+    lib = _lib.load()
+    means3D = _f32c(means3D, "means3D")
+    dev = means3D.device
+    V, P, C = st.views.V, st.P, st.C
+    W, H = st.views.W, st.views.H
+    feat2 = _f32c(features, "features").reshape(P, -1)
+    opacities = _f32c(opacities, "opacities")
+    scales, rotations, cov3D_precomp = _f32c(scales, "scales"), _f32c(rotations, "rotations"), _f32c(cov3D_precomp, "cov3D_precomp")
+    dL_dcolor = _f32c(dL_dcolor, "dL_dout_color")
+    dL_dinvdepth = _f32c(dL_dinvdepth, "dL_dout_invdepth")
+    if dL_dcolor.numel() != V * C * H * W:
+        raise RuntimeError("dL_dout_color has the wrong number of elements")
+    bgC = None
+    if bg is not None and bg.numel() > 0:
+        # the reference reads C floats from its 3-float bg tensor (backward.cu:613-614); pad with zeros instead
+        bgC = torch.zeros(C, dtype=torch.float32, device=dev)
+        k = min(C, bg.numel())
+        bgC[:k] = bg.reshape(-1)[:k].to(device=dev, dtype=torch.float32)
+    e = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+    out = dict(means3D=e(V, P, 3), means2D=e(V, P, 3), opacities=e(V, P, 1), cov3D=e(V, P, 6),
+               scales=e(V, P, 3) if scales is not None else None,
+               rotations=e(V, P, 4) if rotations is not None else None,
+               features=e(V, P, C) if want_dfeatures else None)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    accum = _accum(dev, stream, V, P, C)
+    with torch.cuda.device(dev):
+        rc = lib.sks_backward(V, P, C, W, H, st.views.viewmatrix.data_ptr(), st.views.projmatrix.data_ptr(),
+                              st.views.tanfovx, st.views.tanfovy, _lib.ptr(bgC), _lib.ptr(means3D), _lib.ptr(feat2),
+                              _lib.ptr(opacities), _lib.ptr(scales), _lib.ptr(rotations), _lib.ptr(cov3D_precomp),
+                              st.scale_modifier, st.flags, _lib.ptr(st.radii), st.geom.data_ptr(), _lib.ptr(st.binning),
+                              st.bin_capacity, dL_dcolor.data_ptr(), _lib.ptr(dL_dinvdepth), accum.data_ptr(),
+                              _lib.ptr(out["means3D"]), _lib.ptr(out["means2D"]), _lib.ptr(out["opacities"]),
+                              _lib.ptr(out["scales"]), _lib.ptr(out["rotations"]), _lib.ptr(out["cov3D"]),
+                              _lib.ptr(out["features"]), stream)
+    if rc != 0:
+        reset_scratch()
+    _lib.check(rc, "sks_backward")
+    return out
+
+
+def export_lists(st: ForwardState):
+    """Parity/debug: (point_list (V,cap) int32, ranges (V,Tx*Ty,2) int32, num_rendered (V,) int32) of the binned path."""
+    lib = _lib.load()
+    if st.binning is None:
+        raise RuntimeError("lists exist only on the binned path (force_binned=True)")
+    dev = st.geom.device
+    V, W, H = st.views.V, st.views.W, st.views.H
+    NT = ((W + 15) // 16) * ((H + 15) // 16)
+    pl = torch.empty((V, max(st.bin_capacity, 1)), dtype=torch.int32, device=dev)
+    rg = torch.empty((V, NT, 2), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.sks_export_lists(V, W, H, st.binning.data_ptr(), st.bin_capacity, pl.data_ptr(), rg.data_ptr(),
+                                  torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(rc, "sks_export_lists")
+    return pl, rg, st.num_rendered_dev[:V]
+
+
+# ------------------------------------------------------------------------------------------------------------
+# autograd: single view (the reference's _RasterizeGaussians, __init__.py:44-141) and multi-view
+# ------------------------------------------------------------------------------------------------------------
+def _features_of(sh, colors_precomp, P):
+    # the kernels read features straight from `sh` as flat (P, C) and need M == 1; colors_precomp is
+    # ignored by the reference's kernels -- here it is used when no sh is given (the reference would dereference null).
+    if sh is not None and sh.numel() > 0:
+        if sh.dim() == 3 and sh.shape[1] != 1:
+            raise RuntimeError(f"features must have exactly one SH coefficient (M == 1), got shape {tuple(sh.shape)}")
+        return sh, "sh"
+    if colors_precomp is not None and colors_precomp.numel() > 0:
+        return colors_precomp, "colors"
+    raise RuntimeError("no features: provide shs (P,1,C) or colors_precomp (P,C)")
+
+
+class _RasterizeViews(torch.autograd.Function):
+    """V views of the same Gaussians; outputs (V,C,H,W), (V,P), (V,1,H,W); gradients summed over views."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, views,
+                scale_modifier, antialiasing, clamp01, debug, bg, single):
+        P = means3D.shape[0] if means3D.dim() == 2 else 0
+        feats, src = _features_of(sh, colors_precomp, P)
+        color, invdepth, radii, st = forward_views(views, means3D, feats, opacities, scales, rotations, cov3Ds_precomp,
+                                                   scale_modifier, antialiasing, clamp01, debug)
+        ctx.st, ctx.src, ctx.bg, ctx.single = st, src, bg, single
+        ctx.save_for_backward(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp)
+        ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)  # an unused inverse-depth output costs nothing in backward
+        if single:
+            return color[0], radii[0], invdepth[0]
+        return color, radii, invdepth
+
+    @staticmethod
+    def backward(ctx, grad_color, _grad_radii, grad_invdepth):
+        means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp = ctx.saved_tensors
+        st = ctx.st
+        feats = sh if ctx.src == "sh" else colors_precomp
+        if grad_color is None:
+            V, C, H, W = st.views.V, st.C, st.views.H, st.views.W
+            grad_color = torch.zeros((V, C, H, W), dtype=torch.float32, device=means3D.device)
+        need_feat = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
+        g = backward_views(st, means3D, feats, opacities, scales, rotations, cov3Ds_precomp, grad_color, grad_invdepth,
+                           ctx.bg, want_dfeatures=need_feat)
+        red = (lambda t: None if t is None else t[0]) if st.views.V == 1 else (lambda t: None if t is None else t.sum(0))
+        gf = red(g["features"])
+        grad_sh = gf.reshape(sh.shape) if (gf is not None and ctx.src == "sh") else None
+        grad_cp = gf.reshape(colors_precomp.shape) if (gf is not None and ctx.src == "colors") else None
+        has_cov = cov3Ds_precomp is not None and cov3Ds_precomp.numel() > 0
+        return (red(g["means3D"]), red(g["means2D"]), grad_sh, grad_cp, red(g["opacities"]).reshape(opacities.shape),
+                red(g["scales"]), red(g["rotations"]), red(g["cov3D"]) if has_cov else None,
+                None, None, None, None, None, None, None)
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                        raster_settings, clamp01=False):
+    """DGR/diff_gaussian_rasterization_h36m/__init__.py:21-42."""
+    views = ViewBatch.from_settings(raster_settings)
+    return _RasterizeViews.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                                 views, raster_settings.scale_modifier, bool(raster_settings.antialiasing), clamp01,
+                                 bool(raster_settings.debug), raster_settings.bg, True)
+
+
+def rasterize_views(views: ViewBatch, means3D, means2D, sh, opacities, scales=None, rotations=None, cov3D_precomp=None,
+                    colors_precomp=None, scale_modifier=1.0, antialiasing=False, clamp01=False, debug=False, bg=None):
+    """Multi-view autograd entry point (no reference counterpart: the reference renders one view per call)."""
+    emp = torch.empty(0)
+    z = lambda t: emp if t is None else t
+    return _RasterizeViews.apply(means3D, z(means2D), z(sh), z(colors_precomp), opacities, z(scales), z(rotations),
+                                 z(cov3D_precomp), views, scale_modifier, antialiasing, clamp01, debug, bg, False)
+
+
+class GaussianRasterizer(nn.Module):
+    """DGR/diff_gaussian_rasterization_h36m/__init__.py:158-207.  `num_channels` pins C like the reference's
+    compile-time NUM_CHANNELS (config.h:15); None accepts any C <= 32."""
+    num_channels: Optional[int] = None
+
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        with torch.no_grad():
+            rs = self.raster_settings
+            _need_gpu(positions, "positions")
+            pos = positions.contiguous().float()
+            P = pos.shape[0]
+            present = torch.zeros(P, dtype=torch.bool, device=pos.device)
+            if P:
+                with torch.cuda.device(pos.device):
+                    rc = _lib.load().sks_mark_visible(P, pos.data_ptr(), _f32c(rs.viewmatrix, "viewmatrix").data_ptr(),
+                                                      _f32c(rs.projmatrix, "projmatrix").data_ptr(), present.data_ptr(),
+                                                      torch.cuda.current_stream(pos.device).cuda_stream)
+                _lib.check(rc, "sks_mark_visible")
+        return present
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None, clamp01=False):
+        raster_settings = self.raster_settings
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        if shs is None:
+            shs = torch.Tensor([])
+        if colors_precomp is None:
+            colors_precomp = torch.Tensor([])
+        if scales is None:
+            scales = torch.Tensor([])
+        if rotations is None:
+            rotations = torch.Tensor([])
+        if cov3D_precomp is None:
+            cov3D_precomp = torch.Tensor([])
+        if self.num_channels is not None:
+            f = shs if shs.numel() else colors_precomp
+            if f.shape[-1] != self.num_channels:
+                raise RuntimeError(f"this rasterizer package is fixed to NUM_CHANNELS={self.num_channels}, "
+                                   f"got features with {f.shape[-1]} channels")
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                   raster_settings, clamp01=clamp01)
+
+
+def make_package(num_channels):
+    """Class pair for one of the reference's three packages (NUM_CHANNELS 17 / 19 / 15)."""
+    cls = type(f"GaussianRasterizer{num_channels}", (GaussianRasterizer,), {"num_channels": num_channels})
+    return GaussianRasterizationSettings, cls
+
+
+def decode_geom(st: ForwardState):
+    """Debug/parity view of the forward's per-(view, Gaussian) records: dict of conic_opacity (V,P,4),
+    xy (V,P,2), depths (V,P), rect (V,P,4) [xmin,ymin,xmax,ymax in tiles]."""
+    V, P = st.views.V, st.P
+    n = V * P * 16
+    seg = (n + 255) // 256 * 256
+    g = st.geom
+    co = g[0:n].view(torch.float32).reshape(V, P, 4)
+    xyd = g[seg:seg + n].view(torch.float32).reshape(V, P, 4)
+    rect = g[2 * seg:2 * seg + n].view(torch.int32).reshape(V, P, 4)
+    return dict(conic_opacity=co, xy=xyd[..., :2], depths=xyd[..., 2], rect=rect)

@@ -1,0 +1,56 @@
+"""Seeded rasterizer test cases shared by the CPU (oracle) and GPU (parity) tests."""
+import math
+
+import numpy as np
+
+from oracle import oracle as orc
+from skelsplat_amd.scene import SyntheticScene
+
+
+class Case:
+    pass
+
+
+def make_case(seed, W, H, dataset="h36m", n_views=2, scale_log=4.0, rand_rot=True, opac=None, fxmul=1.0,
+              ring=2500.0, n_skeletons=1, onehot=False, pitch=700.0):
+    """Skeleton(s) seen by `n_views` ring cameras; anisotropic random covariances so splats overlap and saturate."""
+    sc = SyntheticScene(dataset, n_views=n_views, seed=seed, W=W, H=H, ring=ring,
+                        fx=1145.0 * (W / 1000) * fxmul, n_skeletons=n_skeletons, pitch=pitch)
+    rng = np.random.default_rng(seed + 100)
+    c = Case()
+    c.scene = sc
+    c.W, c.H, c.P, c.C = W, H, sc.n_points, sc.n_joints
+    c.means = sc.pose_3d_init.astype(np.float32)
+    c.scales = np.exp(rng.normal(scale_log, 0.3, (c.P, 3))).astype(np.float32)
+    q = rng.normal(0, 1, (c.P, 4)) if rand_rot else np.tile([1.0, 0, 0, 0], (c.P, 1))
+    c.quats = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
+    c.opac = (np.full((c.P, 1), opac, np.float32) if opac is not None
+              else rng.uniform(0.3, 1.0, (c.P, 1)).astype(np.float32))
+    eye = np.eye(c.C, dtype=np.float32)[np.arange(c.P) % c.C]
+    c.feat = eye if onehot else (eye + 0.1 * rng.uniform(0, 1, (c.P, c.C))).astype(np.float32)
+    c.cams = sc.cameras
+    c.ocams = [orc.Cam(W, H, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5),
+                       cam.world_view_transform.numpy(), cam.full_proj_transform.numpy()) for cam in c.cams]
+    c.dL_color = rng.normal(0, 1, (n_views, c.C, H, W)).astype(np.float32)
+    c.dL_inv = rng.normal(0, 1, (n_views, 1, H, W)).astype(np.float32)
+    return c
+
+
+def oracle_forward(c, v, antialiasing=False):
+    return orc.forward(c.means, c.feat, c.opac, c.scales, c.quats, None, c.ocams[v], antialiasing=antialiasing)
+
+
+def oracle_backward(c, v, fwd, antialiasing=False, bg=None, with_inv=True):
+    return orc.backward(fwd, c.means, c.feat, c.opac, c.scales, c.quats, None, c.ocams[v], c.dL_color[v],
+                        c.dL_inv[v] if with_inv else None, bg=bg, antialiasing=antialiasing)
+
+
+def assert_close(name, got, want, rtol=1e-3, atol_scale=1e-5):
+    got = np.asarray(got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    assert got.shape == want.shape, (name, got.shape, want.shape)
+    scale = np.abs(want).max() + 1e-30
+    err = np.abs(got - want)
+    tol = atol_scale * scale + rtol * np.abs(want)
+    bad = err > tol
+    assert not bad.any(), f"{name}: {bad.sum()} / {bad.size} off; max abs err {err.max():.3e} (scale {scale:.3e})"
