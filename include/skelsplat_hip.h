@@ -41,6 +41,9 @@ extern "C" {
 #define SKS_DEBUG_SYNC   8u   /* raster_settings.debug: hipStreamSynchronize + error check after each stage
                                  (CHECK_CUDA, DGR/cuda_rasterizer/auxiliary.h:178-185) */
 
+#define SKS_NO_NT_STORES 16u  /* tuning: plain instead of non-temporal stores for the dense forward planes
+                                 (non-temporal is the default: the planes are written once and read by another kernel) */
+
 const char* sks_last_error(void);
 int sks_version(void);
 
@@ -48,7 +51,7 @@ int sks_version(void);
  * geom: per-view per-Gaussian records kept for backward ("geomBuffer");
  * binning: tile counters / ranges / sorted keys ("binningBuffer"+"imgBuffer" ranges), only used on the binned
  *          path; bin_capacity = max (Gaussian,tile) pairs per view it must hold;
- * accum:  backward accumulators, must be zero on entry to sks_backward and is left zero on return. */
+ * accum:  backward partial-sum slots (plain scratch: no initialisation needed, contents undefined afterwards). */
 int sks_scratch_bytes(int V, int P, int C, int W, int H, size_t bin_capacity,
                       size_t* geom_bytes, size_t* binning_bytes, size_t* accum_bytes);
 
@@ -97,6 +100,13 @@ int sks_mark_visible(int P, const float* means3D, const float* viewmatrix, const
  * point_list (V,bin_capacity) uint32, ranges (V,Tx*Ty,2) uint32 (BinningState / ImageState::ranges). */
 int sks_export_lists(int V, int W, int H, const void* binning, size_t bin_capacity,
                      uint32_t* point_list, uint32_t* ranges, void* stream);
+
+/* Measurement hook used by bench.py (no reference counterpart): while enabled, the dominant kernel of sks_forward
+ * (kind 0: forward compositor) and of sks_backward (kind 1: backward compositor) is bracketed by hipEvents recorded
+ * on the caller's stream.  sks_prof_read waits for the recorded events, returns the summed kernel time in
+ * milliseconds and the number of launches since the last read, and resets the counters. */
+int sks_prof_enable(int on);
+int sks_prof_read(int kind, double* total_ms, long long* launches);
 
 #ifdef __cplusplus
 }

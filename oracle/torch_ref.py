@@ -29,7 +29,8 @@ def _rect(px, py, radius, gx, gy):
 
 
 def rasterize(means3D, means2D, features, opacities, scales, rotations, cov3D_precomp, viewmatrix, projmatrix,
-              W, H, tanfovx, tanfovy, bg=None, scale_modifier=1.0, antialiasing=False, dtype=torch.float32):
+              W, H, tanfovx, tanfovy, bg=None, scale_modifier=1.0, antialiasing=False, dtype=torch.float32,
+              dense=False):
     """Returns (color (C,H,W), radii (P,), invdepth (1,H,W)); differentiable wrt means3D, means2D (NDC-scaled
     screen-space dummy, like `viewspace_points`), features, opacities, scales, rotations, cov3D_precomp."""
     dev = means3D.device
@@ -138,25 +139,37 @@ def rasterize(means3D, means2D, features, opacities, scales, rotations, cov3D_pr
     if bg is not None:
         b = bg.to(dtype).reshape(-1)
         bgC[:min(C, b.numel())] = b[:C]
+    vis_l = visible.tolist()
+    xmin_l, ymin_l, xmax_l, ymax_l = xmin.tolist(), ymin.tolist(), xmax.tolist(), ymax.tolist()
     for g in order:
-        if not bool(visible[g]):
+        if not vis_l[g]:
             continue
-        in_rect = (tyi >= ymin[g]) & (tyi < ymax[g]) & (txi >= xmin[g]) & (txi < xmax[g])
-        dx = pix_x[g] - pxf
-        dy = pix_y[g] - pyf
+        if dense:   # every pixel evaluated, tile rect as a mask (slow; cross-check of the sliced form)
+            sy, sx = slice(0, H), slice(0, W)
+            in_rect = (tyi >= ymin[g]) & (tyi < ymax[g]) & (txi >= xmin[g]) & (txi < xmax[g])
+        else:       # only the pixels of the Gaussian's tile rect (what a CPU rasterizer would do)
+            sy = slice(ymin_l[g] * BLOCK, min(H, ymax_l[g] * BLOCK))
+            sx = slice(xmin_l[g] * BLOCK, min(W, xmax_l[g] * BLOCK))
+            in_rect = True
+        Ts, dones = T[sy, sx], done[sy, sx]
+        dx = pix_x[g] - pxf[:, sx]
+        dy = pix_y[g] - pyf[sy]
         power = -0.5 * (conic_x[g] * dx * dx + conic_z[g] * dy * dy) - conic_y[g] * dx * dy
         G = torch.exp(torch.clamp_max(power, 0.0))
         a_raw = opac[g] * G
         alpha = a_raw + (torch.clamp_max(a_raw, 0.99) - a_raw).detach()
-        valid = in_rect & (power.detach() <= 0) & (alpha.detach() >= 1.0 / 255.0) & ~done
-        test_T = T * (1 - alpha)
+        valid = (power.detach() <= 0) & (alpha.detach() >= 1.0 / 255.0) & ~dones
+        if dense:
+            valid = valid & in_rect
+        test_T = Ts * (1 - alpha)
         newly_done = valid & (test_T.detach() < 0.0001)
-        done = done | newly_done
         contrib = valid & ~newly_done
-        w = torch.where(contrib, alpha * T, torch.zeros_like(T))
-        color = color + features[g][:, None, None] * w[None]
-        invd = invd + (1.0 / depth[g]) * w
-        T = torch.where(contrib, test_T, T)
+        w = torch.where(contrib, alpha * Ts, torch.zeros_like(Ts))
+        pad = (sx.start, W - sx.stop, sy.start, H - sy.stop)
+        color = color + torch.nn.functional.pad(features[g][:, None, None] * w[None], pad)
+        invd = invd + torch.nn.functional.pad((1.0 / depth[g]) * w, pad)
+        T = T + torch.nn.functional.pad(torch.where(contrib, test_T - Ts, torch.zeros_like(Ts)), pad)
+        done = done | torch.nn.functional.pad(newly_done, pad)
     # straight-through background term (value unchanged: the reference does not composite bg, forward.cu:396)
     bgterm = T[None] * bgC[:, None, None]
     color = color + (bgterm - bgterm.detach())

@@ -17,6 +17,7 @@ SKS_ANTIALIASING = 1
 SKS_CLAMP01 = 2
 SKS_FORCE_BINNED = 4
 SKS_DEBUG_SYNC = 8
+SKS_NO_NT_STORES = 16
 
 _vp, _i, _u, _f, _sz = C.c_void_p, C.c_int, C.c_uint, C.c_float, C.c_size_t
 
@@ -31,6 +32,8 @@ SIGNATURES = {
                           _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sks_mark_visible": (_i, [_i, _vp, _vp, _vp, _vp, _vp]),
     "sks_export_lists": (_i, [_i, _i, _i, _vp, _sz, _vp, _vp, _vp]),
+    "sks_prof_enable": (_i, [_i]),
+    "sks_prof_read": (_i, [_i, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
 }
 
 
@@ -79,3 +82,14 @@ def ptr(t):
 
 def farray(vals):
     return (C.c_float * len(vals))(*[float(v) for v in vals])
+
+
+def prof_enable(on):
+    check(load().sks_prof_enable(1 if on else 0), "sks_prof_enable")
+
+
+def prof_read(kind):
+    """(total_ms, launches) of the forward (kind 0) / backward (kind 1) compositor kernel since the last read."""
+    ms, n = C.c_double(0), C.c_longlong(0)
+    check(load().sks_prof_read(kind, C.byref(ms), C.byref(n)), "sks_prof_read")
+    return ms.value, n.value

@@ -52,11 +52,42 @@ int fail(int code, const char* fmt, ...)
         }                                                                                      \
     } while (0)
 
+// ---- measurement hook (sks_prof_enable / sks_prof_read) ----
+constexpr int PROF_MAX = 16384;
+struct ProfKind {
+    hipEvent_t b[PROF_MAX], e[PROF_MAX];
+    int created = 0, n = 0;
+};
+bool g_prof_on = false;
+ProfKind g_prof[2];
+
+struct ProfScope {  // records begin at construction, end at destruction, around one kernel launch
+    ProfKind* k = nullptr;
+    hipStream_t st;
+    ProfScope(int kind, hipStream_t s) : st(s)
+    {
+        if (!g_prof_on) return;
+        ProfKind& p = g_prof[kind];
+        if (p.n >= PROF_MAX) return;
+        if (p.n >= p.created) {
+            if (hipEventCreate(&p.b[p.created]) != hipSuccess || hipEventCreate(&p.e[p.created]) != hipSuccess) return;
+            p.created++;
+        }
+        k = &p;
+        (void)hipEventRecord(p.b[p.n], st);
+    }
+    ~ProfScope()
+    {
+        if (!k) return;
+        (void)hipEventRecord(k->e[k->n], st);
+        k->n++;
+    }
+};
+
 constexpr int LCAP = 256;         // LDS list capacity == SKS_SMALL_P == binned batch size
 constexpr int NACC = 8;           // per-Gaussian accumulators before the feature block:
                                   // 0,1 dL_dmean2D.xy  2,3,4 dL_dconic.{x,y,w}  5 dL_dopacity  6 dL_dinvdepth  7 pad
-constexpr int FWD_PASSES = 4;     // small path forward: 256 thr x 4 px x 4 passes = 4096 px per workgroup
-constexpr int BWD_PASSES = 16;    // small path backward: 256 thr x 1 px x 16 passes
+constexpr int BWD_SPLITS = 16;    // small path backward: partial-sum slots (workgroups) per (view, Gaussian)
 
 struct ViewTan {
     float x[SKS_MAX_VIEWS];
@@ -207,46 +238,6 @@ struct List {
     float feat[LCAP * CG];
 };
 
-// Small path: gather the Gaussians whose tile rect crosses `band`, order by (depth bits, index).
-// Returns n (uniform across the workgroup).  Contains barriers: call from uniform control flow.
-template <int CG>
-__device__ __forceinline__ int build_band_list(List<CG>& L, unsigned long long* s_key, int* s_n, int P, int C,
-                                               int band, const float4* __restrict__ gco,
-                                               const float4* __restrict__ gxyd, const uint4* __restrict__ grect,
-                                               const float* __restrict__ features)
-{
-    const int tid = threadIdx.x;
-    if (tid == 0) *s_n = 0;
-    __syncthreads();
-    if (tid < P) {
-        const uint4 r = grect[tid];
-        if ((int)r.y <= band && band < (int)r.w) {
-            const int slot = atomicAdd(s_n, 1);
-            s_key[slot] = ((unsigned long long)__float_as_uint(gxyd[tid].z) << 32) | (unsigned)tid;
-        }
-    }
-    __syncthreads();
-    const int n = *s_n;
-    if (n == 0) return 0;
-    if (tid < n) {
-        const unsigned long long key = s_key[tid];
-        int rank = 0;
-        for (int j = 0; j < n; j++) rank += (s_key[j] < key) ? 1 : 0;
-        const int id = (int)(unsigned)key;
-        const float4 xyd = gxyd[id];
-        const uint4 r = grect[id];
-        L.xy[rank] = make_float2(xyd.x, xyd.y);
-        L.co[rank] = gco[id];
-        L.invd[rank] = xyd.w;
-        L.xr[rank] = (int)(r.x | (r.z << 16));
-        L.id[rank] = id;
-#pragma unroll
-        for (int ch = 0; ch < CG; ch++) L.feat[rank * CG + ch] = ch < C ? features[id * C + ch] : 0.0f;
-    }
-    __syncthreads();
-    return n;
-}
-
 // Forward compositing of one pixel over n LDS entries (forward.cu:346-386), carrying state across batches.
 template <int CG, bool XF>
 __device__ __forceinline__ void composite_px(const List<CG>& L, int n, float pxf, float pyf, int tx, float& T,
@@ -293,77 +284,204 @@ struct FwdArgs {
 };
 
 // ------------------------------------------------------------------------------------------------------------
-// small path forward: grid (chunks, bands, V).  PPT = 4 -> W % 4 == 0, 16-byte stores; PPT = 1 -> any W.
+// small path forward, "fill + sparse composite" in ONE launch.  With a skeleton (P = 15..19) a view covers ~100 of
+// ~4000 tiles, so the kernel is a dense zero fill of (C+1) planes with a sprinkle of compositing.  Two roles by
+// block index (composite blocks come first so their latency hides under the fill):
+//   * composite role, block (slot, g, v): walks the tiles of Gaussian g's rect (slot, slot+T_SLOTS, ...).  The
+//     tile is rendered by the LOWEST-index Gaussian whose rect covers it (so every covered tile has exactly one
+//     owner); the owner gathers the covering Gaussians, orders them by (depth bits, index) -- the order the
+//     reference gets from its stable radix sort of (tile | depth) keys with index-major emission -- and composites
+//     thread-per-pixel exactly like forward.cu:278-401, writing all C+1 planes of the tile;
+//   * fill role, block (plane, band, v): streams zeros over its plane's 16-row band (rows*W contiguous floats,
+//     16 B per lane), skipping the tile columns some Gaussian rect covers in that band.
+// A pure fill of this shape runs at the memset rate (7+ TB/s for the 288 MB of 4 H36M views on MI355X).
+// PPT = 4 needs W % 4 == 0; PPT = 1 handles any W with 4-byte stores.
 // ------------------------------------------------------------------------------------------------------------
-template <int CG, int PPT>
-__global__ __launch_bounds__(256) void k_render_fwd_small(FwdArgs a)
+constexpr int T_SLOTS = 16;     // composite blocks per (view, Gaussian)
+constexpr int MAXCOL = 4096;    // tile columns (W <= 65536)
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+
+template <bool NT>
+__device__ __forceinline__ void store4(float* p, float a, float b, float c, float d)
 {
-    __shared__ List<CG> L;
-    __shared__ unsigned long long s_key[LCAP];
-    __shared__ int s_n;
-    const int v = blockIdx.z, band = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    v4f v = { a, b, c, d };
+    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(p));
+    else *reinterpret_cast<v4f*>(p) = v;
+}
+
+// dynamic-LDS list with capacity `cap` entries (cap = P rounded up to 16)
+template <int CG>
+struct DynList {
+    float2* xy;
+    float4* co;
+    float* invd;
+    float* feat;               // cap * CG
+    unsigned long long* key;   // cap
+    uint4* rect;               // cap
+    __device__ DynList(char* base, int cap)
+    {
+        co = (float4*)base; base += (size_t)cap * 16;
+        rect = (uint4*)base; base += (size_t)cap * 16;
+        key = (unsigned long long*)base; base += (size_t)cap * 8;
+        xy = (float2*)base; base += (size_t)cap * 8;
+        invd = (float*)base; base += (size_t)cap * 4;
+        feat = (float*)base;
+    }
+    static size_t bytes(int cap, int cg) { return (size_t)cap * (16 + 16 + 8 + 8 + 4 + 4 * (size_t)cg); }
+};
+
+template <int CG, int PPT, bool NT>
+__global__ __launch_bounds__(256) void k_render_fwd_sparse(FwdArgs a, int ncomp, int gy)
+{
+    extern __shared__ __attribute__((aligned(16))) char s_dyn[];
+    __shared__ unsigned char s_cover[MAXCOL];
+    __shared__ int s_n, s_min;
+    const int tid = threadIdx.x;
     const int P = a.P, C = a.C, W = a.W, H = a.H;
     const size_t HW = (size_t)H * W;
-    const size_t go = (size_t)v * P;
-    const int n = build_band_list<CG>(L, s_key, &s_n, P, C, band, a.g.co + go, a.g.xyd + go, a.g.rect + go, a.features);
 
-    const int rows = min(TILE, H - band * TILE);
-    const int Nb = rows * W;  // pixels of this band, contiguous in every plane
-    const size_t band0 = (size_t)band * TILE * W;
-    float* outc = a.out_color + (size_t)v * C * HW;
-    float* outi = a.out_invdepth + (size_t)v * HW;
-    const bool do_clamp = a.flags & SKS_CLAMP01;
-    constexpr int CH = FWD_PASSES * 256 * PPT;
-
-#pragma unroll 1
-    for (int pass = 0; pass < FWD_PASSES; pass++) {
-        const int base = chunk * CH + (pass * 256 + tid) * PPT;
-        if (base >= Nb) continue;
-        const size_t pix0 = band0 + base;
-        float T[PPT], inv[PPT], acc[PPT][CG];
-        uint32_t last[PPT];
-#pragma unroll
-        for (int p = 0; p < PPT; p++) {
-            T[p] = 1.0f;
-            inv[p] = 0.0f;
-            last[p] = 0;
-#pragma unroll
-            for (int ch = 0; ch < CG; ch++) acc[p][ch] = 0.0f;
-        }
-        if (n > 0) {
-            const int y = (int)(pix0 / W);
-            const int x0 = (int)(pix0 - (size_t)y * W);
-#pragma unroll
-            for (int p = 0; p < PPT; p++) {
-                uint32_t contributor = 0;
-                bool done = false;
-                composite_px<CG, true>(L, n, (float)(x0 + p), (float)y, (x0 + p) >> 4, T[p], acc[p], inv[p],
-                                       contributor, last[p], done);
-            }
-        }
-        if (PPT == 4) {
-#pragma unroll
-            for (int ch = 0; ch < CG; ch++) {
-                if (ch < C) {
-                    float4 o = make_float4(acc[0][ch], acc[1 % PPT][ch], acc[2 % PPT][ch], acc[3 % PPT][ch]);
-                    if (do_clamp) o = make_float4(clamp01(o.x), clamp01(o.y), clamp01(o.z), clamp01(o.w));
-                    *reinterpret_cast<float4*>(outc + (size_t)ch * HW + pix0) = o;
+    if ((int)blockIdx.x < ncomp) {
+        // ---------------- composite role ----------------
+        const int slot = blockIdx.x % T_SLOTS;
+        const int g = (blockIdx.x / T_SLOTS) % P;
+        const int v = blockIdx.x / (T_SLOTS * P);
+        const size_t go = (size_t)v * P;
+        const float4* gco = a.g.co + go;
+        const float4* gxyd = a.g.xyd + go;
+        const uint4* grect = a.g.rect + go;
+        const uint4 rg = grect[g];
+        const int wt = (int)(rg.z - rg.x), ht = (int)(rg.w - rg.y);
+        const int ntiles = wt * ht;
+        if (slot >= ntiles) return;
+        const int cap = (P + 15) & ~15;
+        DynList<CG> L(s_dyn, cap);
+        if (tid < P) L.rect[tid] = grect[tid];
+        __syncthreads();
+        float* outc = a.out_color + (size_t)v * C * HW;
+        float* outi = a.out_invdepth + (size_t)v * HW;
+        const bool do_clamp = a.flags & SKS_CLAMP01;
+        for (int t = slot; t < ntiles; t += T_SLOTS) {
+            const int ty = (int)rg.y + t / wt, tx = (int)rg.x + t % wt;
+            if (tid == 0) { s_n = 0; s_min = 0x7fffffff; }
+            __syncthreads();
+            if (tid < P) {
+                const uint4 r = L.rect[tid];
+                if ((int)r.x <= tx && tx < (int)r.z && (int)r.y <= ty && ty < (int)r.w) {
+                    atomicMin(&s_min, tid);
+                    const int sl = atomicAdd(&s_n, 1);
+                    L.key[sl] = ((unsigned long long)__float_as_uint(gxyd[tid].z) << 32) | (unsigned)tid;
                 }
             }
-            *reinterpret_cast<float4*>(outi + pix0) = make_float4(inv[0], inv[1 % PPT], inv[2 % PPT], inv[3 % PPT]);
-            if (a.final_T)
-                *reinterpret_cast<float4*>(a.final_T + (size_t)v * HW + pix0) =
-                    make_float4(T[0], T[1 % PPT], T[2 % PPT], T[3 % PPT]);
-            if (a.n_contrib)
-                *reinterpret_cast<uint4*>(a.n_contrib + (size_t)v * HW + pix0) =
-                    make_uint4(last[0], last[1 % PPT], last[2 % PPT], last[3 % PPT]);
-        } else {
+            __syncthreads();
+            const int n = s_n;
+            if (s_min == g) {  // uniform: this block owns the tile
+                if (tid < n) {
+                    const unsigned long long key = L.key[tid];
+                    int rank = 0;
+                    for (int j = 0; j < n; j++) rank += (L.key[j] < key) ? 1 : 0;
+                    const int id = (int)(unsigned)key;
+                    const float4 xyd = gxyd[id];
+                    L.xy[rank] = make_float2(xyd.x, xyd.y);
+                    L.co[rank] = gco[id];
+                    L.invd[rank] = xyd.w;
 #pragma unroll
-            for (int ch = 0; ch < CG; ch++)
-                if (ch < C) outc[(size_t)ch * HW + pix0] = do_clamp ? clamp01(acc[0][ch]) : acc[0][ch];
-            outi[pix0] = inv[0];
-            if (a.final_T) a.final_T[(size_t)v * HW + pix0] = T[0];
-            if (a.n_contrib) a.n_contrib[(size_t)v * HW + pix0] = last[0];
+                    for (int ch = 0; ch < CG; ch++) L.feat[rank * CG + ch] = ch < C ? a.features[id * C + ch] : 0.0f;
+                }
+                __syncthreads();
+                const int x = tx * TILE + (tid & 15), y = ty * TILE + (tid >> 4);
+                if (x < W && y < H) {
+                    const float pxf = (float)x, pyf = (float)y;
+                    float T = 1.0f, inv = 0.0f, acc[CG];
+#pragma unroll
+                    for (int ch = 0; ch < CG; ch++) acc[ch] = 0.0f;
+                    uint32_t contributor = 0, last = 0;
+                    for (int k = 0; k < n; k++) {  // forward.cu:346-386
+                        contributor++;
+                        const float2 xy = L.xy[k];
+                        const float4 co = L.co[k];
+                        const float dx = xy.x - pxf, dy = xy.y - pyf;
+                        const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+                        if (power > 0.0f) continue;
+                        const float alpha = fminf(0.99f, co.w * expf_fixed(power));
+                        if (alpha < 1.0f / 255.0f) continue;
+                        const float test_T = T * (1 - alpha);
+                        if (test_T < 0.0001f) break;
+#pragma unroll
+                        for (int ch = 0; ch < CG; ch++) acc[ch] += L.feat[k * CG + ch] * alpha * T;
+                        inv += L.invd[k] * alpha * T;
+                        T = test_T;
+                        last = contributor;
+                    }
+                    const size_t pix = (size_t)y * W + x;
+#pragma unroll
+                    for (int ch = 0; ch < CG; ch++)
+                        if (ch < C) outc[(size_t)ch * HW + pix] = do_clamp ? clamp01(acc[ch]) : acc[ch];
+                    outi[pix] = inv;
+                    if (a.final_T) a.final_T[(size_t)v * HW + pix] = T;
+                    if (a.n_contrib) a.n_contrib[(size_t)v * HW + pix] = last;
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    // ---------------- fill role ----------------
+    const int f = blockIdx.x - ncomp;
+    const int plane = f % (C + 1);
+    const int band = (f / (C + 1)) % gy;
+    const int v = f / ((C + 1) * gy);
+    const uint4* grect = a.g.rect + (size_t)v * P;
+    const bool is_inv = plane == C;
+    const int gx = (W + TILE - 1) / TILE;
+    // every wavefront decides on its own (no LDS, no barrier) whether any Gaussian rect crosses this band; all
+    // wavefronts read the same rects, so the answer is uniform across the workgroup
+    bool any = false;
+    for (int i0 = 0; i0 < P; i0 += 64) {
+        const int idx = i0 + (tid & 63);
+        bool hit = false;
+        if (idx < P) {
+            const uint4 r = grect[idx];
+            hit = (int)r.y <= band && band < (int)r.w;
+        }
+        any = any || __any(hit);
+    }
+    if (any) {
+        for (int t = tid; t < gx; t += 256) s_cover[t] = 0;
+        __syncthreads();
+        if (tid < P) {
+            const uint4 r = grect[tid];
+            if ((int)r.y <= band && band < (int)r.w)
+                for (unsigned t = r.x; t < r.z; t++) s_cover[t] = 1;
+        }
+        __syncthreads();
+    }
+    const int rows = min(TILE, H - band * TILE);
+    const int Nb = rows * W;  // this band of this plane: Nb contiguous floats
+    const size_t band0 = (size_t)band * TILE * W;
+    float* out = (is_inv ? a.out_invdepth + (size_t)v * HW : a.out_color + ((size_t)v * C + plane) * HW) + band0;
+    float* outT = (is_inv && a.final_T) ? a.final_T + (size_t)v * HW + band0 : nullptr;
+    uint32_t* outN = (is_inv && a.n_contrib) ? a.n_contrib + (size_t)v * HW + band0 : nullptr;
+    if (!any) {
+#pragma unroll 4
+        for (int base = tid * PPT; base < Nb; base += 256 * PPT) {
+            if (PPT == 4) store4<NT>(out + base, 0.0f, 0.0f, 0.0f, 0.0f);
+            else out[base] = 0.0f;
+        }
+    } else {
+        for (int base = tid * PPT; base < Nb; base += 256 * PPT) {
+            const int x0 = base % W;  // PPT == 4: W % 4 == 0, the 4 pixels share one tile column
+            if (s_cover[x0 >> 4]) continue;  // a composite block writes this tile
+            if (PPT == 4) store4<NT>(out + base, 0.0f, 0.0f, 0.0f, 0.0f);
+            else out[base] = 0.0f;
+        }
+    }
+    if (outT || outN) {  // debug planes of the reference's ImageState: T = 1, no contributor outside covered tiles
+        for (int base = tid; base < Nb; base += 256) {
+            if (any && s_cover[(base % W) >> 4]) continue;
+            if (outT) outT[base] = 1.0f;
+            if (outN) outN[base] = 0u;
         }
     }
 }
@@ -497,10 +615,13 @@ __device__ __forceinline__ void bwd_prepass(const List<CG>& L, int n, float pxf,
     }
 }
 
+// chan == nullptr: identity channel map (position j is channel j), nc == C
 template <int CG>
 __device__ __forceinline__ void bwd_load_pixel(BwdPix<CG>& s, const BwdArgs& a, int v, size_t pix, size_t HW,
-                                               const float (&col)[CG], bool do_clamp, float T_final)
+                                               const float (&col)[CG], bool do_clamp, float T_final,
+                                               const int* chan = nullptr, int nc = -1)
 {
+    if (nc < 0) nc = a.C;
     s.T = T_final;
     s.T_final = T_final;
     s.last_alpha = 0;
@@ -509,75 +630,214 @@ __device__ __forceinline__ void bwd_load_pixel(BwdPix<CG>& s, const BwdArgs& a, 
     s.bgdot = 0;
     const float* dLc = a.dL_color + (size_t)v * a.C * HW + pix;
 #pragma unroll
-    for (int ch = 0; ch < CG; ch++) {
-        float d = ch < a.C ? dLc[(size_t)ch * HW] : 0.0f;
-        // torch.clamp backward passes the gradient where min <= x <= max
-        if (do_clamp && !(col[ch] >= 0.0f && col[ch] <= 1.0f)) d = 0.0f;
-        s.dL[ch] = d;
-        s.accum_rec[ch] = 0;
-        s.last_color[ch] = 0;
-        if (a.bg && ch < a.C) s.bgdot += a.bg[ch] * d;
+    for (int j = 0; j < CG; j++) {
+        float d = 0.0f;
+        if (j < nc) {
+            const int ch = chan ? chan[j] : j;
+            d = dLc[(size_t)ch * HW];
+            // torch.clamp backward passes the gradient where min <= x <= max
+            if (do_clamp && !(col[j] >= 0.0f && col[j] <= 1.0f)) d = 0.0f;
+            if (a.bg) s.bgdot += a.bg[ch] * d;
+        }
+        s.dL[j] = d;
+        s.accum_rec[j] = 0;
+        s.last_color[j] = 0;
     }
     s.dLi = a.dL_invdepth ? a.dL_invdepth[(size_t)v * HW + pix] : 0.0f;
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// small path backward: grid (chunks, bands, V), one pixel per thread per pass
+// small path backward, gathered per Gaussian: grid (BWD_SPLITS, P, V).  Workgroup (s, g, v) walks the pixels of
+// Gaussian g's tile rect (256-pixel chunks s, s+BWD_SPLITS, ...), re-composites each pixel over the LDS list of
+// every Gaussian whose rect meets g's rect, walks back to front like backward.cu:531-637 and keeps ONLY g's terms.
+// Sums stay in registers, are reduced once per workgroup and stored to the (v, g, s) partial slot: no atomics,
+// no zero-initialised scratch, bitwise reproducible gradients.
 // ------------------------------------------------------------------------------------------------------------
+template <int CG>
+struct ListG : List<CG> {
+    int yr[LCAP];  // ymin | ymax << 16 (tile units)
+};
+
 template <int CG, bool DFEAT>
-__global__ __launch_bounds__(256) void k_render_bwd_small(BwdArgs a)
+__global__ __launch_bounds__(256) void k_render_bwd_gather(BwdArgs a)
 {
-    constexpr int NVL = NACC + (DFEAT ? CG : 0);
-    __shared__ List<CG> L;
+    constexpr int NV = NACC + (DFEAT ? CG : 0);
+    __shared__ ListG<CG> L;
     __shared__ unsigned long long s_key[LCAP];
-    __shared__ float s_acc[LCAP * NVL];
+    __shared__ float s_red[4][NV];
+    __shared__ int s_chan[CG], s_act[CG];
     __shared__ int s_n;
-    const int v = blockIdx.z, band = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    const int sp = blockIdx.x, g = blockIdx.y, v = blockIdx.z, tid = threadIdx.x;
     const int P = a.P, C = a.C, W = a.W, H = a.H;
+    const int NVS = NACC + C;
     const size_t HW = (size_t)H * W;
     const size_t go = (size_t)v * P;
-    const int n = build_band_list<CG>(L, s_key, &s_n, P, C, band, a.g.co + go, a.g.xyd + go, a.g.rect + go, a.features);
-    if (n == 0) return;
-    for (int i = tid; i < n * NVL; i += 256) s_acc[i] = 0.0f;
+    const float4* gco = a.g.co + go;
+    const float4* gxyd = a.g.xyd + go;
+    const uint4* grect = a.g.rect + go;
+    float* out = a.accum + (((size_t)v * P + g) * BWD_SPLITS + sp) * NVS;
+    const uint4 rg = grect[g];
+    const int x0 = (int)rg.x * TILE, y0 = (int)rg.y * TILE;
+    const int wpx = min(W, (int)rg.z * TILE) - x0, hpx = min(H, (int)rg.w * TILE) - y0;
+    const int npx = wpx * hpx;  // 0 when culled (rect all zero)
+    const int nchunks = (npx + 255) / 256;
+    if (sp >= nchunks) {  // nothing for this slot (also every slot of an invisible Gaussian)
+        if (tid < NVS) out[tid] = 0.0f;
+        return;
+    }
+    // local list: Gaussians whose tile rect intersects g's, ordered by (depth bits, index)
+    if (tid == 0) s_n = 0;
     __syncthreads();
+    if (tid < P) {
+        const uint4 r = grect[tid];
+        if (r.x < rg.z && r.z > rg.x && r.y < rg.w && r.w > rg.y) {
+            const int slot = atomicAdd(&s_n, 1);
+            s_key[slot] = ((unsigned long long)__float_as_uint(gxyd[tid].z) << 32) | (unsigned)tid;
+        }
+    }
+    __syncthreads();
+    const int n = s_n;
+    if (tid < n) {
+        const unsigned long long key = s_key[tid];
+        int rank = 0;
+        for (int j = 0; j < n; j++) rank += (s_key[j] < key) ? 1 : 0;
+        const int id = (int)(unsigned)key;
+        const float4 xyd = gxyd[id];
+        const uint4 r = grect[id];
+        L.xy[rank] = make_float2(xyd.x, xyd.y);
+        L.co[rank] = gco[id];
+        L.invd[rank] = xyd.w;
+        L.xr[rank] = (int)(r.x | (r.z << 16));
+        L.yr[rank] = (int)(r.y | (r.w << 16));
+        L.id[rank] = id;
+    }
+    __syncthreads();
+    // channel compaction: a channel whose feature is zero for every listed Gaussian multiplies dL/dpixel by exact
+    // zeros everywhere in backward.cu:581-594, so its (dense, far-apart) gradient plane is never read.
+    // All channels stay active when the feature gradient or the background term needs every dL/dpixel.
+    if (tid < CG) {
+        bool act = false;
+        if (tid < C) {
+            act = DFEAT || a.bg != nullptr;
+            for (int k = 0; k < n && !act; k++) act = a.features[L.id[k] * C + tid] != 0.0f;
+        }
+        s_act[tid] = act ? 1 : 0;
+    }
+    __syncthreads();
+    if (tid < CG && s_act[tid]) {
+        int pos = 0;
+        for (int c = 0; c < tid; c++) pos += s_act[c];
+        s_chan[pos] = tid;  // ascending channel order: summation order over channels is fixed
+    }
+    int nc = 0;
+    for (int c = 0; c < CG; c++) nc += s_act[c];
+    __syncthreads();
+    if (tid < n) {
+        const int id = L.id[tid];
+#pragma unroll
+        for (int j = 0; j < CG; j++) L.feat[tid * CG + j] = j < nc ? a.features[id * C + s_chan[j]] : 0.0f;
+    }
+    __syncthreads();
+    int kg = 0;
+    for (int k = 0; k < n; k++) kg = L.id[k] == g ? k : kg;
 
-    const int rows = min(TILE, H - band * TILE);
-    const int Nb = rows * W;
-    const size_t band0 = (size_t)band * TILE * W;
     const bool do_clamp = a.flags & SKS_CLAMP01;
     const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);  // backward.cu:527-528
-    constexpr int CH = BWD_PASSES * 256;
+    float sum[NV];
+#pragma unroll
+    for (int j = 0; j < NV; j++) sum[j] = 0.0f;
 
-#pragma unroll 1
-    for (int pass = 0; pass < BWD_PASSES; pass++) {
-        const int base = chunk * CH + pass * 256 + tid;
-        const bool valid = base < Nb;
-        const size_t pix = band0 + (valid ? base : 0);
-        const int y = (int)(pix / W);
-        const int x = (int)(pix - (size_t)y * W);
-        const int tx = x >> 4;
-        float T = 1.0f;
-        float col[CG];
+    for (int c = sp; c < nchunks; c += BWD_SPLITS) {
+        const int i = c * 256 + tid;
+        if (i >= npx) continue;
+        const int yy = i / wpx;
+        const int x = x0 + (i - yy * wpx), y = y0 + yy;
+        const int tx = x >> 4, ty = y >> 4;
+        const float pxf = (float)x, pyf = (float)y;
+        // re-composite front to back (forward.cu:346-386): T_final, last accepted entry, colours if clamping
+        float T = 1.0f, col[CG];
 #pragma unroll
         for (int ch = 0; ch < CG; ch++) col[ch] = 0.0f;
         int klast = -1;
-        if (valid) {
-            bool done = false;
-            bwd_prepass<CG, true>(L, n, (float)x, (float)y, tx, T, col, do_clamp, klast, done);
+        for (int k = 0; k < n; k++) {
+            const int xr = L.xr[k], yr = L.yr[k];
+            if (tx < (xr & 0xffff) || tx >= (xr >> 16) || ty < (yr & 0xffff) || ty >= (yr >> 16)) continue;
+            const float2 xy = L.xy[k];
+            const float4 co = L.co[k];
+            const float dx = xy.x - pxf, dy = xy.y - pyf;
+            const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+            if (power > 0.0f) continue;
+            const float alpha = fminf(0.99f, co.w * expf_fixed(power));
+            if (alpha < 1.0f / 255.0f) continue;
+            const float test_T = T * (1 - alpha);
+            if (test_T < 0.0001f) break;
+            if (do_clamp) {
+#pragma unroll
+                for (int ch = 0; ch < CG; ch++) col[ch] += L.feat[k * CG + ch] * alpha * T;
+            }
+            T = test_T;
+            klast = k;
         }
-        if (!__any(klast >= 0)) continue;  // nothing composited by this wavefront in this pass
+        if (klast < kg) continue;  // g is behind the last contributor (or nothing contributes) at this pixel
+        const size_t pix = (size_t)y * W + x;
         BwdPix<CG> s;
-        if (klast >= 0) bwd_load_pixel<CG>(s, a, v, pix, HW, col, do_clamp, T);
-        bwd_sweep<CG, true, DFEAT>(L, n, klast, (float)x, (float)y, tx, ddelx_dx, ddely_dy, s, s_acc);
+        bwd_load_pixel<CG>(s, a, v, pix, HW, col, do_clamp, T, s_chan, nc);
+        // back to front down to g (backward.cu:552-636); only g's own terms are kept
+        for (int k = klast; k >= kg; k--) {
+            const int xr = L.xr[k], yr = L.yr[k];
+            if (tx < (xr & 0xffff) || tx >= (xr >> 16) || ty < (yr & 0xffff) || ty >= (yr >> 16)) continue;
+            const float2 xy = L.xy[k];
+            const float4 co = L.co[k];
+            const float dx = xy.x - pxf, dy = xy.y - pyf;
+            const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+            if (power > 0.0f) continue;
+            const float G = expf_fixed(power);
+            const float alpha = fminf(0.99f, co.w * G);
+            if (alpha < 1.0f / 255.0f) continue;
+            s.T = s.T / (1.f - alpha);
+            const float dchannel_dcolor = alpha * s.T;
+            float dL_dalpha = 0.0f;
+            const bool mine = k == kg;
+#pragma unroll
+            for (int ch = 0; ch < CG; ch++) {
+                const float cc = L.feat[k * CG + ch];
+                s.accum_rec[ch] = s.last_alpha * s.last_color[ch] + (1.f - s.last_alpha) * s.accum_rec[ch];
+                s.last_color[ch] = cc;
+                const float dL_dchannel = s.dL[ch];
+                dL_dalpha += (cc - s.accum_rec[ch]) * dL_dchannel;
+                if (DFEAT && mine) sum[NACC + ch] += dchannel_dcolor * dL_dchannel;
+            }
+            const float invd = L.invd[k];
+            s.accum_inv = s.last_alpha * s.last_inv + (1.f - s.last_alpha) * s.accum_inv;
+            s.last_inv = invd;
+            dL_dalpha += (invd - s.accum_inv) * s.dLi;
+            dL_dalpha *= s.T;
+            s.last_alpha = alpha;
+            dL_dalpha += (-s.T_final / (1.f - alpha)) * s.bgdot;
+            if (mine) {
+                const float dL_dG = co.w * dL_dalpha;
+                const float gdx = G * dx, gdy = G * dy;
+                const float dG_ddelx = -gdx * co.x - gdy * co.y;
+                const float dG_ddely = -gdy * co.z - gdx * co.y;
+                sum[0] += dL_dG * dG_ddelx * ddelx_dx;
+                sum[1] += dL_dG * dG_ddely * ddely_dy;
+                sum[2] += -0.5f * gdx * dx * dL_dG;
+                sum[3] += -0.5f * gdx * dy * dL_dG;
+                sum[4] += -0.5f * gdy * dy * dL_dG;
+                sum[5] += G * dL_dalpha;
+                sum[6] += dchannel_dcolor * s.dLi;
+            }
+        }
+    }
+    // workgroup reduction in a fixed order
+    const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+        const float r = wave_sum(sum[j]);
+        if (lane == 0) s_red[wv][j] = r;
     }
     __syncthreads();
-    const int NVS = NACC + C;
-    for (int i = tid; i < n * NVL; i += 256) {
-        const int k = i / NVL, j = i - k * NVL;
-        if (j >= NACC + C) continue;
-        const float val = s_acc[i];
-        if (val != 0.0f) atomicAdd(&a.accum[((size_t)v * P + L.id[k]) * NVS + j], val);
-    }
+    if (tid < NVS) out[tid] = tid < NV ? ((s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid])) : 0.0f;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -597,7 +857,8 @@ struct GeomBwdArgs {
     const float* cov3Dp;
     float smod;
     const int* radii;
-    float* accum;
+    const float* accum;
+    int nsplit;
     float* dmeans3D;
     float* dmeans2D;
     float* dopacity;
@@ -616,17 +877,19 @@ __global__ __launch_bounds__(256) void k_geom_bwd(GeomBwdArgs a, ViewTan vt)
     if (idx >= a.P) return;
     const size_t o = (size_t)v * a.P + idx;
     const int NVS = NACC + a.C;
-    float* acc = a.accum + o * NVS;
+    const float* acc = a.accum + o * a.nsplit * NVS;
     float g[NACC];
 #pragma unroll
     for (int j = 0; j < NACC; j++) {
-        g[j] = acc[j];
-        acc[j] = 0.0f;
+        float t = 0.0f;
+        for (int sp = 0; sp < a.nsplit; sp++) t += acc[sp * NVS + j];  // fixed order: reproducible
+        g[j] = t;
     }
     if (a.dfeat) {
         for (int ch = 0; ch < a.C; ch++) {
-            a.dfeat[o * a.C + ch] = acc[NACC + ch];
-            acc[NACC + ch] = 0.0f;
+            float t = 0.0f;
+            for (int sp = 0; sp < a.nsplit; sp++) t += acc[sp * NVS + NACC + ch];
+            a.dfeat[o * a.C + ch] = t;
         }
     }
     float dmean[3] = { 0, 0, 0 }, dcov[6] = { 0, 0, 0, 0, 0, 0 }, dscale[3] = { 0, 0, 0 }, dq[4] = { 0, 0, 0, 0 };
@@ -1028,30 +1291,34 @@ int check_common(int V, int P, int C, int W, int H)
     if (V < 1 || V > SKS_MAX_VIEWS) return fail(-1, "V=%d out of range [1,%d]", V, SKS_MAX_VIEWS);
     if (P < 0) return fail(-1, "P=%d negative", P);
     if (C < 1 || C > SKS_MAX_CHANNELS) return fail(-1, "C=%d out of range [1,%d]", C, SKS_MAX_CHANNELS);
-    if (W < 1 || H < 1 || W > 65535 * TILE || H > 65535 * TILE) return fail(-1, "image %dx%d out of range", W, H);
+    if (W < 1 || H < 1 || W > 4096 * TILE || H > 65535 * TILE) return fail(-1, "image %dx%d out of range", W, H);
     return 0;
 }
 
 template <int CG>
 void launch_fwd_small(const FwdArgs& a, int V, int gy, hipStream_t st)
 {
-    const int bandpx = TILE * a.W;
+    const int ncomp = T_SLOTS * a.P * V;
+    const int nfill = (a.C + 1) * gy * V;
+    const int cap = (a.P + 15) & ~15;
+    const size_t lds = DynList<CG>::bytes(cap, CG);
+    dim3 grid(ncomp + nfill);
+    const bool nt = !(a.flags & SKS_NO_NT_STORES);
     if (a.W % 4 == 0) {
-        dim3 grid((bandpx + FWD_PASSES * 1024 - 1) / (FWD_PASSES * 1024), gy, V);
-        hipLaunchKernelGGL((k_render_fwd_small<CG, 4>), grid, dim3(256), 0, st, a);
+        if (nt) hipLaunchKernelGGL((k_render_fwd_sparse<CG, 4, true>), grid, dim3(256), lds, st, a, ncomp, gy);
+        else hipLaunchKernelGGL((k_render_fwd_sparse<CG, 4, false>), grid, dim3(256), lds, st, a, ncomp, gy);
     } else {
-        dim3 grid((bandpx + FWD_PASSES * 256 - 1) / (FWD_PASSES * 256), gy, V);
-        hipLaunchKernelGGL((k_render_fwd_small<CG, 1>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((k_render_fwd_sparse<CG, 1, false>), grid, dim3(256), lds, st, a, ncomp, gy);
     }
 }
 
 template <int CG>
 void launch_bwd_small(const BwdArgs& a, int V, int gy, bool dfeat, hipStream_t st)
 {
-    const int bandpx = TILE * a.W;
-    dim3 grid((bandpx + BWD_PASSES * 256 - 1) / (BWD_PASSES * 256), gy, V);
-    if (dfeat) hipLaunchKernelGGL((k_render_bwd_small<CG, true>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((k_render_bwd_small<CG, false>), grid, dim3(256), 0, st, a);
+    (void)gy;
+    dim3 grid(BWD_SPLITS, a.P, V);
+    if (dfeat) hipLaunchKernelGGL((k_render_bwd_gather<CG, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_render_bwd_gather<CG, false>), grid, dim3(256), 0, st, a);
 }
 
 }  // namespace
@@ -1067,7 +1334,7 @@ int sks_scratch_bytes(int V, int P, int C, int W, int H, size_t bin_capacity, si
     const int NT = ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
     if (geom) *geom = geom_bytes(V, P > 0 ? P : 1);
     if (binning) *binning = bin_bytes(V, NT, bin_capacity);
-    if (accum) *accum = (size_t)V * (P > 0 ? P : 1) * (NACC + C) * sizeof(float);
+    if (accum) *accum = (size_t)V * (P > 0 ? P : 1) * BWD_SPLITS * (NACC + C) * sizeof(float);
     return 0;
 }
 
@@ -1104,11 +1371,14 @@ int sks_forward(int V, int P, int C, int W, int H, const float* viewmatrix, cons
     const int cg = pick_cg(C);
     const bool small = P <= SKS_SMALL_P && !(flags & SKS_FORCE_BINNED);
     if (small) {
-        switch (cg) {
-            case 4: launch_fwd_small<4>(a, V, gy, st); break;
-            case 16: launch_fwd_small<16>(a, V, gy, st); break;
-            case 20: launch_fwd_small<20>(a, V, gy, st); break;
-            default: launch_fwd_small<32>(a, V, gy, st); break;
+        {
+            ProfScope prof(0, st);
+            switch (cg) {
+                case 4: launch_fwd_small<4>(a, V, gy, st); break;
+                case 16: launch_fwd_small<16>(a, V, gy, st); break;
+                case 20: launch_fwd_small<20>(a, V, gy, st); break;
+                default: launch_fwd_small<32>(a, V, gy, st); break;
+            }
         }
         STAGE_CHECK("render(small)");
         return 0;
@@ -1125,11 +1395,14 @@ int sks_forward(int V, int P, int C, int W, int H, const float* viewmatrix, cons
     STAGE_CHECK("binning");
     BinView bv{ b.ranges, b.keys, bin_capacity, NT };
     dim3 grid(gx, gy, V);
-    switch (cg) {
-        case 4: hipLaunchKernelGGL((k_render_fwd_binned<4>), grid, dim3(256), 0, st, a, bv); break;
-        case 16: hipLaunchKernelGGL((k_render_fwd_binned<16>), grid, dim3(256), 0, st, a, bv); break;
-        case 20: hipLaunchKernelGGL((k_render_fwd_binned<20>), grid, dim3(256), 0, st, a, bv); break;
-        default: hipLaunchKernelGGL((k_render_fwd_binned<32>), grid, dim3(256), 0, st, a, bv); break;
+    {
+        ProfScope prof(0, st);
+        switch (cg) {
+            case 4: hipLaunchKernelGGL((k_render_fwd_binned<4>), grid, dim3(256), 0, st, a, bv); break;
+            case 16: hipLaunchKernelGGL((k_render_fwd_binned<16>), grid, dim3(256), 0, st, a, bv); break;
+            case 20: hipLaunchKernelGGL((k_render_fwd_binned<20>), grid, dim3(256), 0, st, a, bv); break;
+            default: hipLaunchKernelGGL((k_render_fwd_binned<32>), grid, dim3(256), 0, st, a, bv); break;
+        }
     }
     STAGE_CHECK("render(binned)");
     return 0;
@@ -1159,6 +1432,7 @@ int sks_backward(int V, int P, int C, int W, int H, const float* viewmatrix, con
     const bool dfeat = dL_dfeatures != nullptr;
     const bool small = P <= SKS_SMALL_P && !(flags & SKS_FORCE_BINNED);
     if (small) {
+        ProfScope prof(1, st);
         switch (cg) {
             case 4: launch_bwd_small<4>(a, V, gy, dfeat, st); break;
             case 16: launch_bwd_small<16>(a, V, gy, dfeat, st); break;
@@ -1168,9 +1442,11 @@ int sks_backward(int V, int P, int C, int W, int H, const float* viewmatrix, con
         STAGE_CHECK("render-backward(small)");
     } else {
         if (!binning) return fail(-2, "binned path needs the forward's binning buffer");
+        HIP_TRY(hipMemsetAsync(accum, 0, (size_t)V * P * (NACC + C) * sizeof(float), st));  // atomics target
         Bin b = bin_from(const_cast<void*>(binning), V, NT, bin_capacity);
         BinView bv{ b.ranges, b.keys, bin_capacity, NT };
         dim3 grid(gx, gy, V);
+        ProfScope prof(1, st);
 #define SKS_BWD_BINNED(CGV)                                                                                         \
     if (dfeat) hipLaunchKernelGGL((k_render_bwd_binned<CGV, true>), grid, dim3(256), 0, st, a, bv);                 \
     else hipLaunchKernelGGL((k_render_bwd_binned<CGV, false>), grid, dim3(256), 0, st, a, bv)
@@ -1184,10 +1460,33 @@ int sks_backward(int V, int P, int C, int W, int H, const float* viewmatrix, con
         STAGE_CHECK("render-backward(binned)");
     }
     GeomBwdArgs ga{ P, C, W, H, flags, viewmatrix, projmatrix, means3D, opacities, scales, rotations, cov3D_precomp,
-                    scale_modifier, radii, (float*)accum, dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dscales,
+                    scale_modifier, radii, (const float*)accum, small ? BWD_SPLITS : 1, dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dscales,
                     dL_drotations, dL_dcov3D, dL_dfeatures };
     hipLaunchKernelGGL(k_geom_bwd, dim3((P + 255) / 256, V), dim3(256), 0, st, ga, vt);
     STAGE_CHECK("geometry-backward");
+    return 0;
+}
+
+int sks_prof_enable(int on)
+{
+    g_prof_on = on != 0;
+    return 0;
+}
+
+int sks_prof_read(int kind, double* total_ms, long long* launches)
+{
+    if (kind < 0 || kind > 1 || !total_ms || !launches) return fail(-2, "bad profile query");
+    ProfKind& p = g_prof[kind];
+    double tot = 0;
+    for (int i = 0; i < p.n; i++) {
+        HIP_TRY(hipEventSynchronize(p.e[i]));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, p.b[i], p.e[i]));
+        tot += ms;
+    }
+    *total_ms = tot;
+    *launches = p.n;
+    p.n = 0;
     return 0;
 }
 

@@ -36,13 +36,12 @@ _accum_cache = {}
 
 
 def _accum(device, stream, V, P, C):
-    """Backward accumulators: zero on entry, left zero by sks_backward (consume-and-clear), so one zero-filled
-    buffer per (device, stream, shape) serves every call without a memset."""
+    """Backward partial-sum scratch (uninitialised is fine): one buffer per (device, stream, shape)."""
     key = (device.index, stream, V, P, C)
     buf = _accum_cache.get(key)
     if buf is None:
         _, _, nbytes = _lib.scratch_bytes(V, max(P, 1), C, 16, 16)
-        buf = torch.zeros(nbytes // 4, dtype=torch.float32, device=device)
+        buf = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
         _accum_cache[key] = buf
     return buf
 
@@ -106,7 +105,7 @@ class ForwardState:
 
 def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotations, cov3D_precomp,
                   scale_modifier=1.0, antialiasing=False, clamp01=False, debug=False, force_binned=False,
-                  bin_capacity=None, want_aux=False):
+                  bin_capacity=None, want_aux=False, tune_flags=0):
     """Raw batched forward.  Returns (color (V,C,H,W), invdepth (V,1,H,W), radii (V,P) int32, state[, final_T, n_contrib])."""
     lib = _lib.load()
     means3D = _f32c(means3D, "means3D")
@@ -123,7 +122,7 @@ def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotati
     scales, rotations, cov3D_precomp = _f32c(scales, "scales"), _f32c(rotations, "rotations"), _f32c(cov3D_precomp, "cov3D_precomp")
     V, W, H = views.V, views.W, views.H
     flags = (_lib.SKS_ANTIALIASING if antialiasing else 0) | (_lib.SKS_CLAMP01 if clamp01 else 0) | \
-            (_lib.SKS_DEBUG_SYNC if debug else 0) | (_lib.SKS_FORCE_BINNED if force_binned else 0)
+            (_lib.SKS_DEBUG_SYNC if debug else 0) | (_lib.SKS_FORCE_BINNED if force_binned else 0) | int(tune_flags)
     binned = force_binned or P > _lib.SKS_SMALL_P
     if binned and bin_capacity is None:
         bin_capacity = max(4096, 16 * P)
