@@ -101,6 +101,30 @@ int sks_mark_visible(int P, const float* means3D, const float* viewmatrix, const
 int sks_export_lists(int V, int W, int H, const void* binning, size_t bin_capacity,
                      uint32_t* point_list, uint32_t* ranges, void* stream);
 
+/* Fused masked-L2 heat-map loss of the loop (utils/loss_utils.py:86-100 `l2_loss_gaussian`, called at train.py:150
+ * on the clamped render; its autograd backward at train.py:161).  Per view v over n_per_view = C*H*W elements:
+ *   N_v = #{gt > 0 or render > 0},  S_v = sum over that mask of (render - gt)^2  (loss_v = S_v / N_v),
+ *   dL_unscaled = 2 (render - gt) on the mask, 0 elsewhere  (may be NULL: loss only).
+ * The true gradient is dL_unscaled / N_v; everything downstream is linear in it, so callers scale the resulting
+ * parameter gradients by 1 / N_v instead of re-reading the image.  sums: V x {S_v, N_v} doubles (zeroed by the call). */
+int sks_masked_l2(int V, size_t n_per_view, const float* render, const float* gt, float* dL_unscaled, double* sums,
+                  void* stream);
+
+/* Replaces fusedssim (submodules/fused-ssim/ssim.cu:368-404, binding ext.cpp): img1, img2, ssim_map and the three
+ * optional partial-derivative maps (train == true) are (B,CH,H,W) fp32; "same" zero padding. */
+int sks_fused_ssim_fwd(int B, int CH, int H, int W, float C1, float C2, const float* img1, const float* img2,
+                       float* ssim_map, float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12, void* stream);
+
+/* Replaces fusedssim_backward (ssim.cu:406-444): dL_dimg1 (B,CH,H,W); only img1 is differentiable
+ * (fused_ssim/__init__.py:32). */
+int sks_fused_ssim_bwd(int B, int CH, int H, int W, float C1, float C2, const float* img1, const float* img2,
+                       const float* dL_dmap, const float* dm_dmu1, const float* dm_dsigma1_sq, const float* dm_dsigma12,
+                       float* dL_dimg1, void* stream);
+
+/* Replaces distCUDA2 (submodules/simple-knn/spatial.cu:15-26 -> SimpleKNN::knn simple_knn.cu:186-222):
+ * points (P,3) -> mean squared distance to the 3 nearest neighbours (P). */
+int sks_knn3_meandist2(int P, const float* points, float* mean_dist2, void* stream);
+
 /* Measurement hook used by bench.py (no reference counterpart): while enabled, the dominant kernel of sks_forward
  * (kind 0: forward compositor) and of sks_backward (kind 1: backward compositor) is bracketed by hipEvents recorded
  * on the caller's stream.  sks_prof_read waits for the recorded events, returns the summed kernel time in

@@ -32,6 +32,10 @@ SIGNATURES = {
                           _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sks_mark_visible": (_i, [_i, _vp, _vp, _vp, _vp, _vp]),
     "sks_export_lists": (_i, [_i, _i, _i, _vp, _sz, _vp, _vp, _vp]),
+    "sks_masked_l2": (_i, [_i, _sz, _vp, _vp, _vp, _vp, _vp]),
+    "sks_fused_ssim_fwd": (_i, [_i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sks_fused_ssim_bwd": (_i, [_i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sks_knn3_meandist2": (_i, [_i, _vp, _vp, _vp]),
     "sks_prof_enable": (_i, [_i]),
     "sks_prof_read": (_i, [_i, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
 }

@@ -675,14 +675,15 @@ __global__ __launch_bounds__(256) void k_render_bwd_gather(BwdArgs a)
     const float4* gco = a.g.co + go;
     const float4* gxyd = a.g.xyd + go;
     const uint4* grect = a.g.rect + go;
-    float* out = a.accum + (((size_t)v * P + g) * BWD_SPLITS + sp) * NVS;
+    // partial-sum slots, layout (v, g, value, split): the BWD_SPLITS partials of one value are one 64-byte line
+    float* out = a.accum + ((size_t)v * P + g) * NVS * BWD_SPLITS + sp;
     const uint4 rg = grect[g];
     const int x0 = (int)rg.x * TILE, y0 = (int)rg.y * TILE;
     const int wpx = min(W, (int)rg.z * TILE) - x0, hpx = min(H, (int)rg.w * TILE) - y0;
     const int npx = wpx * hpx;  // 0 when culled (rect all zero)
     const int nchunks = (npx + 255) / 256;
     if (sp >= nchunks) {  // nothing for this slot (also every slot of an invisible Gaussian)
-        if (tid < NVS) out[tid] = 0.0f;
+        if (tid < NVS) out[tid * BWD_SPLITS] = 0.0f;
         return;
     }
     // local list: Gaussians whose tile rect intersects g's, ordered by (depth bits, index)
@@ -837,7 +838,8 @@ __global__ __launch_bounds__(256) void k_render_bwd_gather(BwdArgs a)
         if (lane == 0) s_red[wv][j] = r;
     }
     __syncthreads();
-    if (tid < NVS) out[tid] = tid < NV ? ((s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid])) : 0.0f;
+    if (tid < NVS)
+        out[tid * BWD_SPLITS] = tid < NV ? ((s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid])) : 0.0f;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -877,18 +879,35 @@ __global__ __launch_bounds__(256) void k_geom_bwd(GeomBwdArgs a, ViewTan vt)
     if (idx >= a.P) return;
     const size_t o = (size_t)v * a.P + idx;
     const int NVS = NACC + a.C;
-    const float* acc = a.accum + o * a.nsplit * NVS;
+    const float* acc = a.accum + o * a.nsplit * NVS;  // layout (value, split)
     float g[NACC];
+    if (a.nsplit == BWD_SPLITS) {
+        static_assert(BWD_SPLITS == 16, "4 x float4 per value");
+        float4 q[NACC][4];
 #pragma unroll
-    for (int j = 0; j < NACC; j++) {
-        float t = 0.0f;
-        for (int sp = 0; sp < a.nsplit; sp++) t += acc[sp * NVS + j];  // fixed order: reproducible
-        g[j] = t;
+        for (int j = 0; j < NACC - 1; j++)   // all loads in flight before the first add
+#pragma unroll
+            for (int i = 0; i < 4; i++) q[j][i] = reinterpret_cast<const float4*>(acc + j * BWD_SPLITS)[i];
+#pragma unroll
+        for (int j = 0; j < NACC - 1; j++) {  // fixed order: reproducible
+            float t = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 4; i++) t += (q[j][i].x + q[j][i].y) + (q[j][i].z + q[j][i].w);
+            g[j] = t;
+        }
+        g[NACC - 1] = 0.0f;
+    } else {
+#pragma unroll
+        for (int j = 0; j < NACC; j++) {
+            float t = 0.0f;
+            for (int sp = 0; sp < a.nsplit; sp++) t += acc[j * a.nsplit + sp];
+            g[j] = t;
+        }
     }
     if (a.dfeat) {
         for (int ch = 0; ch < a.C; ch++) {
             float t = 0.0f;
-            for (int sp = 0; sp < a.nsplit; sp++) t += acc[sp * NVS + NACC + ch];
+            for (int sp = 0; sp < a.nsplit; sp++) t += acc[(NACC + ch) * a.nsplit + sp];
             a.dfeat[o * a.C + ch] = t;
         }
     }
@@ -1326,6 +1345,10 @@ void launch_bwd_small(const BwdArgs& a, int V, int gy, bool dfeat, hipStream_t s
 extern "C" {
 
 const char* sks_last_error(void) { return g_err; }
+void sks_set_error_(const char* msg)  // used by the other translation units of the library
+{
+    snprintf(g_err, sizeof(g_err), "%s", msg);
+}
 int sks_version(void) { return 1; }
 
 int sks_scratch_bytes(int V, int P, int C, int W, int H, size_t bin_capacity, size_t* geom, size_t* binning, size_t* accum)

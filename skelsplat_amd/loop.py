@@ -1,0 +1,190 @@
+"""Multi-view optimisation loop of one scene (reference: train.py:130-222), MI355X layout.
+
+What the reference does per iteration: pick view (iteration-1) % V, render it, masked-L2 against that view's heat-map
+plus lambda * limb-symmetry loss, autograd.grad wrt (xyz, _scaling, _rotation, _opacity); store the xyz gradient in
+slot `view` of a V-slot buffer, overwrite the other three .grad with this view's; every `accumulation_steps`
+iterations: xyz.grad = mean over the V slots, Adam step.
+
+Because the parameters only change at those steps, the views of one accumulation group are independent given the
+parameters.  Here a group is ONE batched forward + ONE batched backward launch sequence (blockIdx.z = view), and
+with torch.distributed the views are sharded over ranks (view v -> rank v % world): each rank renders its views and a
+single all_gather of the (V_local, P, 11) per-view parameter gradients over RCCL rebuilds the V slots in view order
+on every rank, so the mean uses the reference's summation order and every rank takes the identical Adam step
+(no parameter broadcast).  Nothing in the group synchronises with the host.
+"""
+import math
+
+import torch
+import torch.distributed as dist
+
+from . import rasterizer as R
+from .scene import DATASETS
+
+
+def l2_loss_gaussian(rendering, gt_heatmap):
+    """utils/loss_utils.py:86-100 ('mean' reduction): mean squared error over pixels where gt > 0 or rendering > 0."""
+    mask = (gt_heatmap > 0) | (rendering > 0)
+    error = (rendering - gt_heatmap) ** 2
+    return error[mask].mean(), error
+
+
+def limb_3d_consistency_loss(xyz, dataset):
+    """utils/loss_utils.py:226-250."""
+    (la0, la1), (ra0, ra1), (ll0, ll1), (rl0, rl1) = DATASETS[dataset]["limbs"]
+    l_arm = torch.norm(xyz[la0] - xyz[la1], dim=-1)
+    r_arm = torch.norm(xyz[ra0] - xyz[ra1], dim=-1)
+    l_leg = torch.norm(xyz[ll0] - xyz[ll1], dim=-1)
+    r_leg = torch.norm(xyz[rl0] - xyz[rl1], dim=-1)
+    return torch.norm(l_arm - r_arm) + torch.norm(l_leg - r_leg)
+
+
+def masked_l2_grad_torch(render, gt):
+    """Plain-tensor-op statement of the masked-L2 gradient (device-side, no host sync); render, gt: (V,C,H,W).
+    Returns (dL, per-view loss, per-view scale): the true gradient is dL * scale[v]."""
+    mask = (gt > 0) | (render > 0)
+    diff = render - gt
+    n = mask.sum(dim=(1, 2, 3)).clamp_min(1).to(render.dtype)
+    loss = (diff * diff * mask).sum(dim=(1, 2, 3)) / n
+    dL = 2.0 * diff * mask
+    return dL, loss, 1.0 / n
+
+
+def activation_chain(gm, g):
+    """Per-view gradients wrt the activated tensors -> wrt the raw parameters (what autograd does through
+    exp / normalize / sigmoid in gaussian_model.py:39-47, 102-131).  g: dict of (V,P,...) tensors."""
+    s = gm.get_scaling.detach()
+    o = gm.get_opacity.detach()
+    raw_q = gm._rotation.detach()
+    nrm = raw_q.norm(dim=1, keepdim=True).clamp_min(1e-12)
+    q = raw_q / nrm
+    d_scaling = g["scales"] * s[None]
+    d_opacity = g["opacities"] * (o * (1 - o))[None]
+    gq = g["rotations"]
+    d_rotation = (gq - q[None] * (q[None] * gq).sum(-1, keepdim=True)) / nrm[None]
+    return d_scaling, d_rotation, d_opacity
+
+
+class MultiViewLoop:
+    """One scene.  `heatmaps`: (V,C,H,W) pseudo-GT on this rank's device (only the local views are read).
+    `loss_grad`: callable (render, gt) -> (dL_unscaled, per-view loss, per-view scale); default: the fused HIP kernel
+    (ops.masked_l2_grad_fused); loop.masked_l2_grad_torch is the same thing in tensor ops."""
+
+    def __init__(self, gaussians, cameras, heatmaps, dataset="h36m", accumulation_steps=4, lambda_consistency=1e-5,
+                 bg=None, antialiasing=False, loss_grad=None, group=None, view_grad_fn=None):
+        self.gm = gaussians
+        self.dataset = dataset
+        self.V = len(cameras)
+        self.acc_steps = int(accumulation_steps)
+        self.lambda_consistency = float(lambda_consistency)
+        self.antialiasing = antialiasing
+        self.group = group
+        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.rank = dist.get_rank(group) if self.world > 1 else 0
+        dev = gaussians._xyz.device
+        self.device = dev
+        self.local_ids = [v for v in range(self.V) if v % self.world == self.rank]
+        # view_grad_fn(loop) -> ((V_local,P,11) raw-parameter gradients, per-view losses) replaces the HIP path;
+        # only the multi-process CPU tests use it (gloo has no GPU), the product path is _local_view_grads.
+        self.view_grad_fn = view_grad_fn
+        self.cameras = cameras
+        self.views = (R.ViewBatch.from_cameras([cameras[v] for v in self.local_ids])
+                      if (self.local_ids and view_grad_fn is None) else None)
+        self.gt = heatmaps[self.local_ids].contiguous() if self.local_ids else None
+        self.bg = bg
+        if loss_grad is None and view_grad_fn is None:
+            from .ops import masked_l2_grad_fused
+            loss_grad = masked_l2_grad_fused
+        self.loss_grad = loss_grad
+        P = gaussians._xyz.shape[0]
+        self.P = P
+        # V-slot buffer of per-view xyz gradients (train.py:121); persists across groups (quirk Q8)
+        self.accumulated_grads = torch.zeros((self.V, P, 3), device=dev)
+        self.iteration = 0
+        self.last_losses = None
+        # all_gather needs equal shard sizes: pad every rank to ceil(V / world) views
+        self.vmax = (self.V + self.world - 1) // self.world
+
+    # -- one accumulation group --------------------------------------------------------------------------
+    def _local_view_grads(self):
+        """Renders this rank's views and returns (V_local, P, 11) raw-parameter gradients + per-view losses."""
+        gm = self.gm
+        P = self.P
+        with torch.no_grad():
+            means = gm._xyz.detach()
+            feats = gm.get_features.reshape(P, -1)
+            opac = gm.get_opacity.detach()
+            scales = gm.get_scaling.detach()
+            quats = gm.get_rotation.detach()
+            color, inv, radii, st = R.forward_views(self.views, means, feats, opac, scales, quats, None,
+                                                    antialiasing=self.antialiasing, clamp01=True)
+            dL, losses, scale = self.loss_grad(color, self.gt)
+            g = R.backward_views(st, means, feats, opac, scales, quats, None, dL, None, bg=self.bg)
+            d_scaling, d_rotation, d_opacity = activation_chain(gm, g)
+            packed = torch.cat([g["means3D"], d_scaling, d_rotation, d_opacity], dim=-1)  # (V_local, P, 11)
+            packed = packed * scale[:, None, None]   # 1 / N_mask of each view (the backward is linear in dL)
+        return packed, losses
+
+    def _consistency_grad(self):
+        xyz = self.gm._xyz.detach().clone().requires_grad_(True)
+        loss = limb_3d_consistency_loss(xyz, self.dataset) * self.lambda_consistency
+        (gx,) = torch.autograd.grad(loss, xyz)
+        return gx, loss.detach()
+
+    def step_group(self):
+        """Runs iterations self.iteration+1 .. up to the next optimiser step (train.py:130-222)."""
+        gm = self.gm
+        it0 = self.iteration + 1
+        it1 = it0
+        while it1 % self.acc_steps != 0:
+            it1 += 1
+        view_of_iter = [(it - 1) % self.V for it in range(it0, it1 + 1)]   # train.py:136-138
+        if not self.local_ids:
+            packed, losses = None, None
+        elif self.view_grad_fn is not None:
+            packed, losses = self.view_grad_fn(self)
+        else:
+            packed, losses = self._local_view_grads()
+        dev = self.device
+        if self.world > 1:
+            shard = torch.zeros((self.vmax, self.P, 11), device=dev)
+            if packed is not None:
+                shard[:packed.shape[0]] = packed
+            allg = torch.empty((self.world * self.vmax, self.P, 11), device=dev)
+            dist.all_gather_into_tensor(allg, shard, group=self.group)
+            # rank r, slot k  <->  view r + k * world
+            full = torch.zeros((self.V, self.P, 11), device=dev)
+            for r in range(self.world):
+                ids = [v for v in range(self.V) if v % self.world == r]
+                if ids:
+                    full[ids] = allg[r * self.vmax:r * self.vmax + len(ids)]
+        else:
+            full = packed
+        gcons, _ = self._consistency_grad() if self.lambda_consistency != 0.0 else (0.0, None)
+        # every view's loss contains the consistency term, so every slot carries its gradient (train.py:150-152,175)
+        for v in dict.fromkeys(view_of_iter):
+            self.accumulated_grads[v] = full[v, :, 0:3] + gcons
+        last = view_of_iter[-1]                                            # quirk Q7: last view's grads win
+        if gm._xyz.grad is None:
+            for p in (gm._xyz, gm._scaling, gm._rotation, gm._opacity):
+                p.grad = torch.zeros_like(p)
+        gm._scaling.grad = full[last, :, 3:6].contiguous()
+        gm._rotation.grad = full[last, :, 6:10].contiguous()
+        gm._opacity.grad = full[last, :, 10:11].contiguous()
+        gm._xyz.grad = self.accumulated_grads.mean(dim=0)                  # train.py:215-218
+        gm.update_learning_rate(it1)                                       # quirk Q9: schedule indexed by iteration
+        with torch.no_grad():
+            gm.optimizer.step()
+            gm.optimizer.zero_grad(set_to_none=True)
+        self.iteration = it1
+        self.last_losses = losses
+        return it1
+
+    def run(self, iterations=500):
+        while self.iteration < iterations:
+            self.step_group()
+        return self.gm._xyz.detach()
+
+
+def mpjpe(pred, gt):
+    """eval.py:123-124: mean Euclidean joint error (same units as the inputs, mm)."""
+    return torch.norm(pred - gt, dim=1).mean()

@@ -1,0 +1,109 @@
+"""Python surface of the smaller hot-path ops (C ABI: sks_masked_l2, sks_fused_ssim_fwd/bwd, sks_knn3_meandist2)."""
+import torch
+
+from . import _lib
+from .rasterizer import _need_gpu
+
+
+def _chk(t, name):
+    _need_gpu(t, name)
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"skelsplat_amd: `{name}` must be float32 (got {t.dtype})")
+    return t.contiguous()
+
+
+def masked_l2(render, gt, want_grad=True):
+    """Fused `l2_loss_gaussian` (utils/loss_utils.py:86-100) for V views: render, gt (V,C,H,W).
+    Returns (dL_unscaled or None, S (V,) f64, N (V,) f64): loss_v = S_v / N_v and dloss_v/drender = dL_unscaled / N_v."""
+    render, gt = _chk(render, "render"), _chk(gt, "gt")
+    if render.shape != gt.shape:
+        raise RuntimeError(f"render {tuple(render.shape)} and gt {tuple(gt.shape)} differ")
+    V = render.shape[0]
+    n = render[0].numel()
+    dev = render.device
+    dL = torch.empty_like(render) if want_grad else None
+    sums = torch.empty((V, 2), dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.load().sks_masked_l2(V, n, render.data_ptr(), gt.data_ptr(), _lib.ptr(dL), sums.data_ptr(),
+                                       torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(rc, "sks_masked_l2")
+    return dL, sums[:, 0], sums[:, 1]
+
+
+def masked_l2_grad_fused(render, gt):
+    """Drop-in for loop.masked_l2_grad_torch: (true gradient, per-view loss)."""
+    dL, S, N = masked_l2(render, gt)
+    n = N.clamp_min(1.0)
+    return dL, (S / n).to(torch.float32), (1.0 / n).to(torch.float32)
+
+
+class FusedSSIMMap(torch.autograd.Function):
+    """submodules/fused-ssim/fused_ssim/__init__.py:8-32."""
+
+    @staticmethod
+    def forward(ctx, C1, C2, img1, img2, padding="same", train=True):
+        img1c, img2c = _chk(img1, "img1"), _chk(img2, "img2")
+        if img1c.dim() != 4 or img1c.shape != img2c.shape:
+            raise RuntimeError("fused_ssim expects two (B,CH,H,W) tensors of equal shape")
+        B, CH, H, W = img1c.shape
+        dev = img1c.device
+        ssim_map = torch.empty_like(img1c)
+        parts = [torch.empty_like(img1c) for _ in range(3)] if train else [None, None, None]
+        with torch.cuda.device(dev):
+            rc = _lib.load().sks_fused_ssim_fwd(B, CH, H, W, float(C1), float(C2), img1c.data_ptr(), img2c.data_ptr(),
+                                                ssim_map.data_ptr(), _lib.ptr(parts[0]), _lib.ptr(parts[1]),
+                                                _lib.ptr(parts[2]), torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(rc, "sks_fused_ssim_fwd")
+        if padding == "valid":
+            ssim_map = ssim_map[:, :, 5:-5, 5:-5]
+        emp = torch.empty(0, device=dev)
+        ctx.save_for_backward(img1c.detach(), img2c, *(p if p is not None else emp for p in parts))
+        ctx.C1, ctx.C2, ctx.padding, ctx.train = C1, C2, padding, train
+        return ssim_map
+
+    @staticmethod
+    def backward(ctx, opt_grad):
+        img1, img2, dm_dmu1, dm_dsigma1_sq, dm_dsigma12 = ctx.saved_tensors
+        if not ctx.train:
+            raise RuntimeError("fused_ssim was called with train=False: no backward state was kept")
+        dL_dmap = opt_grad
+        if ctx.padding == "valid":
+            dL_dmap = torch.zeros_like(img1)
+            dL_dmap[:, :, 5:-5, 5:-5] = opt_grad
+        dL_dmap = dL_dmap.contiguous()
+        B, CH, H, W = img1.shape
+        dev = img1.device
+        grad = torch.empty_like(img1)
+        with torch.cuda.device(dev):
+            rc = _lib.load().sks_fused_ssim_bwd(B, CH, H, W, float(ctx.C1), float(ctx.C2), img1.data_ptr(), img2.data_ptr(),
+                                                dL_dmap.data_ptr(), dm_dmu1.data_ptr(), dm_dsigma1_sq.data_ptr(),
+                                                dm_dsigma12.data_ptr(), grad.data_ptr(),
+                                                torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(rc, "sks_fused_ssim_bwd")
+        return None, None, grad, None, None, None
+
+
+allowed_padding = ["same", "valid"]
+
+
+def fused_ssim(img1, img2, padding="same", train=True):
+    """submodules/fused-ssim/fused_ssim/__init__.py:34-41."""
+    C1 = 0.01 ** 2
+    C2 = 0.03 ** 2
+    assert padding in allowed_padding
+    return FusedSSIMMap.apply(C1, C2, img1, img2, padding, train).mean()
+
+
+def distCUDA2(points):
+    """submodules/simple-knn/spatial.cu:15-26: mean squared distance to the 3 nearest neighbours, (P,)."""
+    pts = _chk(points, "points")
+    if pts.dim() != 2 or pts.shape[1] != 3:
+        raise RuntimeError("points must have dimensions (num_points, 3)")
+    P = pts.shape[0]
+    out = torch.zeros(P, dtype=torch.float32, device=pts.device)
+    if P:
+        with torch.cuda.device(pts.device):
+            rc = _lib.load().sks_knn3_meandist2(P, pts.data_ptr(), out.data_ptr(),
+                                                torch.cuda.current_stream(pts.device).cuda_stream)
+        _lib.check(rc, "sks_knn3_meandist2")
+    return out
