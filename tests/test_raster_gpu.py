@@ -145,3 +145,60 @@ def test_full_size_properties(device):
     mask = torch.nn.functional.max_pool2d(mask, 33, stride=1, padding=16)
     g3 = R.backward_views(st_s, *args, dL * mask)
     util.assert_close("support", g3["means3D"].cpu(), g1["means3D"].cpu(), rtol=1e-4)
+
+
+class _Pipe:  # the `pipeline:` group of configs/*.yaml (configs/h36m.yaml:44-48)
+    convert_SHs_python = False
+    compute_cov3D_python = False
+    debug = False
+    antialiasing = False
+
+
+@pytest.mark.parametrize("dataset,key", [("h36m", "diff-gaussian-rasterization-h36m"),
+                                         ("panoptic", "diff-gaussian-rasterization-panoptic"),
+                                         ("occlusion-person", "diff-gaussian-rasterization-op")])
+def test_render_functions_drop_in_like_train_py(device, dataset, key):
+    """train.py:63,140-161 verbatim call shape: render_functions[pipe.rendering](cam, gaussians, pipe, bg, ...) then
+    torch.autograd.grad(loss, [xyz, _scaling, _rotation, _opacity], create_graph=True, retain_graph=True)."""
+    import math
+    from gaussian_renderer import render_functions
+    from skelsplat_amd.scene import SyntheticScene, GaussianModel
+    from skelsplat_amd.loop import l2_loss_gaussian, limb_3d_consistency_loss
+    from oracle import torch_ref
+    W, H = 160, 128
+    sc = SyntheticScene(dataset, n_views=2, seed=5, W=W, H=H, ring=2500.0, fx=1145.0 * 0.16 * 1.5, device=device)
+    gm = GaussianModel().create_from_points(sc.pose_3d_init, sc.spatial_lr_scale, sc.n_joints, scaling=3.9,
+                                            scene_type=dataset, device=device)
+    with torch.no_grad():   # finite opacity, anisotropic scales, non-trivial rotation: every activation Jacobian matters
+        gm._opacity.fill_(1.5)
+        gm._rotation.add_(0.2 * torch.randn(gm._rotation.shape, generator=torch.Generator().manual_seed(0)).to(device))
+        gm._scaling.add_(0.3 * torch.randn(gm._scaling.shape, generator=torch.Generator().manual_seed(2)).to(device))
+    render = render_functions[key]
+    bg = torch.zeros(3, device=device)
+    cam = sc.cameras[1]
+    pkg = render(cam, gm, _Pipe, bg, use_trained_exp=False, separate_sh=False)
+    image, vsp, radii = pkg["render"], pkg["viewspace_points"], pkg["radii"]
+    assert image.shape == (sc.n_joints, H, W) and pkg["depth"].shape == (1, H, W)
+    assert pkg["visibility_filter"].shape[1] == 1 and pkg["visibility_filter"].dtype == torch.int64
+    gt = torch.rand(image.shape, generator=torch.Generator().manual_seed(1)).to(device) * (image.detach() > 0)
+    l2, _ = l2_loss_gaussian(image, gt)
+    loss = l2 + limb_3d_consistency_loss(gm.get_xyz, dataset) * 1e-5
+    params = [gm.get_xyz, gm._scaling, gm._rotation, gm._opacity]
+    grads = torch.autograd.grad(loss, params, create_graph=True, retain_graph=True)
+    # the same thing on the PyTorch oracle (CPU, fp64 activations -> fp32 rasterizer math in fp64)
+    gm2 = GaussianModel().create_from_points(sc.pose_3d_init, sc.spatial_lr_scale, sc.n_joints, scaling=3.9, scene_type=dataset)
+    with torch.no_grad():
+        gm2._opacity.copy_(gm._opacity.cpu()); gm2._rotation.copy_(gm._rotation.cpu()); gm2._scaling.copy_(gm._scaling.cpu())
+    camc = sc.cameras[1]
+    col, rad2, _ = torch_ref.rasterize(gm2.get_xyz, None, gm2.get_features.reshape(sc.n_points, -1), gm2.get_opacity,
+                                       gm2.get_scaling, gm2.get_rotation, None, camc.world_view_transform.cpu(),
+                                       camc.full_proj_transform.cpu(), W, H, math.tan(camc.FoVx * 0.5), math.tan(camc.FoVy * 0.5),
+                                       dtype=torch.float64)
+    img2 = col.clamp(0, 1)
+    l2r, _ = l2_loss_gaussian(img2, gt.cpu().double())
+    lossr = l2r + limb_3d_consistency_loss(gm2.get_xyz.double(), dataset) * 1e-5
+    gref = torch.autograd.grad(lossr, [gm2._xyz, gm2._scaling, gm2._rotation, gm2._opacity])
+    assert np.array_equal(radii.cpu().numpy(), rad2.numpy())
+    util.assert_close("image", image.detach().cpu(), img2.detach(), rtol=1e-4, atol_scale=1e-5)
+    for name, a, b in zip(("xyz", "scaling", "rotation", "opacity"), grads, gref):
+        util.assert_close(name, a.detach().cpu(), b, rtol=2e-3, atol_scale=2e-4)

@@ -40,3 +40,21 @@ if __name__ == "__main__":
       for nt in (0, 16, 0, 16):
           f, b, tot = run(views, params, dL, nt)
           print(f"{dataset} V={V} plain_stores={nt>0}: fwd {f:7.1f} us ({nbytes/f/1e3:6.0f} GB/s)  bwd {b:6.1f} us  step wall {tot:7.1f} us", flush=True)
+
+  # host-side enqueue cost (no sync inside): is the step CPU-bound?
+  import time
+  scene, views, params, dL = setup("h36m", 4)
+  for _ in range(20):
+      c, i, r, st = R.forward_views(views, *params); R.backward_views(st, *params, dL)
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(200):
+      c, i, r, st = R.forward_views(views, *params)
+  t1 = time.perf_counter()
+  torch.cuda.synchronize()
+  t2 = time.perf_counter()
+  for _ in range(200):
+      R.backward_views(st, *params, dL)
+  t3 = time.perf_counter()
+  torch.cuda.synchronize()
+  print(f"host enqueue: forward_views {1e6*(t1-t0)/200:.1f} us/call, backward_views {1e6*(t3-t2)/200:.1f} us/call")
