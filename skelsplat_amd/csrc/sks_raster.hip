@@ -98,21 +98,33 @@ struct Geom {  // per-(view, Gaussian) records kept for backward ("geomBuffer")
     float4* co;    // conic.x, conic.y, conic.z, opacity * h_convolution_scaling   (forward.cu:269)
     float4* xyd;   // pixel centre x, y, view depth, 1/depth
     uint4* rect;   // tile rect xmin, ymin, xmax, ymax (all 0 when culled)
+    uint32_t* cover;  // per (view, tile band): word 0 = "some rect crosses this band", then one bit per tile column;
+                      // nullptr when not produced (P > SKS_SMALL_P or the image has too many tiles)
 };
 
 __host__ __device__ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-inline Geom geom_from(void* base, int V, int P)
+constexpr int COVER_MAX_WORDS = 4096;  // LDS bitmap of k_geom_fwd (16 KB)
+__host__ __device__ inline int cover_cw(int W) { return 1 + (((W + TILE - 1) / TILE) + 31) / 32; }
+inline bool cover_enabled(int P, int W, int H)
+{
+    return P <= SKS_SMALL_P && ((H + TILE - 1) / TILE) * cover_cw(W) <= COVER_MAX_WORDS;
+}
+inline Geom geom_from(void* base, int V, int P, int W, int H)
 {
     char* p = (char*)base;
     Geom g;
     size_t n = (size_t)V * P;
     g.co = (float4*)p; p += align256(n * sizeof(float4));
     g.xyd = (float4*)p; p += align256(n * sizeof(float4));
-    g.rect = (uint4*)p;
+    g.rect = (uint4*)p; p += align256(n * sizeof(uint4));
+    g.cover = cover_enabled(P, W, H) ? (uint32_t*)p : nullptr;
     return g;
 }
-inline size_t geom_bytes(int V, int P) { return 3 * align256((size_t)V * P * 16); }
+inline size_t geom_bytes(int V, int P, int W, int H)
+{
+    return 3 * align256((size_t)V * P * 16) + align256((size_t)V * ((H + TILE - 1) / TILE) * cover_cw(W) * 4);
+}
 
 struct Bin {  // binned path scratch ("binningBuffer" + ImageState::ranges)
     uint32_t* count;   // V*NT
@@ -147,10 +159,11 @@ __global__ __launch_bounds__(256) void k_geom_fwd(int P, int W, int H, ViewTan v
                                                    const float* __restrict__ rots, const float* __restrict__ cov3Dp,
                                                    float smod, unsigned flags, Geom g, int* __restrict__ radii)
 {
+    __shared__ uint32_t s_cov[COVER_MAX_WORDS];
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int v = blockIdx.y;
-    if (idx >= P) return;
-    const size_t o = (size_t)v * P + idx;
+    const bool live = idx < P;
+    const size_t o = (size_t)v * P + (live ? idx : 0);
     const float* V = vms + 16 * v;
     const float* PM = pms + 16 * v;
     const float tan_fovx = vt.x[v], tan_fovy = vt.y[v];
@@ -162,10 +175,11 @@ __global__ __launch_bounds__(256) void k_geom_fwd(int P, int W, int H, ViewTan v
     uint4 rect = make_uint4(0, 0, 0, 0);
     float4 co = make_float4(0, 0, 0, 0), xyd = make_float4(0, 0, 1.0f, 1.0f);
 
-    const float p_orig[3] = { means[3 * idx], means[3 * idx + 1], means[3 * idx + 2] };
+    const int li = live ? idx : 0;
+    const float p_orig[3] = { means[3 * li], means[3 * li + 1], means[3 * li + 2] };
     float p_view[3];
     transformPoint4x3(p_orig, V, p_view);
-    if (p_view[2] > 0.2f) {
+    if (live && p_view[2] > 0.2f) {
         float p_hom[4];
         transformPoint4x4(p_orig, PM, p_hom);
         const float p_w = 1.0f / (p_hom[3] + 0.0000001f);
@@ -173,10 +187,10 @@ __global__ __launch_bounds__(256) void k_geom_fwd(int P, int W, int H, ViewTan v
         float cov3D[6];
         if (cov3Dp) {
 #pragma unroll
-            for (int i = 0; i < 6; i++) cov3D[i] = cov3Dp[6 * idx + i];
+            for (int i = 0; i < 6; i++) cov3D[i] = cov3Dp[6 * li + i];
         } else {
-            const float s[3] = { scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2] };
-            const float q[4] = { rots[4 * idx], rots[4 * idx + 1], rots[4 * idx + 2], rots[4 * idx + 3] };
+            const float s[3] = { scales[3 * li], scales[3 * li + 1], scales[3 * li + 2] };
+            const float q[4] = { rots[4 * li], rots[4 * li + 1], rots[4 * li + 2], rots[4 * li + 3] };
             computeCov3D(s, smod, q, cov3D);
         }
         Cov2D c;
@@ -203,15 +217,30 @@ __global__ __launch_bounds__(256) void k_geom_fwd(int P, int W, int H, ViewTan v
             if ((xmax - xmin) * (ymax - ymin) != 0) {
                 radius_out = (int)my_radius;
                 rect = make_uint4(xmin, ymin, xmax, ymax);
-                co = make_float4(conic[0], conic[1], conic[2], opac[idx] * h_convolution_scaling);
+                co = make_float4(conic[0], conic[1], conic[2], opac[li] * h_convolution_scaling);
                 xyd = make_float4(px, py, p_view[2], 1 / p_view[2]);
             }
         }
     }
-    radii[o] = radius_out;
-    g.co[o] = co;
-    g.xyd[o] = xyd;
-    g.rect[o] = rect;
+    if (live) {
+        radii[o] = radius_out;
+        g.co[o] = co;
+        g.xyd[o] = xyd;
+        g.rect[o] = rect;
+    }
+    if (g.cover) {  // single block per view (P <= 256): bitmap of covered tiles for the forward's fill blocks
+        const int cw = cover_cw(W), nw = gy * cw;
+        for (int i = threadIdx.x; i < nw; i += 256) s_cov[i] = 0u;
+        __syncthreads();
+        if (live) {
+            for (unsigned y = rect.y; y < rect.w; y++) {
+                atomicOr(&s_cov[y * cw], 1u);
+                for (unsigned x = rect.x; x < rect.z; x++) atomicOr(&s_cov[y * cw + 1 + (x >> 5)], 1u << (x & 31));
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < nw; i += 256) g.cover[(size_t)v * nw + i] = s_cov[i];
+    }
 }
 
 __global__ void k_mark_visible(int P, const float* __restrict__ means, const float* __restrict__ V,
@@ -298,6 +327,8 @@ struct FwdArgs {
 // PPT = 4 needs W % 4 == 0; PPT = 1 handles any W with 4-byte stores.
 // ------------------------------------------------------------------------------------------------------------
 constexpr int T_SLOTS = 16;     // composite blocks per (view, Gaussian)
+constexpr int COMP_STRIDE = 8;  // every 8th block id is a composite block until they run out
+constexpr int FILL_SPLIT = 4;   // fill blocks per (plane, band): ~16 KB each at W = 1000 (finer blocks balance better)
 constexpr int MAXCOL = 4096;    // tile columns (W <= 65536)
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -336,17 +367,26 @@ template <int CG, int PPT, bool NT>
 __global__ __launch_bounds__(256) void k_render_fwd_sparse(FwdArgs a, int ncomp, int gy)
 {
     extern __shared__ __attribute__((aligned(16))) char s_dyn[];
-    __shared__ unsigned char s_cover[MAXCOL];
+    __shared__ __attribute__((aligned(16))) unsigned char s_cover[MAXCOL];  // fill role: cover words of the band
     __shared__ int s_n, s_min;
     const int tid = threadIdx.x;
     const int P = a.P, C = a.C, W = a.W, H = a.H;
     const size_t HW = (size_t)H * W;
 
-    if ((int)blockIdx.x < ncomp) {
+    // composite blocks are interleaved with the fill blocks (one every COMP_STRIDE block ids) so that their latency
+    // (list building, barriers) overlaps the streaming stores instead of crowding the first dispatch wave
+    const int bid = blockIdx.x;
+    const int total = gridDim.x;
+    const int kint = min(ncomp, (total + COMP_STRIDE - 1) / COMP_STRIDE);  // composite blocks that get an interleaved id
+    const bool slot_id = (bid % COMP_STRIDE == 0) && (bid / COMP_STRIDE < kint);
+    const int rest = bid - min(bid / COMP_STRIDE + 1, kint);                // index among the non-interleaved ids
+    const bool comp_role = slot_id || rest < ncomp - kint;                  // leftovers (tiny images) go first
+    if (comp_role) {
         // ---------------- composite role ----------------
-        const int slot = blockIdx.x % T_SLOTS;
-        const int g = (blockIdx.x / T_SLOTS) % P;
-        const int v = blockIdx.x / (T_SLOTS * P);
+        const int cb = slot_id ? bid / COMP_STRIDE : kint + rest;
+        const int slot = cb % T_SLOTS;
+        const int g = (cb / T_SLOTS) % P;
+        const int v = cb / (T_SLOTS * P);
         const size_t go = (size_t)v * P;
         const float4* gco = a.g.co + go;
         const float4* gxyd = a.g.xyd + go;
@@ -428,58 +468,72 @@ __global__ __launch_bounds__(256) void k_render_fwd_sparse(FwdArgs a, int ncomp,
         return;
     }
     // ---------------- fill role ----------------
-    const int f = blockIdx.x - ncomp;
-    const int plane = f % (C + 1);
-    const int band = (f / (C + 1)) % gy;
-    const int v = f / ((C + 1) * gy);
-    const uint4* grect = a.g.rect + (size_t)v * P;
+    const int f = rest - (ncomp - kint);
+    // block order = memory order (chunk, band, plane, view): concurrently running blocks write one contiguous window
+    const int q = f % FILL_SPLIT;
+    const int band = (f / FILL_SPLIT) % gy;
+    const int plane = (f / (FILL_SPLIT * gy)) % (C + 1);
+    const int v = f / (FILL_SPLIT * gy * (C + 1));
     const bool is_inv = plane == C;
-    const int gx = (W + TILE - 1) / TILE;
-    // every wavefront decides on its own (no LDS, no barrier) whether any Gaussian rect crosses this band; all
-    // wavefronts read the same rects, so the answer is uniform across the workgroup
+    const int cw = cover_cw(W);
+    uint32_t* s_cw = reinterpret_cast<uint32_t*>(s_cover);  // cw words: [0] any, then one bit per tile column
     bool any = false;
-    for (int i0 = 0; i0 < P; i0 += 64) {
-        const int idx = i0 + (tid & 63);
-        bool hit = false;
-        if (idx < P) {
-            const uint4 r = grect[idx];
-            hit = (int)r.y <= band && band < (int)r.w;
+    if (a.g.cover) {  // precomputed by k_geom_fwd: one uniform load decides whether this block is a pure fill
+        const uint32_t* cwp = a.g.cover + ((size_t)v * gy + band) * cw;
+        any = cwp[0] != 0u;
+        if (any) {
+            if (tid < cw) s_cw[tid] = cwp[tid];
+            __syncthreads();
         }
-        any = any || __any(hit);
-    }
-    if (any) {
-        for (int t = tid; t < gx; t += 256) s_cover[t] = 0;
-        __syncthreads();
-        if (tid < P) {
-            const uint4 r = grect[tid];
-            if ((int)r.y <= band && band < (int)r.w)
-                for (unsigned t = r.x; t < r.z; t++) s_cover[t] = 1;
+    } else {  // not precomputed: every wavefront tests the rects itself (uniform result), then builds the bits in LDS
+        const uint4* grect = a.g.rect + (size_t)v * P;
+        for (int i0 = 0; i0 < P; i0 += 64) {
+            const int idx = i0 + (tid & 63);
+            bool hit = false;
+            if (idx < P) {
+                const uint4 r = grect[idx];
+                hit = (int)r.y <= band && band < (int)r.w;
+            }
+            any = any || __any(hit);
         }
-        __syncthreads();
+        if (any) {
+            for (int t = tid; t < cw; t += 256) s_cw[t] = 0u;
+            __syncthreads();
+            if (tid < P) {
+                const uint4 r = grect[tid];
+                if ((int)r.y <= band && band < (int)r.w)
+                    for (unsigned t = r.x; t < r.z; t++) atomicOr(&s_cw[1 + (t >> 5)], 1u << (t & 31));
+            }
+            __syncthreads();
+        }
     }
     const int rows = min(TILE, H - band * TILE);
     const int Nb = rows * W;  // this band of this plane: Nb contiguous floats
+    constexpr int PASS = 256 * PPT;
+    const int Nq = ((Nb + FILL_SPLIT * PASS - 1) / (FILL_SPLIT * PASS)) * PASS;  // floats per block, whole passes
+    const int beg = q * Nq, end = min(Nb, beg + Nq);
     const size_t band0 = (size_t)band * TILE * W;
     float* out = (is_inv ? a.out_invdepth + (size_t)v * HW : a.out_color + ((size_t)v * C + plane) * HW) + band0;
     float* outT = (is_inv && a.final_T) ? a.final_T + (size_t)v * HW + band0 : nullptr;
     uint32_t* outN = (is_inv && a.n_contrib) ? a.n_contrib + (size_t)v * HW + band0 : nullptr;
     if (!any) {
 #pragma unroll 4
-        for (int base = tid * PPT; base < Nb; base += 256 * PPT) {
+        for (int base = beg + tid * PPT; base < end; base += PASS) {
             if (PPT == 4) store4<NT>(out + base, 0.0f, 0.0f, 0.0f, 0.0f);
             else out[base] = 0.0f;
         }
     } else {
-        for (int base = tid * PPT; base < Nb; base += 256 * PPT) {
-            const int x0 = base % W;  // PPT == 4: W % 4 == 0, the 4 pixels share one tile column
-            if (s_cover[x0 >> 4]) continue;  // a composite block writes this tile
+        for (int base = beg + tid * PPT; base < end; base += PASS) {
+            const int tx = (base % W) >> 4;  // PPT == 4: W % 4 == 0, the 4 pixels share one tile column
+            if ((s_cw[1 + (tx >> 5)] >> (tx & 31)) & 1u) continue;  // a composite block writes this tile
             if (PPT == 4) store4<NT>(out + base, 0.0f, 0.0f, 0.0f, 0.0f);
             else out[base] = 0.0f;
         }
     }
     if (outT || outN) {  // debug planes of the reference's ImageState: T = 1, no contributor outside covered tiles
-        for (int base = tid; base < Nb; base += 256) {
-            if (any && s_cover[(base % W) >> 4]) continue;
+        for (int base = beg + tid; base < end; base += 256) {
+            const int tx = (base % W) >> 4;
+            if (any && ((s_cw[1 + (tx >> 5)] >> (tx & 31)) & 1u)) continue;
             if (outT) outT[base] = 1.0f;
             if (outN) outN[base] = 0u;
         }
@@ -1318,7 +1372,7 @@ template <int CG>
 void launch_fwd_small(const FwdArgs& a, int V, int gy, hipStream_t st)
 {
     const int ncomp = T_SLOTS * a.P * V;
-    const int nfill = (a.C + 1) * gy * V;
+    const int nfill = FILL_SPLIT * (a.C + 1) * gy * V;
     const int cap = (a.P + 15) & ~15;
     const size_t lds = DynList<CG>::bytes(cap, CG);
     dim3 grid(ncomp + nfill);
@@ -1355,7 +1409,7 @@ int sks_scratch_bytes(int V, int P, int C, int W, int H, size_t bin_capacity, si
 {
     if (int rc = check_common(V, P, C, W, H)) return rc;
     const int NT = ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
-    if (geom) *geom = geom_bytes(V, P > 0 ? P : 1);
+    if (geom) *geom = geom_bytes(V, P > 0 ? P : 1, W, H);
     if (binning) *binning = bin_bytes(V, NT, bin_capacity);
     if (accum) *accum = (size_t)V * (P > 0 ? P : 1) * BWD_SPLITS * (NACC + C) * sizeof(float);
     return 0;
@@ -1383,7 +1437,7 @@ int sks_forward(int V, int P, int C, int W, int H, const float* viewmatrix, cons
     if (!cov3D_precomp && (!scales || !rotations)) return fail(-2, "need scales+rotations or cov3D_precomp");
     ViewTan vt;
     for (int v = 0; v < V; v++) { vt.x[v] = tanfovx[v]; vt.y[v] = tanfovy[v]; }
-    Geom g = geom_from(geom, V, P);
+    Geom g = geom_from(geom, V, P, W, H);
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE, NT = gx * gy;
 
     hipLaunchKernelGGL(k_geom_fwd, dim3((P + 255) / 256, V), dim3(256), 0, st, P, W, H, vt, viewmatrix, projmatrix,
@@ -1448,7 +1502,7 @@ int sks_backward(int V, int P, int C, int W, int H, const float* viewmatrix, con
     if (!cov3D_precomp && (!scales || !rotations)) return fail(-2, "need scales+rotations or cov3D_precomp");
     ViewTan vt;
     for (int v = 0; v < V; v++) { vt.x[v] = tanfovx[v]; vt.y[v] = tanfovy[v]; }
-    Geom g = geom_from(const_cast<void*>(geom), V, P);
+    Geom g = geom_from(const_cast<void*>(geom), V, P, W, H);
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE, NT = gx * gy;
     BwdArgs a{ P, C, W, H, flags, g, features, bg, dL_dout_color, dL_dout_invdepth, (float*)accum };
     const int cg = pick_cg(C);
