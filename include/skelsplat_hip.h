@@ -44,6 +44,8 @@ extern "C" {
 #define SKS_NO_NT_STORES 16u  /* tuning: plain instead of non-temporal stores for the dense forward planes
                                  (non-temporal is the default: the planes are written once and read by another kernel) */
 
+#define SKS_BWD_LDS_LIST (1u << 20) /* tests: use the LDS-list backward even when P <= 64 (default: wave-resident) */
+
 const char* sks_last_error(void);
 int sks_version(void);
 

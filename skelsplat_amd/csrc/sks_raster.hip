@@ -707,20 +707,48 @@ __device__ __forceinline__ void bwd_load_pixel(BwdPix<CG>& s, const BwdArgs& a, 
 // Sums stay in registers, are reduced once per workgroup and stored to the (v, g, s) partial slot: no atomics,
 // no zero-initialised scratch, bitwise reproducible gradients.
 // ------------------------------------------------------------------------------------------------------------
+// dynamic-LDS working set of the gather kernel, capacity `cap` = P rounded up to 16
 template <int CG>
-struct ListG : List<CG> {
-    int yr[LCAP];  // ymin | ymax << 16 (tile units)
+struct GatherLds {
+    // raw records of ALL Gaussians of the view, indexed by Gaussian id (one global round trip fills them)
+    float4* r_co;
+    float4* r_xyd;
+    uint4* r_rect;
+    float* r_feat;  // cap * C
+    unsigned long long* key;  // cap
+    // the local list, ordered by (depth bits, index)
+    float2* xy;
+    float4* co;
+    float* invd;
+    int* xr;
+    int* yr;
+    int* id;
+    float* feat;  // cap * CG, compacted channels
+    __device__ GatherLds(char* p, int cap, int C)
+    {
+        r_co = (float4*)p; p += (size_t)cap * 16;
+        r_xyd = (float4*)p; p += (size_t)cap * 16;
+        r_rect = (uint4*)p; p += (size_t)cap * 16;
+        co = (float4*)p; p += (size_t)cap * 16;
+        key = (unsigned long long*)p; p += (size_t)cap * 8;
+        xy = (float2*)p; p += (size_t)cap * 8;
+        invd = (float*)p; p += (size_t)cap * 4;
+        xr = (int*)p; p += (size_t)cap * 4;
+        yr = (int*)p; p += (size_t)cap * 4;
+        id = (int*)p; p += (size_t)cap * 4;
+        feat = (float*)p; p += (size_t)cap * CG * 4;
+        r_feat = (float*)p;
+    }
+    static size_t bytes(int cap, int cg, int C) { return (size_t)cap * (16 * 4 + 8 * 2 + 4 * 4 + 4 * (size_t)cg + 4 * (size_t)C); }
 };
 
 template <int CG, bool DFEAT>
 __global__ __launch_bounds__(256) void k_render_bwd_gather(BwdArgs a)
 {
     constexpr int NV = NACC + (DFEAT ? CG : 0);
-    __shared__ ListG<CG> L;
-    __shared__ unsigned long long s_key[LCAP];
+    extern __shared__ __attribute__((aligned(16))) char s_dyn[];
     __shared__ float s_red[4][NV];
     __shared__ int s_chan[CG], s_act[CG];
-    __shared__ int s_n;
     const int sp = blockIdx.x, g = blockIdx.y, v = blockIdx.z, tid = threadIdx.x;
     const int P = a.P, C = a.C, W = a.W, H = a.H;
     const int NVS = NACC + C;
@@ -740,31 +768,40 @@ __global__ __launch_bounds__(256) void k_render_bwd_gather(BwdArgs a)
         if (tid < NVS) out[tid * BWD_SPLITS] = 0.0f;
         return;
     }
-    // local list: Gaussians whose tile rect intersects g's, ordered by (depth bits, index)
-    if (tid == 0) s_n = 0;
-    __syncthreads();
+    // one global round trip: every Gaussian's record + features into LDS
+    const int cap = (P + 15) & ~15;
+    GatherLds<CG> L(s_dyn, cap, C);
     if (tid < P) {
-        const uint4 r = grect[tid];
-        if (r.x < rg.z && r.z > rg.x && r.y < rg.w && r.w > rg.y) {
-            const int slot = atomicAdd(&s_n, 1);
-            s_key[slot] = ((unsigned long long)__float_as_uint(gxyd[tid].z) << 32) | (unsigned)tid;
-        }
+        L.r_co[tid] = gco[tid];
+        L.r_xyd[tid] = gxyd[tid];
+        L.r_rect[tid] = grect[tid];
+    }
+    for (int i = tid; i < P * C; i += 256) L.r_feat[i] = a.features[i];
+    __syncthreads();
+    // local list: Gaussians whose tile rect intersects g's, ordered by (depth bits, index)
+    unsigned long long mykey = ~0ull;
+    if (tid < P) {
+        const uint4 r = L.r_rect[tid];
+        if (r.x < rg.z && r.z > rg.x && r.y < rg.w && r.w > rg.y)
+            mykey = ((unsigned long long)__float_as_uint(L.r_xyd[tid].z) << 32) | (unsigned)tid;
+        L.key[tid] = mykey;
     }
     __syncthreads();
-    const int n = s_n;
-    if (tid < n) {
-        const unsigned long long key = s_key[tid];
-        int rank = 0;
-        for (int j = 0; j < n; j++) rank += (s_key[j] < key) ? 1 : 0;
-        const int id = (int)(unsigned)key;
-        const float4 xyd = gxyd[id];
-        const uint4 r = grect[id];
+    int n = 0, rank = 0;
+    for (int j = 0; j < P; j++) {
+        const unsigned long long kj = L.key[j];
+        n += kj != ~0ull ? 1 : 0;
+        rank += kj < mykey ? 1 : 0;
+    }
+    if (mykey != ~0ull) {
+        const float4 xyd = L.r_xyd[tid];
+        const uint4 r = L.r_rect[tid];
         L.xy[rank] = make_float2(xyd.x, xyd.y);
-        L.co[rank] = gco[id];
+        L.co[rank] = L.r_co[tid];
         L.invd[rank] = xyd.w;
         L.xr[rank] = (int)(r.x | (r.z << 16));
         L.yr[rank] = (int)(r.y | (r.w << 16));
-        L.id[rank] = id;
+        L.id[rank] = tid;
     }
     __syncthreads();
     // channel compaction: a channel whose feature is zero for every listed Gaussian multiplies dL/dpixel by exact
@@ -774,7 +811,7 @@ __global__ __launch_bounds__(256) void k_render_bwd_gather(BwdArgs a)
         bool act = false;
         if (tid < C) {
             act = DFEAT || a.bg != nullptr;
-            for (int k = 0; k < n && !act; k++) act = a.features[L.id[k] * C + tid] != 0.0f;
+            for (int k = 0; k < n && !act; k++) act = L.r_feat[L.id[k] * C + tid] != 0.0f;
         }
         s_act[tid] = act ? 1 : 0;
     }
@@ -790,11 +827,15 @@ __global__ __launch_bounds__(256) void k_render_bwd_gather(BwdArgs a)
     if (tid < n) {
         const int id = L.id[tid];
 #pragma unroll
-        for (int j = 0; j < CG; j++) L.feat[tid * CG + j] = j < nc ? a.features[id * C + s_chan[j]] : 0.0f;
+        for (int j = 0; j < CG; j++) L.feat[tid * CG + j] = j < nc ? L.r_feat[id * C + s_chan[j]] : 0.0f;
     }
     __syncthreads();
     int kg = 0;
     for (int k = 0; k < n; k++) kg = L.id[k] == g ? k : kg;
+    if (a.flags & (1u << 18)) {  // EXPERIMENT: prologue only
+        if (tid < NVS) out[tid * BWD_SPLITS] = (float)(n + nc + kg) * 0.0f;
+        return;
+    }
 
     const bool do_clamp = a.flags & SKS_CLAMP01;
     const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);  // backward.cu:527-528
@@ -834,9 +875,34 @@ __global__ __launch_bounds__(256) void k_render_bwd_gather(BwdArgs a)
             klast = k;
         }
         if (klast < kg) continue;  // g is behind the last contributor (or nothing contributes) at this pixel
+        if (a.flags & (1u << 19)) { sum[0] += T; continue; }  // EXPERIMENT: prepass only
+        // upstream gradient of this pixel: only now, only the active channels (most rect pixels never get here)
         const size_t pix = (size_t)y * W + x;
+        float dLraw[CG];
+        {
+            const float* dLc = a.dL_color + (size_t)v * C * HW + pix;
+#pragma unroll
+            for (int j = 0; j < CG; j++) dLraw[j] = j < nc ? dLc[(size_t)s_chan[j] * HW] : 0.0f;
+        }
+        const float dLi_raw = a.dL_invdepth ? a.dL_invdepth[(size_t)v * HW + pix] : 0.0f;
         BwdPix<CG> s;
-        bwd_load_pixel<CG>(s, a, v, pix, HW, col, do_clamp, T, s_chan, nc);
+        s.T = T;
+        s.T_final = T;
+        s.last_alpha = 0;
+        s.accum_inv = 0;
+        s.last_inv = 0;
+        s.bgdot = 0;
+        s.dLi = dLi_raw;
+#pragma unroll
+        for (int j = 0; j < CG; j++) {
+            float d = dLraw[j];
+            // torch.clamp backward passes the gradient where min <= x <= max
+            if (do_clamp && !(col[j] >= 0.0f && col[j] <= 1.0f)) d = 0.0f;
+            if (a.bg && j < nc) s.bgdot += a.bg[s_chan[j]] * d;
+            s.dL[j] = d;
+            s.accum_rec[j] = 0;
+            s.last_color[j] = 0;
+        }
         // back to front down to g (backward.cu:552-636); only g's own terms are kept
         for (int k = klast; k >= kg; k--) {
             const int xr = L.xr[k], yr = L.yr[k];
@@ -886,6 +952,205 @@ __global__ __launch_bounds__(256) void k_render_bwd_gather(BwdArgs a)
     }
     // workgroup reduction in a fixed order
     const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+        const float r = wave_sum(sum[j]);
+        if (lane == 0) s_red[wv][j] = r;
+    }
+    __syncthreads();
+    if (tid < NVS)
+        out[tid * BWD_SPLITS] = tid < NV ? ((s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid])) : 0.0f;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// small path backward for P <= 64, wave-resident: same gather-by-Gaussian scheme as k_render_bwd_gather, but the
+// whole working set lives in registers.  Lane i of every wavefront holds Gaussian i's record; the local list
+// (Gaussians whose rect meets g's, ordered by (depth bits, index)) is a ballot mask + a per-lane rank, and the entry
+// being composited is broadcast with v_readlane (wave-uniform values in SGPRs): no LDS and no barrier until the final
+// cross-wave reduction, which removes the latency chain that dominates a 17-Gaussian backward.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float rl(float x, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane)); }
+__device__ __forceinline__ unsigned rlu(unsigned x, int lane) { return (unsigned)__builtin_amdgcn_readlane((int)x, lane); }
+
+template <int CG, bool DFEAT>
+__global__ __launch_bounds__(256) void k_render_bwd_wave(BwdArgs a)
+{
+    constexpr int NV = NACC + (DFEAT ? CG : 0);
+    __shared__ float s_red[4][NV];
+    const int sp = blockIdx.x, g = blockIdx.y, v = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int P = a.P, C = a.C, W = a.W, H = a.H;
+    const int NVS = NACC + C;
+    const size_t HW = (size_t)H * W;
+    const size_t go = (size_t)v * P;
+    float* out = a.accum + ((size_t)v * P + g) * NVS * BWD_SPLITS + sp;
+    // lane i <- Gaussian i (one global round trip, every load independent)
+    const bool has = lane < P;
+    const int li = has ? lane : 0;
+    const float4 m_co = a.g.co[go + li];
+    const float4 m_xyd = a.g.xyd[go + li];
+    uint4 m_rect = a.g.rect[go + li];
+    if (!has) m_rect = make_uint4(0, 0, 0, 0);
+    float m_feat[CG];
+#pragma unroll
+    for (int ch = 0; ch < CG; ch++) m_feat[ch] = (ch < C && has) ? a.features[li * C + ch] : 0.0f;
+
+    const unsigned gx0 = rlu(m_rect.x, g), gy0 = rlu(m_rect.y, g), gx1 = rlu(m_rect.z, g), gy1 = rlu(m_rect.w, g);
+    const int x0 = (int)gx0 * TILE, y0 = (int)gy0 * TILE;
+    const int wpx = min(W, (int)gx1 * TILE) - x0, hpx = min(H, (int)gy1 * TILE) - y0;
+    const int npx = wpx * hpx;  // 0 when culled (rect all zero)
+    const int nchunks = (npx + 255) / 256;
+    if (sp >= nchunks) {  // nothing for this slot (also every slot of an invisible Gaussian)
+        if (tid < NVS) out[tid * BWD_SPLITS] = 0.0f;
+        return;
+    }
+    // local list = lanes whose rect intersects g's; order = rank of (depth bits, index) among them
+    const bool hit = m_rect.x < gx1 && m_rect.z > gx0 && m_rect.y < gy1 && m_rect.w > gy0;
+    const unsigned long long hm = __ballot(hit);
+    const int n = __popcll(hm);
+    const unsigned mydepth = __float_as_uint(m_xyd.z);
+    int rank = 0;
+    for (unsigned long long m = hm; m; m &= m - 1) {
+        const int j = __builtin_ctzll(m);
+        const unsigned dj = rlu(mydepth, j);
+        rank += (dj < mydepth || (dj == mydepth && j < lane)) ? 1 : 0;
+    }
+    const int kg = __builtin_amdgcn_readlane(rank, g);
+    // channels that can matter (see k_render_bwd_gather): a bit mask, uniform across the wavefront
+    unsigned chmask = 0;
+#pragma unroll
+    for (int ch = 0; ch < CG; ch++) {
+        if (ch < C) {
+            const bool on = (DFEAT || a.bg != nullptr) ? true : (__ballot(hit && m_feat[ch] != 0.0f) != 0ull);
+            chmask |= on ? (1u << ch) : 0u;
+        }
+    }
+    const bool do_clamp = a.flags & SKS_CLAMP01;
+    const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);  // backward.cu:527-528
+    float sum[NV];
+#pragma unroll
+    for (int j = 0; j < NV; j++) sum[j] = 0.0f;
+
+    for (int c = sp; c < nchunks; c += BWD_SPLITS) {
+        const int i = c * 256 + tid;
+        const bool in = i < npx;
+        const int ii = in ? i : 0;
+        const int yy = ii / wpx;
+        const int x = x0 + (ii - yy * wpx), y = y0 + yy;
+        const int tx = x >> 4, ty = y >> 4;
+        const float pxf = (float)x, pyf = (float)y;
+        // re-composite front to back (forward.cu:346-386): T_final, last accepted entry, colours if clamping.
+        // The k loop is wave-uniform (entries are broadcast); per-lane state is predicated.
+        float T = 1.0f, col[CG];
+#pragma unroll
+        for (int ch = 0; ch < CG; ch++) col[ch] = 0.0f;
+        int klast = -1;
+        bool alive = in;
+        for (int k = 0; k < n; k++) {
+            const int lk = __builtin_ctzll(__ballot(hit && rank == k));
+            const int ex0 = (int)rlu(m_rect.x, lk), ey0 = (int)rlu(m_rect.y, lk), ex1 = (int)rlu(m_rect.z, lk), ey1 = (int)rlu(m_rect.w, lk);
+            const float ex = rl(m_xyd.x, lk), ey = rl(m_xyd.y, lk);
+            const float cx = rl(m_co.x, lk), cy = rl(m_co.y, lk), cz = rl(m_co.z, lk), cw = rl(m_co.w, lk);
+            if (!__any(alive)) break;
+            const bool cov = alive && !(tx < ex0 || tx >= ex1 || ty < ey0 || ty >= ey1);
+            const float dx = ex - pxf, dy = ey - pyf;
+            const float power = -0.5f * (cx * dx * dx + cz * dy * dy) - cy * dx * dy;
+            const float alpha = fminf(0.99f, cw * expf_fixed(power));
+            const float test_T = T * (1 - alpha);
+            const bool pass = cov && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+            const bool stop = pass && test_T < 0.0001f;
+            const bool acc = pass && !stop;
+            if (do_clamp) {
+#pragma unroll
+                for (int ch = 0; ch < CG; ch++) {
+                    if (chmask & (1u << ch)) {
+                        const float f = rl(m_feat[ch], lk);
+                        if (acc) col[ch] += f * alpha * T;
+                    }
+                }
+            }
+            if (acc) { T = test_T; klast = k; }
+            if (stop) alive = false;
+        }
+        const bool need = in && klast >= kg;  // g is at or in front of the last contributor at this pixel
+        if (!__any(need)) continue;
+        // upstream gradient of this pixel: only the active channels, only the lanes that need it
+        const size_t pix = (size_t)y * W + x;
+        BwdPix<CG> s;
+        s.T = T; s.T_final = T; s.last_alpha = 0; s.accum_inv = 0; s.last_inv = 0; s.bgdot = 0;
+        s.dLi = (need && a.dL_invdepth) ? a.dL_invdepth[(size_t)v * HW + pix] : 0.0f;
+        {
+            const float* dLc = a.dL_color + (size_t)v * C * HW + pix;
+#pragma unroll
+            for (int ch = 0; ch < CG; ch++) {
+                float d = 0.0f;
+                if (chmask & (1u << ch)) {
+                    if (need) d = dLc[(size_t)ch * HW];
+                    // torch.clamp backward passes the gradient where min <= x <= max
+                    if (do_clamp && !(col[ch] >= 0.0f && col[ch] <= 1.0f)) d = 0.0f;
+                    if (a.bg) s.bgdot += a.bg[ch] * d;
+                }
+                s.dL[ch] = d;
+                s.accum_rec[ch] = 0;
+                s.last_color[ch] = 0;
+            }
+        }
+        // back to front down to g (backward.cu:552-636); only g's own terms are kept
+        for (int k = n - 1; k >= kg; k--) {
+            const int lk = __builtin_ctzll(__ballot(hit && rank == k));
+            const int ex0 = (int)rlu(m_rect.x, lk), ey0 = (int)rlu(m_rect.y, lk), ex1 = (int)rlu(m_rect.z, lk), ey1 = (int)rlu(m_rect.w, lk);
+            const float ex = rl(m_xyd.x, lk), ey = rl(m_xyd.y, lk), einvd = rl(m_xyd.w, lk);
+            const float cx = rl(m_co.x, lk), cy = rl(m_co.y, lk), cz = rl(m_co.z, lk), cw = rl(m_co.w, lk);
+            const float dx = ex - pxf, dy = ey - pyf;
+            const float power = -0.5f * (cx * dx * dx + cz * dy * dy) - cy * dx * dy;
+            const float G = expf_fixed(power);
+            const float alpha = fminf(0.99f, cw * G);
+            const bool act = need && k <= klast && !(tx < ex0 || tx >= ex1 || ty < ey0 || ty >= ey1) && !(power > 0.0f) &&
+                             !(alpha < 1.0f / 255.0f);
+            if (!__any(act)) continue;
+            const bool mine = k == kg;
+            float Tn = s.T, dchannel_dcolor = 0.0f, dL_dalpha = 0.0f;
+            if (act) {
+                Tn = s.T / (1.f - alpha);
+                dchannel_dcolor = alpha * Tn;
+            }
+#pragma unroll
+            for (int ch = 0; ch < CG; ch++) {
+                if (chmask & (1u << ch)) {
+                    const float cc = rl(m_feat[ch], lk);
+                    if (act) {
+                        s.accum_rec[ch] = s.last_alpha * s.last_color[ch] + (1.f - s.last_alpha) * s.accum_rec[ch];
+                        s.last_color[ch] = cc;
+                        const float dL_dchannel = s.dL[ch];
+                        dL_dalpha += (cc - s.accum_rec[ch]) * dL_dchannel;
+                        if (DFEAT && mine) sum[NACC + ch] += dchannel_dcolor * dL_dchannel;
+                    }
+                }
+            }
+            if (act) {
+                s.T = Tn;
+                s.accum_inv = s.last_alpha * s.last_inv + (1.f - s.last_alpha) * s.accum_inv;
+                s.last_inv = einvd;
+                dL_dalpha += (einvd - s.accum_inv) * s.dLi;
+                dL_dalpha *= s.T;
+                s.last_alpha = alpha;
+                dL_dalpha += (-s.T_final / (1.f - alpha)) * s.bgdot;
+                if (mine) {
+                    const float dL_dG = cw * dL_dalpha;
+                    const float gdx = G * dx, gdy = G * dy;
+                    const float dG_ddelx = -gdx * cx - gdy * cy;
+                    const float dG_ddely = -gdy * cz - gdx * cy;
+                    sum[0] += dL_dG * dG_ddelx * ddelx_dx;
+                    sum[1] += dL_dG * dG_ddely * ddely_dy;
+                    sum[2] += -0.5f * gdx * dx * dL_dG;
+                    sum[3] += -0.5f * gdx * dy * dL_dG;
+                    sum[4] += -0.5f * gdy * dy * dL_dG;
+                    sum[5] += G * dL_dalpha;
+                    sum[6] += dchannel_dcolor * s.dLi;
+                }
+            }
+        }
+    }
+    // workgroup reduction in a fixed order
 #pragma unroll
     for (int j = 0; j < NV; j++) {
         const float r = wave_sum(sum[j]);
@@ -1390,8 +1655,20 @@ void launch_bwd_small(const BwdArgs& a, int V, int gy, bool dfeat, hipStream_t s
 {
     (void)gy;
     dim3 grid(BWD_SPLITS, a.P, V);
-    if (dfeat) hipLaunchKernelGGL((k_render_bwd_gather<CG, true>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((k_render_bwd_gather<CG, false>), grid, dim3(256), 0, st, a);
+    if (a.P <= 64 && !(a.flags & (1u << 20))) {  // wave-resident variant (bit 20: force the LDS variant, tests)
+        if (dfeat) hipLaunchKernelGGL((k_render_bwd_wave<CG, true>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_render_bwd_wave<CG, false>), grid, dim3(256), 0, st, a);
+        return;
+    }
+    const size_t lds = GatherLds<CG>::bytes((a.P + 15) & ~15, CG, a.C);
+    if (lds > 48 * 1024) {  // gfx950 has 160 KB of LDS per CU; raise the per-kernel dynamic limit when P is large
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render_bwd_gather<CG, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render_bwd_gather<CG, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    if (dfeat) hipLaunchKernelGGL((k_render_bwd_gather<CG, true>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((k_render_bwd_gather<CG, false>), grid, dim3(256), lds, st, a);
 }
 
 }  // namespace

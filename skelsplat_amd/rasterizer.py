@@ -153,7 +153,7 @@ def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotati
 
 
 def backward_views(st: ForwardState, means3D, features, opacities, scales, rotations, cov3D_precomp, dL_dcolor,
-                   dL_dinvdepth=None, bg=None, want_dfeatures=False):
+                   dL_dinvdepth=None, bg=None, want_dfeatures=False, tune_flags=0):
     """Raw batched backward: per-view gradients, dict of (V,P,...) tensors."""
     lib = _lib.load()
     means3D = _f32c(means3D, "means3D")
@@ -184,7 +184,7 @@ def backward_views(st: ForwardState, means3D, features, opacities, scales, rotat
         rc = lib.sks_backward(V, P, C, W, H, st.views.viewmatrix.data_ptr(), st.views.projmatrix.data_ptr(),
                               st.views.tanfovx, st.views.tanfovy, _lib.ptr(bgC), _lib.ptr(means3D), _lib.ptr(feat2),
                               _lib.ptr(opacities), _lib.ptr(scales), _lib.ptr(rotations), _lib.ptr(cov3D_precomp),
-                              st.scale_modifier, st.flags, _lib.ptr(st.radii), st.geom.data_ptr(), _lib.ptr(st.binning),
+                              st.scale_modifier, st.flags | int(tune_flags), _lib.ptr(st.radii), st.geom.data_ptr(), _lib.ptr(st.binning),
                               st.bin_capacity, dL_dcolor.data_ptr(), _lib.ptr(dL_dinvdepth), accum.data_ptr(),
                               _lib.ptr(out["means3D"]), _lib.ptr(out["means2D"]), _lib.ptr(out["opacities"]),
                               _lib.ptr(out["scales"]), _lib.ptr(out["rotations"]), _lib.ptr(out["cov3D"]),

@@ -79,9 +79,15 @@ def test_backward_vs_oracle(device, kw, binned, aa):
         util.assert_close("dL_drotations", g["rotations"][v].cpu(), b["dL_drotations"])
         util.assert_close("dL_dcov3D", g["cov3D"][v].cpu(), b["dL_dcov3D"])
         util.assert_close("dL_dfeatures", g["features"][v].cpu(), b["dL_dcolors"])
-    # consume-and-clear: a second backward on the same scratch gives the same answer
+    # a second backward on the same scratch gives the same answer (bitwise on the fused path: no atomics)
     g2 = R.backward_views(st, *args, t(c.dL_color, dev), t(c.dL_inv, dev), bg=bg, want_dfeatures=False)
     util.assert_close("repeat", g2["means3D"].cpu(), g["means3D"].cpu(), rtol=1e-4)
+    if not binned:
+        assert torch.equal(g2["means3D"], g["means3D"]) and torch.equal(g2["scales"], g["scales"])
+        # the LDS-list variant of the gather backward (used for 64 < P <= 256) agrees with the wave-resident one
+        g3 = R.backward_views(st, *args, t(c.dL_color, dev), t(c.dL_inv, dev), bg=bg, want_dfeatures=True, tune_flags=1 << 20)
+        for k in ("means3D", "means2D", "opacities", "scales", "rotations", "features"):
+            util.assert_close("lds-vs-wave " + k, g3[k].cpu(), g[k].cpu(), rtol=1e-4, atol_scale=1e-6)
 
 
 def test_autograd_single_view_api(device):
@@ -202,3 +208,20 @@ def test_render_functions_drop_in_like_train_py(device, dataset, key):
     util.assert_close("image", image.detach().cpu(), img2.detach(), rtol=1e-4, atol_scale=1e-5)
     for name, a, b in zip(("xyz", "scaling", "rotation", "opacity"), grads, gref):
         util.assert_close(name, a.detach().cpu(), b, rtol=2e-3, atol_scale=2e-4)
+
+
+def test_many_gaussians_small_path(device):
+    """P = 255 (15 skeletons x 17): the fused path at its capacity, large dynamic LDS in the gather backward."""
+    c = util.make_case(seed=31, W=192, H=160, scale_log=3.2, n_skeletons=15, pitch=250.0, n_views=1)
+    assert c.P == 255
+    dev = device
+    views = R.ViewBatch.from_cameras([cam.to(dev) for cam in c.cams])
+    args = (t(c.means, dev), t(c.feat, dev), t(c.opac, dev), t(c.scales, dev), t(c.quats, dev), None)
+    color, inv, radii, st = R.forward_views(views, *args)
+    o = util.oracle_forward(c, 0)
+    assert np.array_equal(radii[0].cpu().numpy(), o["radii"]) and np.array_equal(color[0].cpu().numpy(), o["color"])
+    g = R.backward_views(st, *args, t(c.dL_color, dev), t(c.dL_inv, dev), want_dfeatures=True)
+    b = util.oracle_backward(c, 0, o)
+    util.assert_close("dL_dmeans3D", g["means3D"][0].cpu(), b["dL_dmeans3D"])
+    util.assert_close("dL_drotations", g["rotations"][0].cpu(), b["dL_drotations"])
+    util.assert_close("dL_dfeatures", g["features"][0].cpu(), b["dL_dcolors"])

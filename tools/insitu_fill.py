@@ -32,3 +32,12 @@ for name, tune in (("sks fwd normal", 0), ("sks fwd no-cover-lookup", 1 << 16), 
     torch.cuda.synchronize()
     ms, n = _lib.prof_read(0); _lib.prof_enable(False)
     print(f"{name}: avg {ms/n*1e3:.1f} us")
+
+for name, tune in (("bwd normal", 0), ("bwd prologue only", 1 << 18), ("bwd prologue+prepass", 1 << 19)):
+    _lib.prof_enable(True); _lib.prof_read(1)
+    for it in range(40):
+        c, i, r, st2 = R.forward_views(views, *params)
+        R.backward_views(st2, *params, dL, tune_flags=tune)
+    torch.cuda.synchronize()
+    ms, n = _lib.prof_read(1); _lib.prof_enable(False)
+    print(f"{name}: avg {ms/n*1e3:.1f} us")
