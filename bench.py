@@ -148,6 +148,54 @@ def main():
         dt = float(tt.item())
     assert torch.isfinite(out).all()
 
+    # ---- extras (not part of `value`): hipGraph replay of the same step, and the full loop step ----------------
+    extras = {}
+    if world == 1:
+        try:
+            graph = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    step()
+            torch.cuda.current_stream().wait_stream(side)
+            with torch.cuda.graph(graph):
+                gout = step()
+            for _ in range(5):
+                graph.replay()
+            torch.cuda.synchronize()
+            tg = time.perf_counter()
+            for _ in range(args.steps):
+                graph.replay()
+            torch.cuda.synchronize()
+            tg = time.perf_counter() - tg
+            extras["graph_replay_views_per_s"] = V * args.steps / tg
+            extras["graph_replay_ms_per_step"] = 1e3 * tg / args.steps
+        except Exception as e:  # capture is an optimisation, never a requirement
+            extras["graph_replay_error"] = repr(e)[:200]
+        try:
+            from skelsplat_amd.loop import MultiViewLoop
+            from skelsplat_amd.heatmaps import generate_heatmaps
+            gm.training_setup()
+            hm = generate_heatmaps(gm._xyz.detach(), gm.get_scaling.detach(), gm._rotation.detach(),
+                                   torch.tensor(ref_scene.poses_2d, device=dev), scene.cameras)
+            for tag, ug in (("", False), ("_hipgraph", True)):
+                loop = MultiViewLoop(gm, scene.cameras, hm, dataset=wl["dataset"], accumulation_steps=V, use_graph=ug)
+                for _ in range(5):
+                    loop.step_group()
+                torch.cuda.synchronize()
+                tl = time.perf_counter()
+                nl = max(10, args.steps // 2)
+                for _ in range(nl):
+                    loop.step_group()
+                torch.cuda.synchronize()
+                tl = time.perf_counter() - tl
+                # V views rendered + fused masked-L2 + backward + device-side Adam step (train.py:130-222)
+                extras["grad_step_ms" + tag] = 1e3 * tl / nl
+                extras["loop_views_per_s" + tag] = V * nl / tl
+        except Exception as e:
+            extras["loop_error"] = repr(e)[:200]
+
     if rank == 0:
         views_total = V * world * args.steps
         res = {
@@ -175,6 +223,7 @@ def main():
                                "avg_launch_us": avg_s * 1e6, "launches": fwd_n, "algorithmic_bytes_per_launch": alg_bytes}
             if bwd_n:
                 res["bwd_kernel_avg_us"] = bwd_ms * 1e3 / bwd_n
+        res.update(extras)
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(ref_scene, params, n_views=2)
         print(json.dumps(res))

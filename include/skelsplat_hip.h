@@ -127,6 +127,26 @@ int sks_fused_ssim_bwd(int B, int CH, int H, int W, float C1, float C2, const fl
  * points (P,3) -> mean squared distance to the 3 nearest neighbours (P). */
 int sks_knn3_meandist2(int P, const float* points, float* mean_dist2, void* stream);
 
+/* Device-side tail of the multi-view loop (train.py:160-222), so that one accumulation group is a fixed launch
+ * sequence with no host state (capturable into a hipGraph):
+ * sks_loop_pack_grads: sks_backward's per-view gradients wrt the ACTIVATED tensors (V,P,..) -> packed (V,P,11) gradients
+ *   wrt the RAW leaf parameters [xyz 3 | _scaling 3 | _rotation 4 | _opacity 1] through the exp / normalize / sigmoid
+ *   Jacobians (scene/gaussian_model.py:39-47), times 1/N_v when loss_sums (V x {S,N} doubles of sks_masked_l2) is given.
+ * sks_loop_adam_step: one optimiser step of the reference loop: slots[v] = grads[v].xyz + limb-symmetry gradient for the
+ *   views in group_mask (utils/loss_utils.py:226-250, train.py:150-152,175), xyz.grad = mean over the V slots
+ *   (train.py:215-217), scaling/rotation/opacity gradients of `last_view` (quirk Q7), exponential LR schedule evaluated at
+ *   the stepping iteration (utils/general_utils.py:38-71, quirk Q9), torch.optim.Adam update (eps from the caller; the
+ *   reference uses 1e-15, gaussian_model.py:218).  counters (device, 2 ints): [0] iteration, advanced by acc_steps,
+ *   [1] Adam step count.  exp_avg / exp_avg_sq: (P,11) each, zero-initialised by the caller.  P <= SKS_SMALL_P. */
+int sks_loop_pack_grads(int V, int P, const float* dL_dmeans3D, const float* dL_dscales, const float* dL_drotations,
+                        const float* dL_dopacity, const float* raw_scaling, const float* raw_rotation,
+                        const float* raw_opacity, const double* loss_sums, float* packed, void* stream);
+int sks_loop_adam_step(int V, int P, const float* grads, float* slots, unsigned long long group_mask, int last_view,
+                       float* xyz, float* scaling, float* rotation, float* opacity, float* exp_avg, float* exp_avg_sq,
+                       int* counters, int acc_steps, const double* lr_sched /*HOST 5: init, final, delay_mult, delay_steps, max_steps*/,
+                       const double* lrs /*HOST 3: scaling, rotation, opacity*/, const double* adam /*HOST 3: beta1, beta2, eps*/,
+                       float lambda_consistency, const int* limb /*HOST 8 ints or NULL*/, void* stream);
+
 /* Measurement hook used by bench.py (no reference counterpart): while enabled, the dominant kernel of sks_forward
  * (kind 0: forward compositor) and of sks_backward (kind 1: backward compositor) is bracketed by hipEvents recorded
  * on the caller's stream.  sks_prof_read waits for the recorded events, returns the summed kernel time in

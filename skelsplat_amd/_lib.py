@@ -36,6 +36,9 @@ SIGNATURES = {
     "sks_fused_ssim_fwd": (_i, [_i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sks_fused_ssim_bwd": (_i, [_i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sks_knn3_meandist2": (_i, [_i, _vp, _vp, _vp]),
+    "sks_loop_pack_grads": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sks_loop_adam_step": (_i, [_i, _i, _vp, _vp, C.c_ulonglong, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp,
+                                _f, _vp, _vp]),
     "sks_prof_enable": (_i, [_i]),
     "sks_prof_read": (_i, [_i, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
 }

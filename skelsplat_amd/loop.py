@@ -70,7 +70,8 @@ class MultiViewLoop:
     (ops.masked_l2_grad_fused); loop.masked_l2_grad_torch is the same thing in tensor ops."""
 
     def __init__(self, gaussians, cameras, heatmaps, dataset="h36m", accumulation_steps=4, lambda_consistency=1e-5,
-                 bg=None, antialiasing=False, loss_grad=None, group=None, view_grad_fn=None):
+                 bg=None, antialiasing=False, loss_grad=None, group=None, view_grad_fn=None, device_tail=None,
+                 use_graph=False):
         self.gm = gaussians
         self.dataset = dataset
         self.V = len(cameras)
@@ -91,6 +92,7 @@ class MultiViewLoop:
                       if (self.local_ids and view_grad_fn is None) else None)
         self.gt = heatmaps[self.local_ids].contiguous() if self.local_ids else None
         self.bg = bg
+        default_loss = loss_grad is None
         if loss_grad is None and view_grad_fn is None:
             from .ops import masked_l2_grad_fused
             loss_grad = masked_l2_grad_fused
@@ -103,6 +105,26 @@ class MultiViewLoop:
         self.last_losses = None
         # all_gather needs equal shard sizes: pad every rank to ceil(V / world) views
         self.vmax = (self.V + self.world - 1) // self.world
+        # device-side tail (sks_loop_pack_grads + sks_loop_adam_step): default whenever the HIP path is used with the
+        # fused loss; the tensor-op tail + torch.optim.Adam below is the same algorithm and stays for custom losses
+        if device_tail is None:
+            device_tail = view_grad_fn is None and default_loss and dev.type == "cuda" and P <= 256
+        self.device_tail = bool(device_tail)
+        self.use_graph = bool(use_graph) and self.device_tail and self.world == 1
+        self._graph = None
+        if self.device_tail:
+            import ctypes
+            from . import _lib
+            cfg = gaussians.opt_cfg
+            self._sched = (ctypes.c_double * 5)(cfg["lr_init"], cfg["lr_final"], cfg["lr_delay_mult"],
+                                                float(cfg["lr_delay_steps"]), float(cfg["lr_max_steps"]))
+            self._lrs = (ctypes.c_double * 3)(cfg["lr_scaling"], cfg["lr_rotation"], cfg["lr_opacity"])
+            self._adam = (ctypes.c_double * 3)(cfg["betas"][0], cfg["betas"][1], cfg["eps"])
+            limbs = [i for pair in DATASETS[dataset]["limbs"] for i in pair]
+            self._limb = (ctypes.c_int * 8)(*limbs) if self.lambda_consistency != 0.0 else None
+            self.exp_avg = torch.zeros((P, 11), device=dev)
+            self.exp_avg_sq = torch.zeros((P, 11), device=dev)
+            self.counters = torch.zeros(2, dtype=torch.int32, device=dev)
 
     # -- one accumulation group --------------------------------------------------------------------------
     def _local_view_grads(self):
@@ -130,6 +152,51 @@ class MultiViewLoop:
         (gx,) = torch.autograd.grad(loss, xyz)
         return gx, loss.detach()
 
+    # -- device-side tail ----------------------------------------------------------------------------------
+    def _device_group(self, group_mask, last_view, n_iters):
+        """forward -> fused masked-L2 -> backward -> pack -> [all_gather] -> Adam, all enqueued, no host sync."""
+        from . import _lib
+        from .ops import masked_l2
+        lib = _lib.load()
+        gm, P, dev = self.gm, self.P, self.device
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.no_grad():
+            if self.local_ids:
+                means = gm._xyz.detach()
+                feats = gm.get_features.reshape(P, -1)
+                opac, scales, quats = gm.get_opacity.detach(), gm.get_scaling.detach(), gm.get_rotation.detach()
+                color, inv, radii, st = R.forward_views(self.views, means, feats, opac, scales, quats, None,
+                                                        antialiasing=self.antialiasing, clamp01=True)
+                dL, S, N = masked_l2(color, self.gt)
+                g = R.backward_views(st, means, feats, opac, scales, quats, None, dL, None, bg=self.bg)
+                Vl = len(self.local_ids)
+                packed = torch.empty((self.vmax if self.world > 1 else Vl, P, 11), device=dev)
+                if self.world > 1 and Vl < self.vmax:
+                    packed[Vl:].zero_()
+                sums = torch.stack([S, N], dim=1).contiguous()
+                _lib.check(lib.sks_loop_pack_grads(Vl, P, g["means3D"].data_ptr(), g["scales"].data_ptr(),
+                                                   g["rotations"].data_ptr(), g["opacities"].data_ptr(),
+                                                   gm._scaling.data_ptr(), gm._rotation.data_ptr(), gm._opacity.data_ptr(),
+                                                   sums.data_ptr(), packed.data_ptr(), stream), "sks_loop_pack_grads")
+                self.last_losses = (S, N)
+            else:
+                packed = torch.zeros((self.vmax, P, 11), device=dev)
+            if self.world > 1:
+                allg = torch.empty((self.world * self.vmax, P, 11), device=dev)
+                dist.all_gather_into_tensor(allg, packed, group=self.group)
+                full = torch.empty((self.V, P, 11), device=dev)
+                for r in range(self.world):     # rank r, slot k  <->  view r + k * world
+                    ids = [v for v in range(self.V) if v % self.world == r]
+                    if ids:
+                        full[ids] = allg[r * self.vmax:r * self.vmax + len(ids)]
+            else:
+                full = packed
+            _lib.check(lib.sks_loop_adam_step(self.V, P, full.data_ptr(), self.accumulated_grads.data_ptr(), group_mask,
+                                              last_view, gm._xyz.data_ptr(), gm._scaling.data_ptr(), gm._rotation.data_ptr(),
+                                              gm._opacity.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                                              self.counters.data_ptr(), n_iters, self._sched, self._lrs, self._adam,
+                                              float(self.lambda_consistency), self._limb, stream), "sks_loop_adam_step")
+
     def step_group(self):
         """Runs iterations self.iteration+1 .. up to the next optimiser step (train.py:130-222)."""
         gm = self.gm
@@ -138,6 +205,23 @@ class MultiViewLoop:
         while it1 % self.acc_steps != 0:
             it1 += 1
         view_of_iter = [(it - 1) % self.V for it in range(it0, it1 + 1)]   # train.py:136-138
+        if self.device_tail:
+            mask = 0
+            for v in view_of_iter:
+                mask |= 1 << v
+            key = (mask, view_of_iter[-1], it1 - it0 + 1)
+            if self.use_graph:
+                if self._graph is None or self._graph[0] != key:
+                    # warm up on a side stream, then capture one group; replays advance the device counters themselves
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        self._device_group(*key)
+                    self._graph = (key, graph)      # the capture itself does not execute: replay below
+                self._graph[1].replay()
+            else:
+                self._device_group(*key)
+            self.iteration = it1
+            return it1
         if not self.local_ids:
             packed, losses = None, None
         elif self.view_grad_fn is not None:

@@ -281,6 +281,12 @@ class GaussianModel:
             {"params": [self._rotation], "lr": opt.rotation_lr, "name": "rotation"},
         ]
         self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+        # the same numbers for the device-side optimiser step of skelsplat_amd.loop (sks_loop_adam_step)
+        self.opt_cfg = dict(lr_init=opt.position_lr_init * self.spatial_lr_scale,
+                            lr_final=opt.position_lr_final * self.spatial_lr_scale,
+                            lr_delay_mult=opt.position_lr_delay_mult, lr_delay_steps=0,
+                            lr_max_steps=opt.position_lr_max_steps, lr_scaling=opt.scaling_lr,
+                            lr_rotation=opt.rotation_lr, lr_opacity=opt.opacity_lr, betas=(0.9, 0.999), eps=1e-15)
         self.xyz_scheduler_args = get_expon_lr_func(
             lr_init=opt.position_lr_init * self.spatial_lr_scale, lr_final=opt.position_lr_final * self.spatial_lr_scale,
             lr_delay_mult=opt.position_lr_delay_mult, max_steps=opt.position_lr_max_steps)

@@ -134,3 +134,36 @@ def test_fused_loss_equals_tensor_op_loss_in_loop(device):
         loop = MultiViewLoop(gm, sc.cameras, hm, dataset="h36m", loss_grad=lg)
         outs.append(loop.run(20).cpu())
     assert (outs[0] - outs[1]).norm(dim=1).max().item() < 1e-3
+
+
+@pytest.mark.parametrize("use_graph", [False, True], ids=["eager", "hipgraph"])
+def test_device_tail_loop_matches_tensor_op_tail(device, use_graph):
+    """sks_loop_pack_grads + sks_loop_adam_step (device-side activation Jacobians, limb gradient, LR schedule, Adam)
+    reproduce the tensor-op tail + torch.optim.Adam; also as one captured hipGraph per accumulation group."""
+    from skelsplat_amd.loop import MultiViewLoop, masked_l2_grad_torch
+    from skelsplat_amd.heatmaps import generate_heatmaps
+    sc, model = _make_loop_scene(device, seed=7)
+    res = []
+    for mode in ("device", "torch"):
+        gm = model(device)
+        with torch.no_grad():   # finite opacity, tilted quaternions, anisotropic scales: every Jacobian carries signal
+            gm._opacity.fill_(2.0)   # (with isotropic scales the rotation gradient is rounding noise, which Adam's
+            #                           1/sqrt(v) normalisation turns into +-lr steps of arbitrary sign)
+            gm._rotation.add_(0.1 * torch.randn(gm._rotation.shape, generator=torch.Generator().manual_seed(0)).to(device))
+            gm._scaling.add_(0.3 * torch.randn(gm._scaling.shape, generator=torch.Generator().manual_seed(1)).to(device))
+        hm = generate_heatmaps(gm._xyz.detach(), gm.get_scaling.detach(), gm._rotation.detach(),
+                               torch.tensor(sc.poses_2d, device=device), sc.cameras)
+        if mode == "device":
+            loop = MultiViewLoop(gm, sc.cameras, hm, dataset="h36m", use_graph=use_graph)
+            assert loop.device_tail and loop.use_graph == use_graph
+        else:
+            loop = MultiViewLoop(gm, sc.cameras, hm, dataset="h36m", loss_grad=masked_l2_grad_torch)
+            assert not loop.device_tail
+        loop.run(40)
+        res.append([p.detach().cpu().clone() for p in (gm._xyz, gm._scaling, gm._rotation, gm._opacity)])
+    moved = (res[1][0] - torch.tensor(sc.pose_3d_init).float()).norm(dim=1).mean().item()
+    assert moved > 1.0
+    assert (res[0][0] - res[1][0]).norm(dim=1).max().item() < 2e-3 * moved        # xyz within 0.2 % of the distance moved
+    util.assert_close("scaling", res[0][1], res[1][1], rtol=1e-4, atol_scale=1e-4)
+    util.assert_close("rotation", res[0][2], res[1][2], rtol=1e-4, atol_scale=1e-4)
+    util.assert_close("opacity", res[0][3], res[1][3], rtol=1e-5, atol_scale=1e-5)
