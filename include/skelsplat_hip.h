@@ -127,6 +127,30 @@ int sks_fused_ssim_bwd(int B, int CH, int H, int W, float C1, float C2, const fl
  * points (P,3) -> mean squared distance to the 3 nearest neighbours (P). */
 int sks_knn3_meandist2(int P, const float* points, float* mean_dist2, void* stream);
 
+/* Sparse fused training step (no dense image, no dense gradient).  In the loop the render is only ever compared with the
+ * constant pseudo-GT heat-maps (train.py:148-152), and it is exactly zero outside the tiles some Gaussian rect covers,
+ * so render + clamp + masked-L2 + backward can be evaluated on the covered tiles alone:
+ *  sks_gt_tile_stats (once per scene): per (view, tile, channel) sum of gt^2 and count of gt > 0 -> tile_S, tile_N
+ *      (V, Ty*Tx, C) floats, and per-view totals (V x 2 doubles);
+ *  sks_geometry: the geometry stage of sks_forward alone (fills `geom` and `radii`);
+ *  sks_backward_fused_loss: like sks_backward, but takes the heat-maps `gt` (V,C,H,W) instead of dL/d(render):
+ *      re-composites each covered pixel, forms 2 (clamp(r) - gt) on the mask {gt > 0 or r > 0} on the fly, and
+ *      returns per-view {S, N} (loss_v = S/N) in loss_sums; gradients are UNSCALED (multiply by 1/N_v, e.g. with
+ *      sks_loop_pack_grads).  P <= 64. */
+int sks_gt_tile_stats(int V, int C, int W, int H, const float* gt, float* tile_S, float* tile_N, double* totals, void* stream);
+int sks_geometry(int V, int P, int C, int W, int H, const float* viewmatrix, const float* projmatrix,
+                 const float* tanfovx /*HOST V*/, const float* tanfovy /*HOST V*/, const float* means3D,
+                 const float* opacities, const float* scales, const float* rotations, const float* cov3D_precomp,
+                 float scale_modifier, unsigned flags, int* radii, void* geom, void* stream);
+int sks_backward_fused_loss(int V, int P, int C, int W, int H, const float* viewmatrix, const float* projmatrix,
+                            const float* tanfovx /*HOST V*/, const float* tanfovy /*HOST V*/, const float* bg,
+                            const float* means3D, const float* features, const float* opacities, const float* scales,
+                            const float* rotations, const float* cov3D_precomp, float scale_modifier, unsigned flags,
+                            const int* radii, const void* geom, const float* gt, const float* tile_S, const float* tile_N,
+                            const double* gt_totals, void* accum, float* dL_dmeans3D, float* dL_dmeans2D,
+                            float* dL_dopacity, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
+                            double* loss_sums, void* stream);
+
 /* Device-side tail of the multi-view loop (train.py:160-222), so that one accumulation group is a fixed launch
  * sequence with no host state (capturable into a hipGraph):
  * sks_loop_pack_grads: sks_backward's per-view gradients wrt the ACTIVATED tensors (V,P,..) -> packed (V,P,11) gradients

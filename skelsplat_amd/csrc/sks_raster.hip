@@ -632,9 +632,11 @@ struct BwdArgs {
     Geom g;
     const float* features;
     const float* bg;
-    const float* dL_color;
+    const float* dL_color;     // fused-loss mode: the pseudo-GT heat-maps (V,C,H,W) instead of dL/d(render)
     const float* dL_invdepth;
     float* accum;  // (V,P,NACC+C)
+    const float* tile_S;       // fused-loss mode: per (view, tile, channel) sum of gt^2 and count of gt > 0
+    const float* tile_N;
 };
 
 // prepass of one pixel over an LDS batch: same walk as the forward; records the LDS index of the last accepted
@@ -972,10 +974,17 @@ __global__ __launch_bounds__(256) void k_render_bwd_gather(BwdArgs a)
 __device__ __forceinline__ float rl(float x, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane)); }
 __device__ __forceinline__ unsigned rlu(unsigned x, int lane) { return (unsigned)__builtin_amdgcn_readlane((int)x, lane); }
 
-template <int CG, bool DFEAT>
+// LOSS = true fuses the loop's masked-L2 loss (utils/loss_utils.py:86-100 on the clamped render, train.py:150) into
+// this kernel: a.dL_color holds the pseudo-GT heat-maps; dL/d(render) = 2 (r - gt) on the mask {gt > 0 or r > 0} is
+// formed per pixel from the re-composited colours, so neither the rendered image nor a dense gradient ever exists.
+// The loss sums over the WHOLE image are (precomputed per-tile sums of the constant heat-maps) - (those sums for the
+// tiles some rect covers) + (exact sums over the covered tiles), the latter two accumulated here by each tile's owner
+// (lowest-index covering Gaussian) into slots 7 (S) and 8 (N); outside covered tiles the render is exactly zero.
+template <int CG, bool DFEAT, bool LOSS>
 __global__ __launch_bounds__(256) void k_render_bwd_wave(BwdArgs a)
 {
-    constexpr int NV = NACC + (DFEAT ? CG : 0);
+    static_assert(!(DFEAT && LOSS), "the fused-loss variant has no feature gradient");
+    constexpr int NV = LOSS ? NACC + 1 : NACC + (DFEAT ? CG : 0);
     __shared__ float s_red[4][NV];
     const int sp = blockIdx.x, g = blockIdx.y, v = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int P = a.P, C = a.C, W = a.W, H = a.H;
@@ -1044,14 +1053,17 @@ __global__ __launch_bounds__(256) void k_render_bwd_wave(BwdArgs a)
 #pragma unroll
         for (int ch = 0; ch < CG; ch++) col[ch] = 0.0f;
         int klast = -1;
+        int minid = 0x7fffffff;  // lowest Gaussian index whose rect covers this pixel's tile (the tile's owner)
         bool alive = in;
         for (int k = 0; k < n; k++) {
             const int lk = __builtin_ctzll(__ballot(hit && rank == k));
             const int ex0 = (int)rlu(m_rect.x, lk), ey0 = (int)rlu(m_rect.y, lk), ex1 = (int)rlu(m_rect.z, lk), ey1 = (int)rlu(m_rect.w, lk);
             const float ex = rl(m_xyd.x, lk), ey = rl(m_xyd.y, lk);
             const float cx = rl(m_co.x, lk), cy = rl(m_co.y, lk), cz = rl(m_co.z, lk), cw = rl(m_co.w, lk);
-            if (!__any(alive)) break;
-            const bool cov = alive && !(tx < ex0 || tx >= ex1 || ty < ey0 || ty >= ey1);
+            const bool covers = !(tx < ex0 || tx >= ex1 || ty < ey0 || ty >= ey1);
+            if (LOSS && covers) minid = min(minid, lk);
+            if (!LOSS && !__any(alive)) break;
+            const bool cov = alive && covers;
             const float dx = ex - pxf, dy = ey - pyf;
             const float power = -0.5f * (cx * dx * dx + cz * dy * dy) - cy * dx * dy;
             const float alpha = fminf(0.99f, cw * expf_fixed(power));
@@ -1059,7 +1071,7 @@ __global__ __launch_bounds__(256) void k_render_bwd_wave(BwdArgs a)
             const bool pass = cov && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
             const bool stop = pass && test_T < 0.0001f;
             const bool acc = pass && !stop;
-            if (do_clamp) {
+            if (do_clamp || LOSS) {
 #pragma unroll
                 for (int ch = 0; ch < CG; ch++) {
                     if (chmask & (1u << ch)) {
@@ -1072,21 +1084,33 @@ __global__ __launch_bounds__(256) void k_render_bwd_wave(BwdArgs a)
             if (stop) alive = false;
         }
         const bool need = in && klast >= kg;  // g is at or in front of the last contributor at this pixel
-        if (!__any(need)) continue;
+        const bool own = LOSS && in && minid == g;  // this block accounts for the loss at this pixel
+        if (!__any(need || own)) continue;
         // upstream gradient of this pixel: only the active channels, only the lanes that need it
         const size_t pix = (size_t)y * W + x;
         BwdPix<CG> s;
         s.T = T; s.T_final = T; s.last_alpha = 0; s.accum_inv = 0; s.last_inv = 0; s.bgdot = 0;
-        s.dLi = (need && a.dL_invdepth) ? a.dL_invdepth[(size_t)v * HW + pix] : 0.0f;
+        s.dLi = (!LOSS && need && a.dL_invdepth) ? a.dL_invdepth[(size_t)v * HW + pix] : 0.0f;
         {
             const float* dLc = a.dL_color + (size_t)v * C * HW + pix;
 #pragma unroll
             for (int ch = 0; ch < CG; ch++) {
                 float d = 0.0f;
                 if (chmask & (1u << ch)) {
-                    if (need) d = dLc[(size_t)ch * HW];
-                    // torch.clamp backward passes the gradient where min <= x <= max
-                    if (do_clamp && !(col[ch] >= 0.0f && col[ch] <= 1.0f)) d = 0.0f;
+                    if (LOSS) {
+                        const float gtv = (need || own) ? dLc[(size_t)ch * HW] : 0.0f;
+                        const float r = clamp01(col[ch]);          // gaussian_renderer/__init__.py:129
+                        const bool msk = gtv > 0.0f || r > 0.0f;   // loss_utils.py:88-91
+                        const float e = r - gtv;
+                        if (own && msk) { sum[7] += e * e; sum[8] += 1.0f; }
+                        d = msk ? 2.0f * e : 0.0f;
+                        if (!(col[ch] >= 0.0f && col[ch] <= 1.0f)) d = 0.0f;   // clamp backward
+                        if (!need) d = 0.0f;
+                    } else {
+                        if (need) d = dLc[(size_t)ch * HW];
+                        // torch.clamp backward passes the gradient where min <= x <= max
+                        if (do_clamp && !(col[ch] >= 0.0f && col[ch] <= 1.0f)) d = 0.0f;
+                    }
                     if (a.bg) s.bgdot += a.bg[ch] * d;
                 }
                 s.dL[ch] = d;
@@ -1094,6 +1118,16 @@ __global__ __launch_bounds__(256) void k_render_bwd_wave(BwdArgs a)
                 s.last_color[ch] = 0;
             }
         }
+        if (LOSS && own && (x & 15) == 0 && (y & 15) == 0) {
+            // the owned tile's precomputed heat-map sums are replaced by the exact sums accumulated above
+            const int gxt = (W + TILE - 1) / TILE;
+            const size_t tb = (((size_t)v * ((H + TILE - 1) / TILE) + ty) * gxt + tx) * C;
+#pragma unroll
+            for (int ch = 0; ch < CG; ch++) {
+                if (chmask & (1u << ch)) { sum[7] -= a.tile_S[tb + ch]; sum[8] -= a.tile_N[tb + ch]; }
+            }
+        }
+        if (!__any(need)) continue;
         // back to front down to g (backward.cu:552-636); only g's own terms are kept
         for (int k = n - 1; k >= kg; k--) {
             const int lk = __builtin_ctzll(__ballot(hit && rank == k));
@@ -1161,6 +1195,36 @@ __global__ __launch_bounds__(256) void k_render_bwd_wave(BwdArgs a)
         out[tid * BWD_SPLITS] = tid < NV ? ((s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid])) : 0.0f;
 }
 
+// per (view, tile, channel) statistics of the constant pseudo-GT heat-maps, once per scene: sum of gt^2 and count of
+// gt > 0 (what the masked-L2 loss sees wherever the render is zero), and their per-view totals.
+__global__ __launch_bounds__(256) void k_gt_tile_stats(int C, int W, int H, const float* __restrict__ gt, float* __restrict__ tile_S,
+                                                        float* __restrict__ tile_N, double* __restrict__ totals)
+{
+    __shared__ float s_r[2][4];
+    const int tx = blockIdx.x, ty = blockIdx.y, v = blockIdx.z, tid = threadIdx.x;
+    const int x = tx * TILE + (tid & 15), y = ty * TILE + (tid >> 4);
+    const bool in = x < W && y < H;
+    const size_t HW = (size_t)H * W;
+    const size_t tb = (((size_t)v * gridDim.y + ty) * gridDim.x + tx) * C;
+    double tS = 0.0, tN = 0.0;
+    for (int ch = 0; ch < C; ch++) {
+        const float g = in ? gt[((size_t)v * C + ch) * HW + (size_t)y * W + x] : 0.0f;
+        const float S = wave_sum(g * g), N = wave_sum(g > 0.0f ? 1.0f : 0.0f);
+        __syncthreads();
+        if ((tid & 63) == 0) { s_r[0][tid >> 6] = S; s_r[1][tid >> 6] = N; }
+        __syncthreads();
+        if (tid == 0) {
+            const float fs = (s_r[0][0] + s_r[0][1]) + (s_r[0][2] + s_r[0][3]);
+            const float fn = (s_r[1][0] + s_r[1][1]) + (s_r[1][2] + s_r[1][3]);
+            tile_S[tb + ch] = fs;
+            tile_N[tb + ch] = fn;
+            tS += (double)fs;
+            tN += (double)fn;
+        }
+    }
+    if (tid == 0) { atomicAdd(&totals[2 * v], tS); atomicAdd(&totals[2 * v + 1], tN); }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // geometry backward: computeCov2DCUDA (backward.cu:147-326) + preprocessCUDA (:398-449) + computeCov3D
 // (:330-393) fused; consumes and clears the accumulators.  SH backward (:443-444) intentionally not reproduced
@@ -1180,6 +1244,8 @@ struct GeomBwdArgs {
     const int* radii;
     const float* accum;
     int nsplit;
+    const double* gt_totals;   // fused-loss mode: per-view {sum gt^2, count gt > 0} over the whole image, else nullptr
+    double* loss_sums;         // fused-loss mode: out, per-view {S, N} of the masked-L2 loss
     float* dmeans3D;
     float* dmeans2D;
     float* dopacity;
@@ -1195,8 +1261,7 @@ __global__ __launch_bounds__(256) void k_geom_bwd(GeomBwdArgs a, ViewTan vt)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int v = blockIdx.y;
-    if (idx >= a.P) return;
-    const size_t o = (size_t)v * a.P + idx;
+    const size_t o = (size_t)v * a.P + (idx < a.P ? idx : 0);
     const int NVS = NACC + a.C;
     const float* acc = a.accum + o * a.nsplit * NVS;  // layout (value, split)
     float g[NACC];
@@ -1230,6 +1295,25 @@ __global__ __launch_bounds__(256) void k_geom_bwd(GeomBwdArgs a, ViewTan vt)
             a.dfeat[o * a.C + ch] = t;
         }
     }
+    if (a.loss_sums) {  // fused-loss mode (single block per view): image-wide S and N from the owners' partial sums
+        __shared__ double s_l[2][4];
+        double pS = 0.0, pN = 0.0;
+        if (idx < a.P) {
+            for (int sp = 0; sp < a.nsplit; sp++) {
+                pS += (double)acc[7 * a.nsplit + sp];
+                pN += (double)acc[8 * a.nsplit + sp];
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { pS += __shfl_down(pS, off, 64); pN += __shfl_down(pN, off, 64); }
+        if ((threadIdx.x & 63) == 0) { s_l[0][threadIdx.x >> 6] = pS; s_l[1][threadIdx.x >> 6] = pN; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            a.loss_sums[2 * v] = a.gt_totals[2 * v] + ((s_l[0][0] + s_l[0][1]) + (s_l[0][2] + s_l[0][3]));
+            a.loss_sums[2 * v + 1] = a.gt_totals[2 * v + 1] + ((s_l[1][0] + s_l[1][1]) + (s_l[1][2] + s_l[1][3]));
+        }
+    }
+    if (idx >= a.P) return;
     float dmean[3] = { 0, 0, 0 }, dcov[6] = { 0, 0, 0, 0, 0, 0 }, dscale[3] = { 0, 0, 0 }, dq[4] = { 0, 0, 0, 0 };
     float dop = g[5];
     const float dm2x = g[0], dm2y = g[1];
@@ -1656,8 +1740,8 @@ void launch_bwd_small(const BwdArgs& a, int V, int gy, bool dfeat, hipStream_t s
     (void)gy;
     dim3 grid(BWD_SPLITS, a.P, V);
     if (a.P <= 64 && !(a.flags & (1u << 20))) {  // wave-resident variant (bit 20: force the LDS variant, tests)
-        if (dfeat) hipLaunchKernelGGL((k_render_bwd_wave<CG, true>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((k_render_bwd_wave<CG, false>), grid, dim3(256), 0, st, a);
+        if (dfeat) hipLaunchKernelGGL((k_render_bwd_wave<CG, true, false>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_render_bwd_wave<CG, false, false>), grid, dim3(256), 0, st, a);
         return;
     }
     const size_t lds = GatherLds<CG>::bytes((a.P + 15) & ~15, CG, a.C);
@@ -1781,7 +1865,7 @@ int sks_backward(int V, int P, int C, int W, int H, const float* viewmatrix, con
     for (int v = 0; v < V; v++) { vt.x[v] = tanfovx[v]; vt.y[v] = tanfovy[v]; }
     Geom g = geom_from(const_cast<void*>(geom), V, P, W, H);
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE, NT = gx * gy;
-    BwdArgs a{ P, C, W, H, flags, g, features, bg, dL_dout_color, dL_dout_invdepth, (float*)accum };
+    BwdArgs a{ P, C, W, H, flags, g, features, bg, dL_dout_color, dL_dout_invdepth, (float*)accum, nullptr, nullptr };
     const int cg = pick_cg(C);
     const bool dfeat = dL_dfeatures != nullptr;
     const bool small = P <= SKS_SMALL_P && !(flags & SKS_FORCE_BINNED);
@@ -1814,10 +1898,81 @@ int sks_backward(int V, int P, int C, int W, int H, const float* viewmatrix, con
         STAGE_CHECK("render-backward(binned)");
     }
     GeomBwdArgs ga{ P, C, W, H, flags, viewmatrix, projmatrix, means3D, opacities, scales, rotations, cov3D_precomp,
-                    scale_modifier, radii, (const float*)accum, small ? BWD_SPLITS : 1, dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dscales,
+                    scale_modifier, radii, (const float*)accum, small ? BWD_SPLITS : 1, nullptr, nullptr, dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dscales,
                     dL_drotations, dL_dcov3D, dL_dfeatures };
     hipLaunchKernelGGL(k_geom_bwd, dim3((P + 255) / 256, V), dim3(256), 0, st, ga, vt);
     STAGE_CHECK("geometry-backward");
+    return 0;
+}
+
+int sks_gt_tile_stats(int V, int C, int W, int H, const float* gt, float* tile_S, float* tile_N, double* totals, void* stream)
+{
+    if (int rc = check_common(V, 1, C, W, H)) return rc;
+    if (!gt || !tile_S || !tile_N || !totals) return fail(-2, "gt_tile_stats: missing pointer");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(totals, 0, (size_t)V * 2 * sizeof(double), st));
+    dim3 grid((W + TILE - 1) / TILE, (H + TILE - 1) / TILE, V);
+    hipLaunchKernelGGL(k_gt_tile_stats, grid, dim3(256), 0, st, C, W, H, gt, tile_S, tile_N, totals);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int sks_backward_fused_loss(int V, int P, int C, int W, int H, const float* viewmatrix, const float* projmatrix,
+                            const float* tanfovx, const float* tanfovy, const float* bg, const float* means3D,
+                            const float* features, const float* opacities, const float* scales, const float* rotations,
+                            const float* cov3D_precomp, float scale_modifier, unsigned flags, const int* radii,
+                            const void* geom, const float* gt, const float* tile_S, const float* tile_N,
+                            const double* gt_totals, void* accum, float* dL_dmeans3D, float* dL_dmeans2D,
+                            float* dL_dopacity, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
+                            double* loss_sums, void* stream)
+{
+    if (int rc = check_common(V, P, C, W, H)) return rc;
+    if (P < 1 || P > 64) return fail(-1, "fused-loss backward needs 1 <= P <= 64 (got %d)", P);
+    hipStream_t st = (hipStream_t)stream;
+    if (!viewmatrix || !projmatrix || !tanfovx || !tanfovy || !means3D || !features || !opacities || !radii || !geom || !gt ||
+        !tile_S || !tile_N || !gt_totals || !accum || !dL_dmeans3D || !dL_dmeans2D || !dL_dopacity || !loss_sums)
+        return fail(-2, "missing required pointer");
+    if (!cov3D_precomp && (!scales || !rotations)) return fail(-2, "need scales+rotations or cov3D_precomp");
+    ViewTan vt;
+    for (int v = 0; v < V; v++) { vt.x[v] = tanfovx[v]; vt.y[v] = tanfovy[v]; }
+    Geom g = geom_from(const_cast<void*>(geom), V, P, W, H);
+    BwdArgs a{ P, C, W, H, flags | SKS_CLAMP01, g, features, bg, gt, nullptr, (float*)accum, tile_S, tile_N };
+    dim3 grid(BWD_SPLITS, P, V);
+    {
+        ProfScope prof(1, st);
+        switch (pick_cg(C)) {
+            case 4: hipLaunchKernelGGL((k_render_bwd_wave<4, false, true>), grid, dim3(256), 0, st, a); break;
+            case 16: hipLaunchKernelGGL((k_render_bwd_wave<16, false, true>), grid, dim3(256), 0, st, a); break;
+            case 20: hipLaunchKernelGGL((k_render_bwd_wave<20, false, true>), grid, dim3(256), 0, st, a); break;
+            default: hipLaunchKernelGGL((k_render_bwd_wave<32, false, true>), grid, dim3(256), 0, st, a); break;
+        }
+    }
+    STAGE_CHECK("fused loss + render-backward");
+    GeomBwdArgs ga{ P, C, W, H, flags, viewmatrix, projmatrix, means3D, opacities, scales, rotations, cov3D_precomp,
+                    scale_modifier, radii, (const float*)accum, BWD_SPLITS, gt_totals, loss_sums, dL_dmeans3D, dL_dmeans2D,
+                    dL_dopacity, dL_dscales, dL_drotations, dL_dcov3D, nullptr };
+    hipLaunchKernelGGL(k_geom_bwd, dim3((P + 255) / 256, V), dim3(256), 0, st, ga, vt);
+    STAGE_CHECK("geometry-backward");
+    return 0;
+}
+
+int sks_geometry(int V, int P, int C, int W, int H, const float* viewmatrix, const float* projmatrix, const float* tanfovx,
+                 const float* tanfovy, const float* means3D, const float* opacities, const float* scales,
+                 const float* rotations, const float* cov3D_precomp, float scale_modifier, unsigned flags, int* radii,
+                 void* geom, void* stream)
+{
+    if (int rc = check_common(V, P, C, W, H)) return rc;
+    if (P < 1) return fail(-1, "P must be positive");
+    if (!viewmatrix || !projmatrix || !tanfovx || !tanfovy || !means3D || !opacities || !radii || !geom)
+        return fail(-2, "missing required pointer");
+    if (!cov3D_precomp && (!scales || !rotations)) return fail(-2, "need scales+rotations or cov3D_precomp");
+    hipStream_t st = (hipStream_t)stream;
+    ViewTan vt;
+    for (int v = 0; v < V; v++) { vt.x[v] = tanfovx[v]; vt.y[v] = tanfovy[v]; }
+    Geom g = geom_from(geom, V, P, W, H);
+    hipLaunchKernelGGL(k_geom_fwd, dim3((P + 255) / 256, V), dim3(256), 0, st, P, W, H, vt, viewmatrix, projmatrix,
+                       means3D, opacities, scales, rotations, cov3D_precomp, scale_modifier, flags, g, radii);
+    STAGE_CHECK("geometry");
     return 0;
 }
 

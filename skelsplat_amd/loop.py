@@ -71,7 +71,7 @@ class MultiViewLoop:
 
     def __init__(self, gaussians, cameras, heatmaps, dataset="h36m", accumulation_steps=4, lambda_consistency=1e-5,
                  bg=None, antialiasing=False, loss_grad=None, group=None, view_grad_fn=None, device_tail=None,
-                 use_graph=False):
+                 use_graph=False, sparse=None):
         self.gm = gaussians
         self.dataset = dataset
         self.V = len(cameras)
@@ -112,6 +112,12 @@ class MultiViewLoop:
         self.device_tail = bool(device_tail)
         self.use_graph = bool(use_graph) and self.device_tail and self.world == 1
         self._graph = None
+        # sparse fused step: render + clamp + masked-L2 + backward only on the tiles some Gaussian rect covers, using
+        # per-tile statistics of the constant heat-maps (sks_gt_tile_stats); no dense image / gradient is ever written
+        if sparse is None:
+            sparse = self.device_tail and P <= 64
+        self.sparse = bool(sparse) and self.device_tail and P <= 64
+        self._stats = R.gt_tile_stats(self.gt) if (self.sparse and self.local_ids) else None
         if self.device_tail:
             import ctypes
             from . import _lib
@@ -165,15 +171,21 @@ class MultiViewLoop:
                 means = gm._xyz.detach()
                 feats = gm.get_features.reshape(P, -1)
                 opac, scales, quats = gm.get_opacity.detach(), gm.get_scaling.detach(), gm.get_rotation.detach()
-                color, inv, radii, st = R.forward_views(self.views, means, feats, opac, scales, quats, None,
-                                                        antialiasing=self.antialiasing, clamp01=True)
-                dL, S, N = masked_l2(color, self.gt)
-                g = R.backward_views(st, means, feats, opac, scales, quats, None, dL, None, bg=self.bg)
+                if self.sparse:
+                    st = R.geometry_views(self.views, means, feats.shape[1], opac, scales, quats, None,
+                                          antialiasing=self.antialiasing)
+                    g, sums = R.backward_fused_loss(st, self._stats, means, feats, opac, scales, quats, None, bg=self.bg)
+                    S, N = sums[:, 0], sums[:, 1]
+                else:
+                    color, inv, radii, st = R.forward_views(self.views, means, feats, opac, scales, quats, None,
+                                                            antialiasing=self.antialiasing, clamp01=True)
+                    dL, S, N = masked_l2(color, self.gt)
+                    g = R.backward_views(st, means, feats, opac, scales, quats, None, dL, None, bg=self.bg)
+                    sums = torch.stack([S, N], dim=1).contiguous()
                 Vl = len(self.local_ids)
                 packed = torch.empty((self.vmax if self.world > 1 else Vl, P, 11), device=dev)
                 if self.world > 1 and Vl < self.vmax:
                     packed[Vl:].zero_()
-                sums = torch.stack([S, N], dim=1).contiguous()
                 _lib.check(lib.sks_loop_pack_grads(Vl, P, g["means3D"].data_ptr(), g["scales"].data_ptr(),
                                                    g["rotations"].data_ptr(), g["opacities"].data_ptr(),
                                                    gm._scaling.data_ptr(), gm._rotation.data_ptr(), gm._opacity.data_ptr(),

@@ -352,3 +352,93 @@ def decode_geom(st: ForwardState):
     xyd = g[seg:seg + n].view(torch.float32).reshape(V, P, 4)
     rect = g[2 * seg:2 * seg + n].view(torch.int32).reshape(V, P, 4)
     return dict(conic_opacity=co, xy=xyd[..., :2], depths=xyd[..., 2], rect=rect)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# sparse fused training step (sks_gt_tile_stats / sks_geometry / sks_backward_fused_loss)
+# ------------------------------------------------------------------------------------------------------------
+class GtStats:
+    """Per-scene statistics of the constant pseudo-GT heat-maps (V,C,H,W): what the masked-L2 loss sees wherever the
+    render is zero."""
+    __slots__ = ("gt", "tile_S", "tile_N", "totals")
+
+
+def gt_tile_stats(gt):
+    gt = _f32c(gt, "gt")
+    V, C, H, W = gt.shape
+    NT = ((W + 15) // 16) * ((H + 15) // 16)
+    dev = gt.device
+    st = GtStats()
+    st.gt = gt
+    st.tile_S = torch.empty((V, NT, C), dtype=torch.float32, device=dev)
+    st.tile_N = torch.empty((V, NT, C), dtype=torch.float32, device=dev)
+    st.totals = torch.empty((V, 2), dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.load().sks_gt_tile_stats(V, C, W, H, gt.data_ptr(), st.tile_S.data_ptr(), st.tile_N.data_ptr(),
+                                           st.totals.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(rc, "sks_gt_tile_stats")
+    return st
+
+
+def geometry_views(views: ViewBatch, means3D, C, opacities, scales, rotations, cov3D_precomp, scale_modifier=1.0,
+                   antialiasing=False):
+    """Geometry stage only (no image): returns a ForwardState usable by backward_fused_loss."""
+    lib = _lib.load()
+    means3D = _f32c(means3D, "means3D")
+    dev = means3D.device
+    P = means3D.shape[0]
+    opacities = _f32c(opacities, "opacities")
+    scales, rotations, cov3D_precomp = _f32c(scales, "scales"), _f32c(rotations, "rotations"), _f32c(cov3D_precomp, "cov3D_precomp")
+    V, W, H = views.V, views.W, views.H
+    flags = _lib.SKS_ANTIALIASING if antialiasing else 0
+    gbytes, _, _ = _lib.scratch_bytes(V, max(P, 1), C, W, H, 0)
+    radii = torch.empty((V, P), dtype=torch.int32, device=dev)
+    geom = torch.empty(gbytes, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.sks_geometry(V, P, C, W, H, views.viewmatrix.data_ptr(), views.projmatrix.data_ptr(), views.tanfovx,
+                              views.tanfovy, _lib.ptr(means3D), _lib.ptr(opacities), _lib.ptr(scales), _lib.ptr(rotations),
+                              _lib.ptr(cov3D_precomp), float(scale_modifier), flags, radii.data_ptr(), geom.data_ptr(),
+                              torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(rc, "sks_geometry")
+    st = ForwardState()
+    st.views, st.P, st.C, st.flags, st.scale_modifier = views, P, C, flags, float(scale_modifier)
+    st.geom, st.binning, st.bin_capacity, st.radii, st.num_rendered_dev = geom, None, 0, radii, None
+    return st
+
+
+def backward_fused_loss(st: ForwardState, stats: GtStats, means3D, features, opacities, scales, rotations, cov3D_precomp,
+                        bg=None):
+    """Render + clamp + masked-L2 + backward on the covered tiles only.  Returns (grads dict of (V,P,..) UNSCALED
+    gradients, loss_sums (V,2) f64 = per-view {S, N}); the true gradient is grads / N_v, loss_v = S_v / N_v."""
+    lib = _lib.load()
+    means3D = _f32c(means3D, "means3D")
+    dev = means3D.device
+    V, P, C = st.views.V, st.P, st.C
+    W, H = st.views.W, st.views.H
+    if tuple(stats.gt.shape) != (V, C, H, W):
+        raise RuntimeError(f"heat-maps {tuple(stats.gt.shape)} do not match the views {(V, C, H, W)}")
+    feat2 = _f32c(features, "features").reshape(P, -1)
+    opacities = _f32c(opacities, "opacities")
+    scales, rotations, cov3D_precomp = _f32c(scales, "scales"), _f32c(rotations, "rotations"), _f32c(cov3D_precomp, "cov3D_precomp")
+    bgC = None
+    if bg is not None and bg.numel() > 0 and bool((bg != 0).any()):
+        bgC = torch.zeros(C, dtype=torch.float32, device=dev)
+        k = min(C, bg.numel())
+        bgC[:k] = bg.reshape(-1)[:k].to(device=dev, dtype=torch.float32)
+    e = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+    out = dict(means3D=e(V, P, 3), means2D=e(V, P, 3), opacities=e(V, P, 1), cov3D=e(V, P, 6),
+               scales=e(V, P, 3) if scales is not None else None, rotations=e(V, P, 4) if rotations is not None else None)
+    sums = torch.empty((V, 2), dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    accum = _accum(dev, stream, V, P, C)
+    with torch.cuda.device(dev):
+        rc = lib.sks_backward_fused_loss(V, P, C, W, H, st.views.viewmatrix.data_ptr(), st.views.projmatrix.data_ptr(),
+                                         st.views.tanfovx, st.views.tanfovy, _lib.ptr(bgC), _lib.ptr(means3D), _lib.ptr(feat2),
+                                         _lib.ptr(opacities), _lib.ptr(scales), _lib.ptr(rotations), _lib.ptr(cov3D_precomp),
+                                         st.scale_modifier, st.flags, st.radii.data_ptr(), st.geom.data_ptr(),
+                                         stats.gt.data_ptr(), stats.tile_S.data_ptr(), stats.tile_N.data_ptr(),
+                                         stats.totals.data_ptr(), accum.data_ptr(), _lib.ptr(out["means3D"]),
+                                         _lib.ptr(out["means2D"]), _lib.ptr(out["opacities"]), _lib.ptr(out["scales"]),
+                                         _lib.ptr(out["rotations"]), _lib.ptr(out["cov3D"]), sums.data_ptr(), stream)
+    _lib.check(rc, "sks_backward_fused_loss")
+    return out, sums

@@ -167,3 +167,54 @@ def test_device_tail_loop_matches_tensor_op_tail(device, use_graph):
     util.assert_close("scaling", res[0][1], res[1][1], rtol=1e-4, atol_scale=1e-4)
     util.assert_close("rotation", res[0][2], res[1][2], rtol=1e-4, atol_scale=1e-4)
     util.assert_close("opacity", res[0][3], res[1][3], rtol=1e-5, atol_scale=1e-5)
+
+
+@pytest.mark.parametrize("dataset", ["h36m", "panoptic"])
+def test_sparse_fused_loss_backward_equals_dense_path(device, dataset):
+    """sks_geometry + sks_backward_fused_loss (no image, no dense gradient, per-tile heat-map statistics) give the
+    same loss sums and the same gradients as sks_forward(clamp) -> sks_masked_l2 -> sks_backward."""
+    from skelsplat_amd import rasterizer as R
+    from skelsplat_amd.ops import masked_l2
+    from skelsplat_amd.scene import SyntheticScene, GaussianModel
+    from skelsplat_amd.heatmaps import generate_heatmaps
+    W, H = 176, 144
+    sc = SyntheticScene(dataset, n_views=3, seed=11, W=W, H=H, ring=2500.0, fx=1145.0 * (W / 1000) * 1.5, device=device)
+    gm = GaussianModel().create_from_points(sc.pose_3d_init, sc.spatial_lr_scale, sc.n_joints, scaling=4.2, scene_type=dataset,
+                                            device=device)
+    hm = generate_heatmaps(torch.tensor(sc.pose_3d_gt, device=device).float(), gm.get_scaling.detach() * 1.3,
+                           gm._rotation.detach(), torch.tensor(sc.poses_2d, device=device), sc.cameras)
+    P, C = sc.n_points, sc.n_joints
+    with torch.no_grad():
+        args = (gm._xyz.detach(), gm.get_features.reshape(P, C), gm.get_opacity.detach(), gm.get_scaling.detach(),
+                gm.get_rotation.detach(), None)
+    views = R.ViewBatch.from_cameras(sc.cameras)
+    color, inv, radii, st = R.forward_views(views, *args, clamp01=True)
+    dL, S, N = masked_l2(color, hm)
+    gd = R.backward_views(st, *args, dL)
+    stats = R.gt_tile_stats(hm)
+    st2 = R.geometry_views(views, args[0], C, args[2], args[3], args[4], None)
+    gs, sums = R.backward_fused_loss(st2, stats, *args)
+    assert torch.equal(st2.radii, radii)
+    assert torch.equal(sums[:, 1], N), (sums[:, 1], N)                       # mask counts are integers: exact
+    assert ((sums[:, 0] - S).abs() <= 1e-5 * S.abs()).all(), (sums[:, 0], S)
+    assert float(N.min()) > 1000 and float(S.min()) > 0
+    for k in ("means3D", "means2D", "opacities", "scales", "rotations"):
+        util.assert_close(k, gs[k].cpu(), gd[k].cpu(), rtol=1e-4, atol_scale=1e-5)
+
+
+def test_sparse_loop_equals_dense_loop(device):
+    from skelsplat_amd.loop import MultiViewLoop
+    from skelsplat_amd.heatmaps import generate_heatmaps
+    sc, model = _make_loop_scene(device, seed=9)
+    outs = []
+    for sparse in (True, False):
+        gm = model(device)
+        hm = generate_heatmaps(gm._xyz.detach(), gm.get_scaling.detach(), gm._rotation.detach(),
+                               torch.tensor(sc.poses_2d, device=device), sc.cameras)
+        loop = MultiViewLoop(gm, sc.cameras, hm, dataset="h36m", sparse=sparse, use_graph=sparse)
+        assert loop.sparse == sparse
+        loop.run(40)
+        outs.append((gm._xyz.detach().cpu().clone(), gm._scaling.detach().cpu().clone()))
+    moved = (outs[0][0] - torch.tensor(sc.pose_3d_init).float()).norm(dim=1).mean().item()
+    assert moved > 1.0 and (outs[0][0] - outs[1][0]).norm(dim=1).max().item() < 2e-3 * moved
+    util.assert_close("scaling", outs[0][1], outs[1][1], rtol=1e-4, atol_scale=1e-4)
