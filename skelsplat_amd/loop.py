@@ -88,9 +88,21 @@ class MultiViewLoop:
         # only the multi-process CPU tests use it (gloo has no GPU), the product path is _local_view_grads.
         self.view_grad_fn = view_grad_fn
         self.cameras = cameras
-        self.views = (R.ViewBatch.from_cameras([cameras[v] for v in self.local_ids])
-                      if (self.local_ids and view_grad_fn is None) else None)
-        self.gt = heatmaps[self.local_ids].contiguous() if self.local_ids else None
+        # `heatmaps`: one (V,C,H,W) tensor, or a list of V (C,H_v,W_v) tensors when the cameras differ in size
+        # (H36M mixes 1000x1000 and 1002x1000 sensors, quirk Q11).  Local views are grouped by image size; every
+        # size group is one batched launch sequence.  self.order = local slot -> position in the concatenated groups.
+        hm_of = (lambda v: heatmaps[v])
+        by_size = {}
+        for k, v in enumerate(self.local_ids):
+            key = (int(cameras[v].image_width), int(cameras[v].image_height))
+            by_size.setdefault(key, []).append(k)
+        self.size_groups = []   # (local slots, ViewBatch or None, gt (Vg,C,H,W), stats or None)
+        for key, slots in by_size.items():
+            vb = (R.ViewBatch.from_cameras([cameras[self.local_ids[k]] for k in slots]) if view_grad_fn is None else None)
+            gt = torch.stack([hm_of(self.local_ids[k]) for k in slots]).contiguous()
+            self.size_groups.append([slots, vb, gt, None])
+        self.gt = self.size_groups[0][2] if len(self.size_groups) == 1 else None   # single-size convenience (tests, view_grad_fn)
+        self.views = self.size_groups[0][1] if len(self.size_groups) == 1 else None
         self.bg = bg
         default_loss = loss_grad is None
         if loss_grad is None and view_grad_fn is None:
@@ -117,7 +129,9 @@ class MultiViewLoop:
         if sparse is None:
             sparse = self.device_tail and P <= 64
         self.sparse = bool(sparse) and self.device_tail and P <= 64
-        self._stats = R.gt_tile_stats(self.gt) if (self.sparse and self.local_ids) else None
+        if self.sparse:
+            for grp in self.size_groups:
+                grp[3] = R.gt_tile_stats(grp[2])
         if self.device_tail:
             import ctypes
             from . import _lib
@@ -143,13 +157,17 @@ class MultiViewLoop:
             opac = gm.get_opacity.detach()
             scales = gm.get_scaling.detach()
             quats = gm.get_rotation.detach()
-            color, inv, radii, st = R.forward_views(self.views, means, feats, opac, scales, quats, None,
-                                                    antialiasing=self.antialiasing, clamp01=True)
-            dL, losses, scale = self.loss_grad(color, self.gt)
-            g = R.backward_views(st, means, feats, opac, scales, quats, None, dL, None, bg=self.bg)
-            d_scaling, d_rotation, d_opacity = activation_chain(gm, g)
-            packed = torch.cat([g["means3D"], d_scaling, d_rotation, d_opacity], dim=-1)  # (V_local, P, 11)
-            packed = packed * scale[:, None, None]   # 1 / N_mask of each view (the backward is linear in dL)
+            packed = torch.empty((len(self.local_ids), P, 11), device=means.device)
+            losses = torch.empty(len(self.local_ids), device=means.device)
+            for slots, vb, gt, _ in self.size_groups:
+                color, inv, radii, st = R.forward_views(vb, means, feats, opac, scales, quats, None,
+                                                        antialiasing=self.antialiasing, clamp01=True)
+                dL, lv, scale = self.loss_grad(color, gt)
+                g = R.backward_views(st, means, feats, opac, scales, quats, None, dL, None, bg=self.bg)
+                d_scaling, d_rotation, d_opacity = activation_chain(gm, g)
+                pk = torch.cat([g["means3D"], d_scaling, d_rotation, d_opacity], dim=-1)  # (Vg, P, 11)
+                packed[slots] = pk * scale[:, None, None]   # 1 / N_mask of each view (the backward is linear in dL)
+                losses[slots] = lv
         return packed, losses
 
     def _consistency_grad(self):
@@ -171,26 +189,35 @@ class MultiViewLoop:
                 means = gm._xyz.detach()
                 feats = gm.get_features.reshape(P, -1)
                 opac, scales, quats = gm.get_opacity.detach(), gm.get_scaling.detach(), gm.get_rotation.detach()
-                if self.sparse:
-                    st = R.geometry_views(self.views, means, feats.shape[1], opac, scales, quats, None,
-                                          antialiasing=self.antialiasing)
-                    g, sums = R.backward_fused_loss(st, self._stats, means, feats, opac, scales, quats, None, bg=self.bg)
-                    S, N = sums[:, 0], sums[:, 1]
-                else:
-                    color, inv, radii, st = R.forward_views(self.views, means, feats, opac, scales, quats, None,
-                                                            antialiasing=self.antialiasing, clamp01=True)
-                    dL, S, N = masked_l2(color, self.gt)
-                    g = R.backward_views(st, means, feats, opac, scales, quats, None, dL, None, bg=self.bg)
-                    sums = torch.stack([S, N], dim=1).contiguous()
                 Vl = len(self.local_ids)
                 packed = torch.empty((self.vmax if self.world > 1 else Vl, P, 11), device=dev)
                 if self.world > 1 and Vl < self.vmax:
                     packed[Vl:].zero_()
-                _lib.check(lib.sks_loop_pack_grads(Vl, P, g["means3D"].data_ptr(), g["scales"].data_ptr(),
-                                                   g["rotations"].data_ptr(), g["opacities"].data_ptr(),
-                                                   gm._scaling.data_ptr(), gm._rotation.data_ptr(), gm._opacity.data_ptr(),
-                                                   sums.data_ptr(), packed.data_ptr(), stream), "sks_loop_pack_grads")
-                self.last_losses = (S, N)
+                single = len(self.size_groups) == 1
+                all_sums = None if single else torch.empty((Vl, 2), dtype=torch.float64, device=dev)
+                for slots, vb, gt, stats in self.size_groups:
+                    if self.sparse:
+                        st = R.geometry_views(vb, means, feats.shape[1], opac, scales, quats, None,
+                                              antialiasing=self.antialiasing)
+                        g, sums = R.backward_fused_loss(st, stats, means, feats, opac, scales, quats, None, bg=self.bg)
+                    else:
+                        color, inv, radii, st = R.forward_views(vb, means, feats, opac, scales, quats, None,
+                                                                antialiasing=self.antialiasing, clamp01=True)
+                        dL, S, N = masked_l2(color, gt)
+                        g = R.backward_views(st, means, feats, opac, scales, quats, None, dL, None, bg=self.bg)
+                        sums = torch.stack([S, N], dim=1).contiguous()
+                    Vg = len(slots)
+                    pk = packed if single else torch.empty((Vg, P, 11), device=dev)
+                    _lib.check(lib.sks_loop_pack_grads(Vg, P, g["means3D"].data_ptr(), g["scales"].data_ptr(),
+                                                       g["rotations"].data_ptr(), g["opacities"].data_ptr(),
+                                                       gm._scaling.data_ptr(), gm._rotation.data_ptr(), gm._opacity.data_ptr(),
+                                                       sums.data_ptr(), pk.data_ptr(), stream), "sks_loop_pack_grads")
+                    if single:
+                        all_sums = sums
+                    else:
+                        packed[slots] = pk
+                        all_sums[slots] = sums
+                self.last_losses = (all_sums[:, 0], all_sums[:, 1])
             else:
                 packed = torch.zeros((self.vmax, P, 11), device=dev)
             if self.world > 1:

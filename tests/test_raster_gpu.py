@@ -225,3 +225,40 @@ def test_many_gaussians_small_path(device):
     util.assert_close("dL_dmeans3D", g["means3D"][0].cpu(), b["dL_dmeans3D"])
     util.assert_close("dL_drotations", g["rotations"][0].cpu(), b["dL_drotations"])
     util.assert_close("dL_dfeatures", g["features"][0].cpu(), b["dL_dcolors"])
+
+
+def test_stress_config_binned_path(device):
+    """BASELINE config 5 shape: 256 skeletons (P = 4352, C = 17), 2048x2048, binned path.  The oracle is too slow at this
+    size, so: oracle parity on a cropped-resolution twin (same P, 512x512) + size-independent properties at full size."""
+    dev = device
+    c = util.make_case(seed=41, W=512, H=512, n_views=1, scale_log=3.3, n_skeletons=256, pitch=1500.0, ring=20000.0, fxmul=4.0)
+    assert c.P == 4352
+    views = R.ViewBatch.from_cameras([cam.to(dev) for cam in c.cams])
+    args = (t(c.means, dev), t(c.feat, dev), t(c.opac, dev), t(c.scales, dev), t(c.quats, dev), None)
+    color, inv, radii, st, final_T, n_contrib = R.forward_views(views, *args, want_aux=True, bin_capacity=200000)
+    o = util.oracle_forward(c, 0)
+    pl, rg, nr = R.export_lists(st)
+    assert int(nr[0].item()) == o["R"] and o["R"] > 4000
+    assert np.array_equal(pl[0, :o["R"]].cpu().numpy().astype(np.uint32), o["point_list"])
+    assert np.array_equal(rg[0].cpu().numpy().astype(np.uint32), o["ranges"])
+    assert np.array_equal(color[0].cpu().numpy(), o["color"]) and np.array_equal(n_contrib[0].cpu().numpy().astype(np.uint32), o["n_contrib"])
+    g = R.backward_views(st, *args, t(c.dL_color, dev), t(c.dL_inv, dev))
+    b = util.oracle_backward(c, 0, o)
+    util.assert_close("dL_dmeans3D", g["means3D"][0].cpu(), b["dL_dmeans3D"])
+    util.assert_close("dL_dscales", g["scales"][0].cpu(), b["dL_dscales"])
+    # full size: 8 views at 2048^2
+    big = util.make_case(seed=42, W=2048, H=2048, n_views=8, scale_log=3.0, n_skeletons=256, pitch=1500.0, ring=20000.0,
+                         fxmul=2300.0 / (1145.0 * 2.048), onehot=True, opac=1.0)
+    views = R.ViewBatch.from_cameras([cam.to(dev) for cam in big.cams])
+    args = (t(big.means, dev), t(big.feat, dev), t(big.opac, dev), t(big.scales, dev), t(big.quats, dev), None)
+    color, inv, radii, st = R.forward_views(views, *args, bin_capacity=400000)
+    nr = st.num_rendered_dev[:8].cpu()
+    assert (nr > 4000).all() and (nr < 400000).all(), nr
+    # same-channel joints of different skeletons overlap, so a channel can exceed 0.99 but never reach 1 (1 - prod(1-a))
+    assert torch.isfinite(color).all() and float(color.max()) < 1.0 and float(color.min()) >= 0.0
+    assert (radii > 0).float().mean() > 0.5   # part of the 24 m grid is outside some of the ring cameras
+    dL = torch.randn(color.shape, device=dev)
+    g1 = R.backward_views(st, *args, dL)
+    g2 = R.backward_views(st, *args, 3.0 * dL)
+    assert torch.isfinite(g1["means3D"]).all()
+    util.assert_close("linearity", g2["means3D"].cpu(), 3.0 * g1["means3D"].cpu(), rtol=1e-3, atol_scale=1e-4)
