@@ -44,6 +44,9 @@ extern "C" {
 #define SKS_NO_NT_STORES 16u  /* tuning: plain instead of non-temporal stores for the dense forward planes
                                  (non-temporal is the default: the planes are written once and read by another kernel) */
 
+#define SKS_RAW_PARAMS   32u   /* opacities / scales / rotations are the LEAF parameters (_opacity logits, _scaling
+                                 log-scales, raw _rotation); sigmoid / exp / normalize (scene/gaussian_model.py:39-47)
+                                 run inside the kernels (sks_geometry, sks_forward, sks_backward*) */
 #define SKS_BWD_LDS_LIST (1u << 20) /* tests: use the LDS-list backward even when P <= 64 (default: wave-resident) */
 
 const char* sks_last_error(void);
@@ -149,7 +152,9 @@ int sks_backward_fused_loss(int V, int P, int C, int W, int H, const float* view
                             const int* radii, const void* geom, const float* gt, const float* tile_S, const float* tile_N,
                             const double* gt_totals, void* accum, float* dL_dmeans3D, float* dL_dmeans2D,
                             float* dL_dopacity, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
-                            double* loss_sums, void* stream);
+                            double* loss_sums, float* packed_raw_grads /* optional (V,P,11), see sks_loop_pack_grads:
+                            with SKS_RAW_PARAMS the activation Jacobians and the 1/N_v scale are applied here */,
+                            void* stream);
 
 /* Device-side tail of the multi-view loop (train.py:160-222), so that one accumulation group is a fixed launch
  * sequence with no host state (capturable into a hipGraph):

@@ -18,6 +18,7 @@ SKS_CLAMP01 = 2
 SKS_FORCE_BINNED = 4
 SKS_DEBUG_SYNC = 8
 SKS_NO_NT_STORES = 16
+SKS_RAW_PARAMS = 32
 
 _vp, _i, _u, _f, _sz = C.c_void_p, C.c_int, C.c_uint, C.c_float, C.c_size_t
 
@@ -39,7 +40,7 @@ SIGNATURES = {
     "sks_gt_tile_stats": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "sks_geometry": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _u, _vp, _vp, _vp]),
     "sks_backward_fused_loss": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _u,
-                                     _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+                                     _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sks_loop_pack_grads": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sks_loop_adam_step": (_i, [_i, _i, _vp, _vp, C.c_ulonglong, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp,
                                 _f, _vp, _vp]),

@@ -102,18 +102,27 @@ __global__ __launch_bounds__(256) void k_loop_adam(AdamArgs a)
     if (live) {
         s_xyz[3 * p] = a.xyz[3 * p]; s_xyz[3 * p + 1] = a.xyz[3 * p + 1]; s_xyz[3 * p + 2] = a.xyz[3 * p + 2];
     }
-    __syncthreads();
-    // LR schedule evaluated at that iteration, in double like the host code (train.py:134, quirk Q9)
-    double lr_xyz = 0.0;
-    if (!(a.lr_init == 0.0 && a.lr_final == 0.0)) {
-        double delay = 1.0;
-        if (a.lr_delay_steps > 0) {
-            const double c = fmin(fmax((double)it1 / (double)a.lr_delay_steps, 0.0), 1.0);
-            delay = a.lr_delay_mult + (1.0 - a.lr_delay_mult) * sin(0.5 * 3.14159265358979323846 * c);
+    // LR schedule + bias corrections, in double like the host code (train.py:134, quirk Q9); one thread computes them
+    __shared__ float s_hyp[6];  // step sizes xyz / scaling / rotation / opacity, sqrt(bias_correction2), spare
+    if (p == 0) {
+        double lr_xyz = 0.0;
+        if (!(a.lr_init == 0.0 && a.lr_final == 0.0)) {
+            double delay = 1.0;
+            if (a.lr_delay_steps > 0) {
+                const double c = fmin(fmax((double)it1 / (double)a.lr_delay_steps, 0.0), 1.0);
+                delay = a.lr_delay_mult + (1.0 - a.lr_delay_mult) * sin(0.5 * 3.14159265358979323846 * c);
+            }
+            const double t = fmin(fmax((double)it1 / (double)a.lr_max_steps, 0.0), 1.0);
+            lr_xyz = delay * exp(log(a.lr_init) * (1.0 - t) + log(a.lr_final) * t);
         }
-        const double t = fmin(fmax((double)it1 / (double)a.lr_max_steps, 0.0), 1.0);
-        lr_xyz = delay * exp(log(a.lr_init) * (1.0 - t) + log(a.lr_final) * t);
+        const double bc1 = 1.0 - pow(a.beta1, (double)step);
+        s_hyp[0] = (float)(lr_xyz / bc1);
+        s_hyp[1] = (float)(a.lr_scaling / bc1);
+        s_hyp[2] = (float)(a.lr_rotation / bc1);
+        s_hyp[3] = (float)(a.lr_opacity / bc1);
+        s_hyp[4] = (float)sqrt(1.0 - pow(a.beta2, (double)step));
     }
+    __syncthreads();
     // limb-symmetry loss gradient: L = lambda * (| |la| - |ra| | + | |ll| - |rl| |)  (loss_utils.py:226-250);
     // every view's loss contains it, so every slot carries it (train.py:150-152,175)
     float gc[3] = { 0, 0, 0 };
@@ -156,11 +165,9 @@ __global__ __launch_bounds__(256) void k_loop_adam(AdamArgs a)
 #pragma unroll
     for (int c = 0; c < 3; c++) gx[c] /= (float)V;
     const float* gl = a.grads + ((size_t)a.last_view * P + p) * 11;
-    const double bc1 = 1.0 - pow(a.beta1, (double)step);
-    const float bc2s = (float)sqrt(1.0 - pow(a.beta2, (double)step));
+    const float bc2s = s_hyp[4];
     const float w1 = (float)(1.0 - a.beta1), b2 = (float)a.beta2, w2 = (float)(1.0 - a.beta2), eps = (float)a.eps;
-    const float ss_xyz = (float)(lr_xyz / bc1), ss_s = (float)(a.lr_scaling / bc1), ss_r = (float)(a.lr_rotation / bc1),
-                ss_o = (float)(a.lr_opacity / bc1);
+    const float ss_xyz = s_hyp[0], ss_s = s_hyp[1], ss_r = s_hyp[2], ss_o = s_hyp[3];
     float* m = a.m + (size_t)p * 11;
     float* vv = a.vv + (size_t)p * 11;
 #pragma unroll

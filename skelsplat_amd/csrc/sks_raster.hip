@@ -104,6 +104,33 @@ struct Geom {  // per-(view, Gaussian) records kept for backward ("geomBuffer")
 
 __host__ __device__ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// SKS_RAW_PARAMS: the caller passes the LEAF parameters (_opacity logits, _scaling log-scales, _rotation raw
+// quaternions) and the activations of scene/gaussian_model.py:39-47 (sigmoid / exp / F.normalize) run in-kernel.
+struct Activated {
+    float opacity, s[3], q[4], qnorm;
+};
+__device__ __forceinline__ Activated activate(bool raw, float op, const float s[3], const float q[4])
+{
+    Activated a;
+    if (raw) {
+        a.opacity = 1.0f / (1.0f + expf_fixed(-op));
+#pragma unroll
+        for (int k = 0; k < 3; k++) a.s[k] = expf_fixed(s[k]);
+        const float nn = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+        a.qnorm = fmaxf(sqrtf(nn), 1e-12f);
+#pragma unroll
+        for (int k = 0; k < 4; k++) a.q[k] = q[k] / a.qnorm;
+    } else {
+        a.opacity = op;
+        a.qnorm = 1.0f;
+#pragma unroll
+        for (int k = 0; k < 3; k++) a.s[k] = s[k];
+#pragma unroll
+        for (int k = 0; k < 4; k++) a.q[k] = q[k];
+    }
+    return a;
+}
+
 constexpr int COVER_MAX_WORDS = 4096;  // LDS bitmap of k_geom_fwd (16 KB)
 __host__ __device__ inline int cover_cw(int W) { return 1 + (((W + TILE - 1) / TILE) + 31) / 32; }
 inline bool cover_enabled(int P, int W, int H)
@@ -191,7 +218,8 @@ __global__ __launch_bounds__(256) void k_geom_fwd(int P, int W, int H, ViewTan v
         } else {
             const float s[3] = { scales[3 * li], scales[3 * li + 1], scales[3 * li + 2] };
             const float q[4] = { rots[4 * li], rots[4 * li + 1], rots[4 * li + 2], rots[4 * li + 3] };
-            computeCov3D(s, smod, q, cov3D);
+            const Activated ac = activate(flags & SKS_RAW_PARAMS, 0.0f, s, q);
+            computeCov3D(ac.s, smod, ac.q, cov3D);
         }
         Cov2D c;
         cov2d(p_orig, focal_x, focal_y, tan_fovx, tan_fovy, cov3D, V, c);
@@ -217,7 +245,9 @@ __global__ __launch_bounds__(256) void k_geom_fwd(int P, int W, int H, ViewTan v
             if ((xmax - xmin) * (ymax - ymin) != 0) {
                 radius_out = (int)my_radius;
                 rect = make_uint4(xmin, ymin, xmax, ymax);
-                co = make_float4(conic[0], conic[1], conic[2], opac[li] * h_convolution_scaling);
+                const float op_raw = opac[li];
+                const float op = (flags & SKS_RAW_PARAMS) ? 1.0f / (1.0f + expf_fixed(-op_raw)) : op_raw;
+                co = make_float4(conic[0], conic[1], conic[2], op * h_convolution_scaling);
                 xyd = make_float4(px, py, p_view[2], 1 / p_view[2]);
             }
         }
@@ -1246,6 +1276,7 @@ struct GeomBwdArgs {
     int nsplit;
     const double* gt_totals;   // fused-loss mode: per-view {sum gt^2, count gt > 0} over the whole image, else nullptr
     double* loss_sums;         // fused-loss mode: out, per-view {S, N} of the masked-L2 loss
+    float* packed;             // optional (V,P,11) raw-parameter gradients (scaled by 1/N_v when loss_sums is set)
     float* dmeans3D;
     float* dmeans2D;
     float* dopacity;
@@ -1312,9 +1343,11 @@ __global__ __launch_bounds__(256) void k_geom_bwd(GeomBwdArgs a, ViewTan vt)
             a.loss_sums[2 * v] = a.gt_totals[2 * v] + ((s_l[0][0] + s_l[0][1]) + (s_l[0][2] + s_l[0][3]));
             a.loss_sums[2 * v + 1] = a.gt_totals[2 * v + 1] + ((s_l[1][0] + s_l[1][1]) + (s_l[1][2] + s_l[1][3]));
         }
+        __syncthreads();   // the packed-gradient epilogue of every thread reads N_v back (same block, same L1)
     }
     if (idx >= a.P) return;
     float dmean[3] = { 0, 0, 0 }, dcov[6] = { 0, 0, 0, 0, 0, 0 }, dscale[3] = { 0, 0, 0 }, dq[4] = { 0, 0, 0, 0 };
+    float sc[3] = { 0, 0, 0 }, q[4] = { 1, 0, 0, 0 }, qnorm = 1.0f;   // activated scale / rotation (raw mode: see activate())
     float dop = g[5];
     const float dm2x = g[0], dm2y = g[1];
 
@@ -1326,13 +1359,16 @@ __global__ __launch_bounds__(256) void k_geom_bwd(GeomBwdArgs a, ViewTan vt)
         const float h_x = a.W / (2.0f * tan_fovx);
         const float mean[3] = { a.means[3 * idx], a.means[3 * idx + 1], a.means[3 * idx + 2] };
         float cov3D[6];
-        float sc[3] = { 0, 0, 0 }, q[4] = { 1, 0, 0, 0 };
         if (a.cov3Dp) {
 #pragma unroll
             for (int i = 0; i < 6; i++) cov3D[i] = a.cov3Dp[6 * idx + i];
         } else {
-            sc[0] = a.scales[3 * idx]; sc[1] = a.scales[3 * idx + 1]; sc[2] = a.scales[3 * idx + 2];
-            q[0] = a.rots[4 * idx]; q[1] = a.rots[4 * idx + 1]; q[2] = a.rots[4 * idx + 2]; q[3] = a.rots[4 * idx + 3];
+            const float rs[3] = { a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2] };
+            const float rq[4] = { a.rots[4 * idx], a.rots[4 * idx + 1], a.rots[4 * idx + 2], a.rots[4 * idx + 3] };
+            const Activated ac = activate(a.flags & SKS_RAW_PARAMS, 0.0f, rs, rq);
+            sc[0] = ac.s[0]; sc[1] = ac.s[1]; sc[2] = ac.s[2];
+            q[0] = ac.q[0]; q[1] = ac.q[1]; q[2] = ac.q[2]; q[3] = ac.q[3];
+            qnorm = ac.qnorm;
             computeCov3D(sc, a.smod, q, cov3D);
         }
         const float dL_dconic[3] = { g[2], g[3], g[4] };
@@ -1355,7 +1391,8 @@ __global__ __launch_bounds__(256) void k_geom_bwd(GeomBwdArgs a, ViewTan vt)
             const float det_cov_plus_h_cov = c_xx * c_yy - c_xy * c_xy;
             const float h_convolution_scaling = sqrtf(fmaxf(0.000025f, det_cov / det_cov_plus_h_cov));
             const float dL_dopacity_v = dop;
-            const float d_h_convolution_scaling = dL_dopacity_v * a.opac[idx];
+            const float op_raw = a.opac[idx];
+            const float d_h_convolution_scaling = dL_dopacity_v * ((a.flags & SKS_RAW_PARAMS) ? 1.0f / (1.0f + expf_fixed(-op_raw)) : op_raw);
             dop = dL_dopacity_v * h_convolution_scaling;
             d_inside_root = (det_cov / det_cov_plus_h_cov) <= 0.000025f ? 0.f : d_h_convolution_scaling / (2 * h_convolution_scaling);
         } else {
@@ -1461,6 +1498,31 @@ __global__ __launch_bounds__(256) void k_geom_bwd(GeomBwdArgs a, ViewTan vt)
     }
     if (a.dscales) { a.dscales[3 * o] = dscale[0]; a.dscales[3 * o + 1] = dscale[1]; a.dscales[3 * o + 2] = dscale[2]; }
     if (a.drots) { a.drots[4 * o] = dq[0]; a.drots[4 * o + 1] = dq[1]; a.drots[4 * o + 2] = dq[2]; a.drots[4 * o + 3] = dq[3]; }
+    if (a.packed) {
+        // raw-parameter gradients [xyz 3 | _scaling 3 | _rotation 4 | _opacity 1] through the activation Jacobians
+        // (what autograd does through exp / normalize / sigmoid), times 1/N_v of the fused masked-L2 loss
+        float scl = 1.0f;
+        if (a.loss_sums) {
+            const double n = a.loss_sums[2 * v + 1];   // written by thread 0 of this block above
+            scl = (float)(1.0 / (n < 1.0 ? 1.0 : n));
+        }
+        float* pk = a.packed + o * 11;
+        const bool raw = a.flags & SKS_RAW_PARAMS;
+        pk[0] = dmean[0] * scl; pk[1] = dmean[1] * scl; pk[2] = dmean[2] * scl;
+#pragma unroll
+        for (int k = 0; k < 3; k++) pk[3 + k] = dscale[k] * (raw ? sc[k] : 1.0f) * scl;
+        float dot = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; k++) dot += q[k] * dq[k];
+#pragma unroll
+        for (int k = 0; k < 4; k++) pk[6 + k] = (raw ? (dq[k] - q[k] * dot) / qnorm : dq[k]) * scl;
+        float oj = 1.0f;
+        if (raw) {
+            const float so = 1.0f / (1.0f + expf_fixed(-a.opac[idx]));
+            oj = so * (1.0f - so);
+        }
+        pk[10] = dop * oj * scl;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1898,7 +1960,7 @@ int sks_backward(int V, int P, int C, int W, int H, const float* viewmatrix, con
         STAGE_CHECK("render-backward(binned)");
     }
     GeomBwdArgs ga{ P, C, W, H, flags, viewmatrix, projmatrix, means3D, opacities, scales, rotations, cov3D_precomp,
-                    scale_modifier, radii, (const float*)accum, small ? BWD_SPLITS : 1, nullptr, nullptr, dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dscales,
+                    scale_modifier, radii, (const float*)accum, small ? BWD_SPLITS : 1, nullptr, nullptr, nullptr, dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dscales,
                     dL_drotations, dL_dcov3D, dL_dfeatures };
     hipLaunchKernelGGL(k_geom_bwd, dim3((P + 255) / 256, V), dim3(256), 0, st, ga, vt);
     STAGE_CHECK("geometry-backward");
@@ -1924,7 +1986,7 @@ int sks_backward_fused_loss(int V, int P, int C, int W, int H, const float* view
                             const void* geom, const float* gt, const float* tile_S, const float* tile_N,
                             const double* gt_totals, void* accum, float* dL_dmeans3D, float* dL_dmeans2D,
                             float* dL_dopacity, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
-                            double* loss_sums, void* stream)
+                            double* loss_sums, float* packed_raw_grads, void* stream)
 {
     if (int rc = check_common(V, P, C, W, H)) return rc;
     if (P < 1 || P > 64) return fail(-1, "fused-loss backward needs 1 <= P <= 64 (got %d)", P);
@@ -1949,7 +2011,7 @@ int sks_backward_fused_loss(int V, int P, int C, int W, int H, const float* view
     }
     STAGE_CHECK("fused loss + render-backward");
     GeomBwdArgs ga{ P, C, W, H, flags, viewmatrix, projmatrix, means3D, opacities, scales, rotations, cov3D_precomp,
-                    scale_modifier, radii, (const float*)accum, BWD_SPLITS, gt_totals, loss_sums, dL_dmeans3D, dL_dmeans2D,
+                    scale_modifier, radii, (const float*)accum, BWD_SPLITS, gt_totals, loss_sums, packed_raw_grads, dL_dmeans3D, dL_dmeans2D,
                     dL_dopacity, dL_dscales, dL_drotations, dL_dcov3D, nullptr };
     hipLaunchKernelGGL(k_geom_bwd, dim3((P + 255) / 256, V), dim3(256), 0, st, ga, vt);
     STAGE_CHECK("geometry-backward");

@@ -188,7 +188,8 @@ class MultiViewLoop:
             if self.local_ids:
                 means = gm._xyz.detach()
                 feats = gm.get_features.reshape(P, -1)
-                opac, scales, quats = gm.get_opacity.detach(), gm.get_scaling.detach(), gm.get_rotation.detach()
+                if not self.sparse:
+                    opac, scales, quats = gm.get_opacity.detach(), gm.get_scaling.detach(), gm.get_rotation.detach()
                 Vl = len(self.local_ids)
                 packed = torch.empty((self.vmax if self.world > 1 else Vl, P, 11), device=dev)
                 if self.world > 1 and Vl < self.vmax:
@@ -197,9 +198,19 @@ class MultiViewLoop:
                 all_sums = None if single else torch.empty((Vl, 2), dtype=torch.float64, device=dev)
                 for slots, vb, gt, stats in self.size_groups:
                     if self.sparse:
-                        st = R.geometry_views(vb, means, feats.shape[1], opac, scales, quats, None,
-                                              antialiasing=self.antialiasing)
-                        g, sums = R.backward_fused_loss(st, stats, means, feats, opac, scales, quats, None, bg=self.bg)
+                        # leaf parameters straight into the kernels: activations, their Jacobians and the 1/N scale
+                        # all run inside sks_geometry / sks_backward_fused_loss (SKS_RAW_PARAMS)
+                        st = R.geometry_views(vb, means, feats.shape[1], gm._opacity, gm._scaling, gm._rotation, None,
+                                              antialiasing=self.antialiasing, raw_params=True)
+                        pk = packed if single else torch.empty((len(slots), P, 11), device=dev)
+                        g, sums = R.backward_fused_loss(st, stats, means, feats, gm._opacity, gm._scaling, gm._rotation,
+                                                        None, bg=self.bg, packed_out=pk)
+                        if single:
+                            all_sums = sums
+                        else:
+                            packed[slots] = pk
+                            all_sums[slots] = sums
+                        continue
                     else:
                         color, inv, radii, st = R.forward_views(vb, means, feats, opac, scales, quats, None,
                                                                 antialiasing=self.antialiasing, clamp01=True)

@@ -381,8 +381,9 @@ def gt_tile_stats(gt):
 
 
 def geometry_views(views: ViewBatch, means3D, C, opacities, scales, rotations, cov3D_precomp, scale_modifier=1.0,
-                   antialiasing=False):
-    """Geometry stage only (no image): returns a ForwardState usable by backward_fused_loss."""
+                   antialiasing=False, raw_params=False):
+    """Geometry stage only (no image): returns a ForwardState usable by backward_fused_loss.  raw_params: the three
+    tensors are the leaf parameters (_opacity, _scaling, _rotation); activations run in-kernel (SKS_RAW_PARAMS)."""
     lib = _lib.load()
     means3D = _f32c(means3D, "means3D")
     dev = means3D.device
@@ -390,7 +391,7 @@ def geometry_views(views: ViewBatch, means3D, C, opacities, scales, rotations, c
     opacities = _f32c(opacities, "opacities")
     scales, rotations, cov3D_precomp = _f32c(scales, "scales"), _f32c(rotations, "rotations"), _f32c(cov3D_precomp, "cov3D_precomp")
     V, W, H = views.V, views.W, views.H
-    flags = _lib.SKS_ANTIALIASING if antialiasing else 0
+    flags = (_lib.SKS_ANTIALIASING if antialiasing else 0) | (_lib.SKS_RAW_PARAMS if raw_params else 0)
     gbytes, _, _ = _lib.scratch_bytes(V, max(P, 1), C, W, H, 0)
     radii = torch.empty((V, P), dtype=torch.int32, device=dev)
     geom = torch.empty(gbytes, dtype=torch.uint8, device=dev)
@@ -407,7 +408,7 @@ def geometry_views(views: ViewBatch, means3D, C, opacities, scales, rotations, c
 
 
 def backward_fused_loss(st: ForwardState, stats: GtStats, means3D, features, opacities, scales, rotations, cov3D_precomp,
-                        bg=None):
+                        bg=None, packed_out=None):
     """Render + clamp + masked-L2 + backward on the covered tiles only.  Returns (grads dict of (V,P,..) UNSCALED
     gradients, loss_sums (V,2) f64 = per-view {S, N}); the true gradient is grads / N_v, loss_v = S_v / N_v."""
     lib = _lib.load()
@@ -439,6 +440,7 @@ def backward_fused_loss(st: ForwardState, stats: GtStats, means3D, features, opa
                                          stats.gt.data_ptr(), stats.tile_S.data_ptr(), stats.tile_N.data_ptr(),
                                          stats.totals.data_ptr(), accum.data_ptr(), _lib.ptr(out["means3D"]),
                                          _lib.ptr(out["means2D"]), _lib.ptr(out["opacities"]), _lib.ptr(out["scales"]),
-                                         _lib.ptr(out["rotations"]), _lib.ptr(out["cov3D"]), sums.data_ptr(), stream)
+                                         _lib.ptr(out["rotations"]), _lib.ptr(out["cov3D"]), sums.data_ptr(),
+                                         _lib.ptr(packed_out), stream)
     _lib.check(rc, "sks_backward_fused_loss")
     return out, sums
