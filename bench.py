@@ -193,6 +193,19 @@ def main():
                 # V views rendered + fused masked-L2 + backward + device-side Adam step (train.py:130-222)
                 extras["grad_step_ms" + tag] = 1e3 * tl / nl
                 extras["loop_views_per_s" + tag] = V * nl / tl
+            # one whole scene like configs/h36m.yaml (500 iterations), accumulation groups captured 25 per hipGraph
+            loop = MultiViewLoop(gm, scene.cameras, hm, dataset=wl["dataset"], accumulation_steps=V, use_graph=True)
+            loop.run(500)                      # captures
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            for _ in range(3):
+                loop.iteration = 0             # parameters keep evolving; the work per iteration does not change
+                loop.run(500)
+            torch.cuda.synchronize()
+            ts = (time.perf_counter() - ts) / 3
+            extras["scene_500it_ms_hipgraph"] = 1e3 * ts
+            extras["loop_views_per_s_scene_hipgraph"] = 500 / ts
+            extras["grad_step_ms_scene_hipgraph"] = 1e3 * ts / (500 / V)
         except Exception as e:
             extras["loop_error"] = repr(e)[:200]
 

@@ -45,13 +45,26 @@ def main():
     loop.run(args.iters)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # a second scene reuses the captured graphs (what a dataset-scale run sees per frame)
+    gm2 = GaussianModel().create_from_points(init, sc.spatial_lr_scale, sc.n_joints, scene_type=args.dataset, device=dev)
+    with torch.no_grad():
+        for a, b in zip((gm._xyz, gm._scaling, gm._rotation, gm._opacity), (gm2._xyz, gm2._scaling, gm2._rotation, gm2._opacity)):
+            keep = a.detach().clone(); a.copy_(b); b.copy_(keep)     # gm <- fresh parameters, gm2 <- result
+        loop.exp_avg.zero_(); loop.exp_avg_sq.zero_(); loop.counters.zero_(); loop.accumulated_grads.zero_()
+    loop.iteration = 0
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    loop.run(args.iters)
+    torch.cuda.synchronize()
+    dt2 = time.perf_counter() - t1
+    assert torch.allclose(gm._xyz, gm2._xyz, atol=1e-3), "replayed scene differs from the first run"
     pred = gm._xyz.detach().cpu().numpy()
     path = os.path.join(args.out, "point_cloud", f"iteration_{args.iters}", "synthetic_0.ply")
     io.save_ply(path, gm)
     assert np.allclose(io.read_ply_xyz(path), pred, atol=1e-4)
     S, N = loop.last_losses
-    print(f"{args.dataset} V={args.views} {sc.W}x{sc.H}: {args.iters} iterations in {dt * 1e3:.1f} ms "
-          f"({args.iters / dt:.0f} it/s); MPJPE {e0:.2f} mm -> {io.mpjpe(pred, sc.pose_3d_gt):.2f} mm "
+    print(f"{args.dataset} V={args.views} {sc.W}x{sc.H}: {args.iters} iterations in {dt * 1e3:.1f} ms first scene, "
+          f"{dt2 * 1e3:.1f} ms with graphs cached ({args.iters / dt2:.0f} it/s); MPJPE {e0:.2f} mm -> {io.mpjpe(pred, sc.pose_3d_gt):.2f} mm "
           f"(root-relative {io.mpjpe_root_relative(pred, sc.pose_3d_gt):.2f} mm); last losses {(S / N).tolist()}")
 
 

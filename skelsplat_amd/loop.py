@@ -313,7 +313,29 @@ class MultiViewLoop:
         self.last_losses = losses
         return it1
 
-    def run(self, iterations=500):
+    def run(self, iterations=500, groups_per_graph=25):
+        """Runs the loop up to `iterations`.  With use_graph, `groups_per_graph` consecutive accumulation groups are
+        captured into ONE hipGraph (the step has no host state: counters, LR schedule and Adam live on the device), so
+        a 500-iteration scene is a handful of graph launches."""
+        if self.use_graph and self.acc_steps % self.V == 0 and self.iteration % self.acc_steps == 0:
+            mask = (1 << self.V) - 1
+            key = (mask, (self.acc_steps - 1) % self.V, self.acc_steps)
+            remaining = (iterations - self.iteration) // self.acc_steps
+            G = min(int(groups_per_graph), remaining)
+            if G > 1:
+                if getattr(self, "_multi", None) is None or self._multi[0] != (key, G):
+                    self._device_group(*key)            # one eager group: warms allocations, counts as a real step
+                    self.iteration += self.acc_steps
+                    remaining -= 1
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        for _ in range(G):
+                            self._device_group(*key)
+                    self._multi = ((key, G), graph)
+                while remaining >= G:
+                    self._multi[1].replay()
+                    self.iteration += G * self.acc_steps
+                    remaining -= G
         while self.iteration < iterations:
             self.step_group()
         return self.gm._xyz.detach()
