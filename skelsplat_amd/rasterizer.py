@@ -105,14 +105,24 @@ class ForwardState:
 
 def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotations, cov3D_precomp,
                   scale_modifier=1.0, antialiasing=False, clamp01=False, debug=False, force_binned=False,
-                  bin_capacity=None, want_aux=False, tune_flags=0):
+                  bin_capacity=None, want_aux=False, tune_flags=0, check_capacity=True):
     """Raw batched forward.  Returns (color (V,C,H,W), invdepth (V,1,H,W), radii (V,P) int32, state[, final_T, n_contrib])."""
     lib = _lib.load()
-    means3D = _f32c(means3D, "means3D")
-    if means3D is None:
-        raise RuntimeError("means3D must have dimensions (num_points, 3)")
-    if means3D.dim() != 2 or means3D.shape[1] != 3:
+    if means3D is None or means3D.dim() != 2 or means3D.shape[1] != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")  # DGR/rasterize_points.cu:58-60
+    _need_gpu(means3D, "means3D")
+    if means3D.shape[0] == 0:   # DGR/rasterize_points.cu:88: nothing is rasterised, the outputs stay zero
+        dev, V, W, H = means3D.device, views.V, views.W, views.H
+        C = int(features.shape[-1])
+        st = ForwardState()
+        st.views, st.P, st.C, st.flags, st.scale_modifier = views, 0, C, 0, float(scale_modifier)
+        st.geom = st.binning = st.num_rendered_dev = None
+        st.bin_capacity, st.radii = 0, torch.zeros((V, 0), dtype=torch.int32, device=dev)
+        out = (torch.zeros((V, C, H, W), device=dev), torch.zeros((V, 1, H, W), device=dev), st.radii, st)
+        if want_aux:
+            out += (torch.ones((V, H, W), device=dev), torch.zeros((V, H, W), dtype=torch.int32, device=dev))
+        return out
+    means3D = _f32c(means3D, "means3D")
     dev = means3D.device
     P = means3D.shape[0]
     features = _f32c(features, "features")
@@ -144,6 +154,14 @@ def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotati
                              color.data_ptr(), invdepth.data_ptr(), _lib.ptr(radii), geom.data_ptr(),
                              _lib.ptr(binning), cap, _lib.ptr(nrend), _lib.ptr(final_T), _lib.ptr(n_contrib), stream)
     _lib.check(rc, "sks_forward")
+    if binned and check_capacity:
+        # like the reference (rasterizer_impl.cu:283-288) the binned path needs the pair count on the host to size its
+        # buffers: one D2H read; grow and redo when the arena was too small (entries beyond it were dropped)
+        need = int(nrend[:V].max().item())
+        if need > cap:
+            return forward_views(views, means3D, features, opacities, scales, rotations, cov3D_precomp, scale_modifier,
+                                 antialiasing, clamp01, debug, force_binned, int(need * 1.25) + 1024, want_aux, tune_flags,
+                                 check_capacity)
     st = ForwardState()
     st.views, st.P, st.C, st.flags, st.scale_modifier = views, P, C, flags, float(scale_modifier)
     st.geom, st.binning, st.bin_capacity, st.radii, st.num_rendered_dev = geom, binning, cap, radii, nrend
@@ -156,6 +174,11 @@ def backward_views(st: ForwardState, means3D, features, opacities, scales, rotat
                    dL_dinvdepth=None, bg=None, want_dfeatures=False, tune_flags=0):
     """Raw batched backward: per-view gradients, dict of (V,P,...) tensors."""
     lib = _lib.load()
+    if st.P == 0:
+        dev, V, C = means3D.device, st.views.V, st.C
+        z = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
+        return dict(means3D=z(V, 0, 3), means2D=z(V, 0, 3), opacities=z(V, 0, 1), cov3D=z(V, 0, 6), scales=z(V, 0, 3),
+                    rotations=z(V, 0, 4), features=z(V, 0, C) if want_dfeatures else None)
     means3D = _f32c(means3D, "means3D")
     dev = means3D.device
     V, P, C = st.views.V, st.P, st.C

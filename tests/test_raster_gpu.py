@@ -10,6 +10,7 @@ import torch
 
 from tests import util
 from skelsplat_amd import rasterizer as R
+from oracle import oracle as orc
 
 pytestmark = pytest.mark.gpu
 
@@ -262,3 +263,62 @@ def test_stress_config_binned_path(device):
     g2 = R.backward_views(st, *args, 3.0 * dL)
     assert torch.isfinite(g1["means3D"]).all()
     util.assert_close("linearity", g2["means3D"].cpu(), 3.0 * g1["means3D"].cpu(), rtol=1e-3, atol_scale=1e-4)
+
+
+def test_binned_capacity_grows_on_overflow(device):
+    c = util.make_case(seed=0, W=160, H=128, scale_log=4.0, n_views=1)
+    dev = device
+    views = R.ViewBatch.from_cameras([cam.to(dev) for cam in c.cams])
+    args = (t(c.means, dev), t(c.feat, dev), t(c.opac, dev), t(c.scales, dev), t(c.quats, dev), None)
+    o = util.oracle_forward(c, 0)
+    assert o["R"] > 16
+    color, inv, radii, st = R.forward_views(views, *args, force_binned=True, bin_capacity=16)   # far too small
+    assert st.bin_capacity >= o["R"]
+    assert np.array_equal(color[0].cpu().numpy(), o["color"])
+
+
+def test_edge_cases(device):
+    dev = device
+    c = util.make_case(seed=2, W=100, H=60, scale_log=3.5, n_views=2)
+    views = R.ViewBatch.from_cameras([cam.to(dev) for cam in c.cams])
+    args = [t(c.means, dev), t(c.feat, dev), t(c.opac, dev), t(c.scales, dev), t(c.quats, dev), None]
+    # everything behind the cameras: zero images, zero radii, zero gradients, on both paths
+    far = list(args)
+    far[0] = torch.tensor([[0.0, 0.0, 1e7]], device=dev).repeat(c.P, 1)
+    for binned in (False, True):
+        color, inv, radii, st = R.forward_views(views, *far, force_binned=binned)
+        assert not color.any() and not inv.any() and not radii.any()
+        g = R.backward_views(st, *far, t(c.dL_color, dev), t(c.dL_inv, dev), want_dfeatures=True)
+        assert all(not v.any() for v in g.values() if v is not None)
+    # one huge splat covering the whole image (rect = every tile, thousands of pixels per backward slot)
+    big = list(args)
+    big[3] = args[3].clone()
+    big[3][0] = 3000.0
+    color, inv, radii, st = R.forward_views(views, *big)
+    o = orc_forward_custom(c, 0, scales=big[3].cpu().numpy())
+    assert np.array_equal(color[0].cpu().numpy(), o["color"]) and int(radii[0, 0]) == o["radii"][0] > 100
+    g = R.backward_views(st, *big, t(c.dL_color, dev), t(c.dL_inv, dev))
+    b = orc_backward_custom(c, 0, o, scales=big[3].cpu().numpy())
+    util.assert_close("huge splat dL_dmeans3D", g["means3D"][0].cpu(), b["dL_dmeans3D"], rtol=2e-3, atol_scale=1e-4)
+    util.assert_close("huge splat dL_dscales", g["scales"][0].cpu(), b["dL_dscales"], rtol=2e-3, atol_scale=1e-4)
+    # P == 0: nothing to do, outputs zero (rasterize_points.cu:88)
+    e = torch.empty((0, 3), device=dev)
+    color, inv, radii, st = R.forward_views(views, e, torch.empty((0, 17), device=dev), torch.empty((0, 1), device=dev),
+                                            e, torch.empty((0, 4), device=dev), None)
+    assert color.shape == (2, 17, 60, 100) and not color.any() and radii.shape == (2, 0)
+    # C = 3 (RGB-like) and C = 32 (the supported maximum); C = 33 is refused with a message
+    for C in (3, 32):
+        f = torch.rand((c.P, C), device=dev)
+        col, _, _, st = R.forward_views(views, args[0], f, *args[2:])
+        oo = orc.forward(c.means, f.cpu().numpy(), c.opac, c.scales, c.quats, None, c.ocams[1])
+        assert np.array_equal(col[1].cpu().numpy(), oo["color"])
+    with pytest.raises(RuntimeError, match="out of range"):
+        R.forward_views(views, args[0], torch.rand((c.P, 33), device=dev), *args[2:])
+
+
+def orc_forward_custom(c, v, scales):
+    return orc.forward(c.means, c.feat, c.opac, scales, c.quats, None, c.ocams[v])
+
+
+def orc_backward_custom(c, v, fwd, scales):
+    return orc.backward(fwd, c.means, c.feat, c.opac, scales, c.quats, None, c.ocams[v], c.dL_color[v], c.dL_inv[v])
