@@ -89,8 +89,12 @@ def main():
         raise SystemExit("bench.py needs a ROCm device (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("SKS_BENCH_FORCE_DIST") == "1"   # the env switch exercises RCCL at world 1
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
     assert world == args.gpus or world == 1, (world, args.gpus)
 
@@ -108,13 +112,13 @@ def main():
                   gm.get_scaling.detach().clone(), gm.get_rotation.detach().clone())
     means, feat, opac, scales, quats = params
     dL = torch.randn((V, C, H, W), device=dev, generator=torch.Generator(device=dev).manual_seed(rank))
-    gathered = torch.empty((world * V, P, 3), device=dev) if world > 1 else None
+    gathered = torch.empty((world * V, P, 3), device=dev) if use_dist else None
 
     def step():
         color, inv, radii, st = R.forward_views(views, means, feat, opac, scales, quats, None)
         g = R.backward_views(st, means, feat, opac, scales, quats, None, dL)
         gx = g["means3D"]
-        if world > 1:  # view-sharded loop: every rank needs all per-view joint gradients (train.py:175,215-217)
+        if use_dist:  # view-sharded loop: every rank needs all per-view joint gradients (train.py:175,215-217)
             dist.all_gather_into_tensor(gathered, gx)
             gx = gathered
         return gx.mean(dim=0)
@@ -122,7 +126,7 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     prof = not args.no_prof
@@ -133,7 +137,7 @@ def main():
     for _ in range(args.steps):
         out = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -142,7 +146,7 @@ def main():
         fwd_ms, fwd_n = _lib.prof_read(0)
         bwd_ms, bwd_n = _lib.prof_read(1)
         _lib.prof_enable(False)
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -150,7 +154,7 @@ def main():
 
     # ---- extras (not part of `value`): hipGraph replay of the same step, and the full loop step ----------------
     extras = {}
-    if world == 1:
+    if world == 1 and not use_dist:
         try:
             graph = torch.cuda.CUDAGraph()
             side = torch.cuda.Stream()
@@ -240,7 +244,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(ref_scene, params, n_views=2)
         print(json.dumps(res))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

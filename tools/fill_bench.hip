@@ -24,6 +24,28 @@ __global__ __launch_bounds__(256) void fill_chunk(v4f* p, size_t n4, int chunk4)
     size_t e = b + chunk4 < n4 ? b + chunk4 : n4;
     for (size_t i = b + threadIdx.x; i < e; i += 256) ST(p[i], z);
 }
+// V2b: like fill_chunk, plus what the rasterizer's fill role carries: a dependent uniform load deciding the path,
+// 4 KB of static LDS, `nskip` early-exit blocks interleaved every 8th id
+__global__ __launch_bounds__(256) void fill_chunk_like(v4f* p, size_t n4, int chunk4, const unsigned* cover, int nskip)
+{
+    __shared__ unsigned s_cw[1024];
+    const int bid = blockIdx.x;
+    const bool slot = (bid % 8 == 0) && (bid / 8 < nskip);
+    if (slot) return;
+    const int f = bid - min(bid / 8 + 1, nskip);
+    const unsigned any = cover[f & 255];
+    if (any) {
+        if (threadIdx.x < 64) s_cw[threadIdx.x] = cover[threadIdx.x];
+        __syncthreads();
+    }
+    v4f z = { 0, 0, 0, 0 };
+    size_t b = (size_t)f * chunk4;
+    size_t e = b + chunk4 < n4 ? b + chunk4 : n4;
+    for (size_t i = b + threadIdx.x; i < e; i += 256) {
+        if (any && ((s_cw[(i >> 2) & 63] >> (i & 31)) & 1u)) continue;
+        ST(p[i], z);
+    }
+}
 // V3: WG (chunk, band) writes `passes` x 4 KB in each of `planes` planes (plane stride = plane4 float4)
 __global__ __launch_bounds__(256) void fill_planes(v4f* p, size_t plane4, int planes, int band4, int passes)
 {
@@ -85,6 +107,14 @@ int main()
         int chunk4 = kb * 1024 / 16; int G = (int)((n4 + chunk4 - 1) / chunk4);
         char nm[64]; snprintf(nm, 64, "chunk %d KB/WG (G=%d)", kb, G);
         timeit(nm, [&] { hipLaunchKernelGGL(fill_chunk, dim3(G), dim3(256), 0, 0, d, n4, chunk4); });
+    }
+    unsigned* dcover;
+    CK(hipMalloc(&dcover, 4096));
+    CK(hipMemset(dcover, 0, 4096));
+    for (int nskip : { 0, 1088 }) {
+        int chunk4 = 16 * 1024 / 16; int G = (int)((n4 + chunk4 - 1) / chunk4) + nskip;
+        char nm[64]; snprintf(nm, 64, "chunk16K + cover load + LDS, %d skip blocks", nskip);
+        timeit(nm, [&] { hipLaunchKernelGGL(fill_chunk_like, dim3(G), dim3(256), 0, 0, d, n4, chunk4, dcover, nskip); });
     }
     for (int G : { 1024, 2048, 4096 }) {
         char nm[64]; snprintf(nm, 64, "persistent 4KB tiles G=%d", G);
