@@ -44,6 +44,7 @@ extern "C" {
 #define SKS_NO_NT_STORES 16u  /* tuning: plain instead of non-temporal stores for the dense forward planes
                                  (non-temporal is the default: the planes are written once and read by another kernel) */
 
+/* tuning: bits 8..15 of `flags` = 4 KB passes per fill block of the fused forward (0 = automatic) */
 #define SKS_RAW_PARAMS   32u   /* opacities / scales / rotations are the LEAF parameters (_opacity logits, _scaling
                                  log-scales, raw _rotation); sigmoid / exp / normalize (scene/gaussian_model.py:39-47)
                                  run inside the kernels (sks_geometry, sks_forward, sks_backward*) */

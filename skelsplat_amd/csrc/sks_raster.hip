@@ -357,9 +357,6 @@ struct FwdArgs {
 // PPT = 4 needs W % 4 == 0; PPT = 1 handles any W with 4-byte stores.
 // ------------------------------------------------------------------------------------------------------------
 constexpr int T_SLOTS = 16;     // composite blocks per (view, Gaussian)
-constexpr int COMP_STRIDE = 8;  // every 8th block id is a composite block until they run out
-constexpr int FILL_SPLIT = 4;   // fill blocks per (plane, band): ~16 KB each at W = 1000 (finer blocks balance better)
-constexpr int MAXCOL = 4096;    // tile columns (W <= 65536)
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
@@ -394,26 +391,25 @@ struct DynList {
 };
 
 template <int CG, int PPT, bool NT>
-__global__ __launch_bounds__(256) void k_render_fwd_sparse(FwdArgs a, int ncomp, int gy)
+__global__ __launch_bounds__(256) void k_render_fwd_sparse(FwdArgs a, int ncomp, int gy, int fsplit, int pb,
+                                                           const uint32_t* __restrict__ cover)
 {
     extern __shared__ __attribute__((aligned(16))) char s_dyn[];
-    __shared__ __attribute__((aligned(16))) unsigned char s_cover[MAXCOL];  // fill role: cover words of the band
     __shared__ int s_n, s_min;
     const int tid = threadIdx.x;
     const int P = a.P, C = a.C, W = a.W, H = a.H;
     const size_t HW = (size_t)H * W;
 
-    // composite blocks are interleaved with the fill blocks (one every COMP_STRIDE block ids) so that their latency
-    // (list building, barriers) overlaps the streaming stores instead of crowding the first dispatch wave
-    const int bid = blockIdx.x;
-    const int total = gridDim.x;
-    const int kint = min(ncomp, (total + COMP_STRIDE - 1) / COMP_STRIDE);  // composite blocks that get an interleaved id
-    const bool slot_id = (bid % COMP_STRIDE == 0) && (bid / COMP_STRIDE < kint);
-    const int rest = bid - min(bid / COMP_STRIDE + 1, kint);                // index among the non-interleaved ids
-    const bool comp_role = slot_id || rest < ncomp - kint;                  // leftovers (tiny images) go first
+    // grid (fsplit + xc, bands, (C+1) * V): x < fsplit are the fill passes of one (band, plane, view) row, the xc extra
+    // blocks per row carry the composite role (spread through the dispatch order so that their latency -- list
+    // building, barriers -- overlaps the streaming stores).  No integer division on the fill path except z / (C+1).
+    const int xq = blockIdx.x, band_id = blockIdx.y, zid = blockIdx.z;
+    const int xc = gridDim.x - fsplit;
+    const bool comp_role = xq >= fsplit;
     if (comp_role) {
         // ---------------- composite role ----------------
-        const int cb = slot_id ? bid / COMP_STRIDE : kint + rest;
+        const int cb = (zid * gy + band_id) * xc + (xq - fsplit);
+        if (cb >= ncomp) return;
         const int slot = cb % T_SLOTS;
         const int g = (cb / T_SLOTS) % P;
         const int v = cb / (T_SLOTS * P);
@@ -498,74 +494,62 @@ __global__ __launch_bounds__(256) void k_render_fwd_sparse(FwdArgs a, int ncomp,
         return;
     }
     // ---------------- fill role ----------------
-    const int f = rest - (ncomp - kint);
-    // block order = memory order (chunk, band, plane, view): concurrently running blocks write one contiguous window
-    const int q = f % FILL_SPLIT;
-    const int band = (f / FILL_SPLIT) % gy;
-    const int plane = (f / (FILL_SPLIT * gy)) % (C + 1);
-    const int v = f / (FILL_SPLIT * gy * (C + 1));
+    // One block = ONE pass: 256 threads x 16 B = 4 KB of one plane.  On MI355X a dispatch of many 4 KB blocks is the
+    // fastest fill shape measured (tools/fill_bench.hip: 44-47 us for 288 MB vs 48-55 us with 16 KB per block), but only
+    // if nothing VECTOR-memory sits in front of the store: a dependent global_load queues behind the chip-wide flood of
+    // stores (measured: 2.4 TB/s).  The band's cover words written by k_geom_fwd are therefore read through the SCALAR
+    // cache (s_load: `cover` is a const __restrict__ kernel argument and the address is made wave-uniform).
+    // block order = memory order (pass, band, plane, view): concurrently running blocks write one contiguous window
+    const int q = xq, band = band_id;
+    const int v = zid / (C + 1);
+    const int plane = zid - v * (C + 1);
     const bool is_inv = plane == C;
     const int cw = cover_cw(W);
-    uint32_t* s_cw = reinterpret_cast<uint32_t*>(s_cover);  // cw words: [0] any, then one bit per tile column
-    bool any = false;
-    if (a.g.cover) {  // precomputed by k_geom_fwd: one uniform load decides whether this block is a pure fill
-        const uint32_t* cwp = a.g.cover + ((size_t)v * gy + band) * cw;
-        any = cwp[0] != 0u;
-        if (any) {
-            if (tid < cw) s_cw[tid] = cwp[tid];
-            __syncthreads();
-        }
-    } else {  // not precomputed: every wavefront tests the rects itself (uniform result), then builds the bits in LDS
-        const uint4* grect = a.g.rect + (size_t)v * P;
-        for (int i0 = 0; i0 < P; i0 += 64) {
-            const int idx = i0 + (tid & 63);
-            bool hit = false;
-            if (idx < P) {
-                const uint4 r = grect[idx];
-                hit = (int)r.y <= band && band < (int)r.w;
-            }
-            any = any || __any(hit);
-        }
-        if (any) {
-            for (int t = tid; t < cw; t += 256) s_cw[t] = 0u;
-            __syncthreads();
-            if (tid < P) {
-                const uint4 r = grect[tid];
-                if ((int)r.y <= band && band < (int)r.w)
-                    for (unsigned t = r.x; t < r.z; t++) atomicOr(&s_cw[1 + (t >> 5)], 1u << (t & 31));
-            }
-            __syncthreads();
-        }
-    }
+    constexpr int PASS = 256 * PPT;
     const int rows = min(TILE, H - band * TILE);
     const int Nb = rows * W;  // this band of this plane: Nb contiguous floats
-    constexpr int PASS = 256 * PPT;
-    const int Nq = ((Nb + FILL_SPLIT * PASS - 1) / (FILL_SPLIT * PASS)) * PASS;  // floats per block, whole passes
-    const int beg = q * Nq, end = min(Nb, beg + Nq);
+    const int base0 = q * PASS * pb + tid * PPT;     // this block covers passes q*pb .. q*pb + pb - 1 of the band
     const size_t band0 = (size_t)band * TILE * W;
     float* out = (is_inv ? a.out_invdepth + (size_t)v * HW : a.out_color + ((size_t)v * C + plane) * HW) + band0;
     float* outT = (is_inv && a.final_T) ? a.final_T + (size_t)v * HW + band0 : nullptr;
     uint32_t* outN = (is_inv && a.n_contrib) ? a.n_contrib + (size_t)v * HW + band0 : nullptr;
-    if (!any) {
-#pragma unroll 4
-        for (int base = beg + tid * PPT; base < end; base += PASS) {
-            if (PPT == 4) store4<NT>(out + base, 0.0f, 0.0f, 0.0f, 0.0f);
-            else out[base] = 0.0f;
-        }
-    } else {
-        for (int base = beg + tid * PPT; base < end; base += PASS) {
-            const int tx = (base % W) >> 4;  // PPT == 4: W % 4 == 0, the 4 pixels share one tile column
-            if ((s_cw[1 + (tx >> 5)] >> (tx & 31)) & 1u) continue;  // a composite block writes this tile
-            if (PPT == 4) store4<NT>(out + base, 0.0f, 0.0f, 0.0f, 0.0f);
-            else out[base] = 0.0f;
-        }
+    bool any = false;
+    const uint32_t* __restrict__ cwp = cover;
+    if (cover) {
+        const int wo = __builtin_amdgcn_readfirstlane((v * gy + band) * cw);
+        cwp = cover + wo;
+        any = cwp[0] != 0u;   // wave-uniform scalar load; only bands some rect crosses look at the tile bits
     }
-    if (outT || outN) {  // debug planes of the reference's ImageState: T = 1, no contributor outside covered tiles
-        for (int base = beg + tid; base < end; base += 256) {
+    uint32_t w0 = 0u, w1 = 0u, w2 = 0u, w3 = 0u;
+    if (any && cw <= 5) {  // W <= 2048: the band's <= 4 bit words via the scalar cache, selected per lane below
+        w0 = cwp[1]; w1 = cw > 2 ? cwp[2] : 0u; w2 = cw > 3 ? cwp[3] : 0u; w3 = cw > 4 ? cwp[4] : 0u;
+    }
+    for (int k = 0; k < pb; k++) {
+        const int base = base0 + k * PASS;
+        if (base >= Nb) break;
+        bool skip0 = false;  // does a composite block write this thread's tile?
+        if (any) {
+            const int tx = (base % W) >> 4;  // PPT == 4: W % 4 == 0, the 4 pixels share one tile column
+            const int wi = tx >> 5;
+            const uint32_t word = cw <= 5 ? (wi == 0 ? w0 : wi == 1 ? w1 : wi == 2 ? w2 : w3) : cwp[1 + wi];
+            skip0 = (word >> (tx & 31)) & 1u;
+        } else if (!cover) {  // cover not precomputed (very large images): test the rects directly
+            const uint4* grect = a.g.rect + (size_t)v * P;
             const int tx = (base % W) >> 4;
-            if (any && ((s_cw[1 + (tx >> 5)] >> (tx & 31)) & 1u)) continue;
-            if (outT) outT[base] = 1.0f;
-            if (outN) outN[base] = 0u;
+            for (int i = 0; i < P; i++) {
+                const uint4 r = grect[i];
+                skip0 = skip0 || ((int)r.y <= band && band < (int)r.w && (int)r.x <= tx && tx < (int)r.z);
+            }
+        }
+        if (skip0) continue;
+        if (PPT == 4) store4<NT>(out + base, 0.0f, 0.0f, 0.0f, 0.0f);
+        else out[base] = 0.0f;
+        if (outT || outN) {  // debug planes of the reference's ImageState: T = 1, no contributor outside covered tiles
+#pragma unroll
+            for (int p = 0; p < PPT; p++) {
+                if (outT) outT[base + p] = 1.0f;
+                if (outN) outN[base + p] = 0u;
+            }
         }
     }
 }
@@ -1783,16 +1767,22 @@ template <int CG>
 void launch_fwd_small(const FwdArgs& a, int V, int gy, hipStream_t st)
 {
     const int ncomp = T_SLOTS * a.P * V;
-    const int nfill = FILL_SPLIT * (a.C + 1) * gy * V;
+    const int ppt = a.W % 4 == 0 ? 4 : 1;
+    const int passes = (TILE * a.W + 256 * ppt - 1) / (256 * ppt);
+    int pb = (int)((a.flags >> 8) & 0xff);                            // passes (4 KB each) per fill block; tuning knob
+    if (pb <= 0) pb = passes / 8 > 2 ? (passes + 4) / 8 : 2;          // ~8 fill blocks per (plane, band) row measured best
+    const int fsplit = (passes + pb - 1) / pb;                        // fill blocks per (plane, band) row
+    const int rows_zy = (a.C + 1) * V * gy;
+    const int xc = (ncomp + rows_zy - 1) / rows_zy;                   // composite blocks appended to every row
     const int cap = (a.P + 15) & ~15;
     const size_t lds = DynList<CG>::bytes(cap, CG);
-    dim3 grid(ncomp + nfill);
+    dim3 grid(fsplit + xc, gy, (a.C + 1) * V);
     const bool nt = !(a.flags & SKS_NO_NT_STORES);
     if (a.W % 4 == 0) {
-        if (nt) hipLaunchKernelGGL((k_render_fwd_sparse<CG, 4, true>), grid, dim3(256), lds, st, a, ncomp, gy);
-        else hipLaunchKernelGGL((k_render_fwd_sparse<CG, 4, false>), grid, dim3(256), lds, st, a, ncomp, gy);
+        if (nt) hipLaunchKernelGGL((k_render_fwd_sparse<CG, 4, true>), grid, dim3(256), lds, st, a, ncomp, gy, fsplit, pb, (const uint32_t*)a.g.cover);
+        else hipLaunchKernelGGL((k_render_fwd_sparse<CG, 4, false>), grid, dim3(256), lds, st, a, ncomp, gy, fsplit, pb, (const uint32_t*)a.g.cover);
     } else {
-        hipLaunchKernelGGL((k_render_fwd_sparse<CG, 1, false>), grid, dim3(256), lds, st, a, ncomp, gy);
+        hipLaunchKernelGGL((k_render_fwd_sparse<CG, 1, false>), grid, dim3(256), lds, st, a, ncomp, gy, fsplit, pb, (const uint32_t*)a.g.cover);
     }
 }
 

@@ -46,6 +46,26 @@ __global__ __launch_bounds__(256) void fill_chunk_like(v4f* p, size_t n4, int ch
         ST(p[i], z);
     }
 }
+// V2c: 4 KB chunks with per-block resources like the fused rasterizer kernel (dynamic LDS, many VGPRs)
+__global__ __launch_bounds__(256) void fill_chunk_dynlds(v4f* p, size_t n4, int chunk4, int heavy)
+{
+    extern __shared__ char dyn[];
+    float acc[40];
+    if (heavy) {  // never taken at run time (heavy == 0), but forces the register allocation
+#pragma unroll
+        for (int i = 0; i < 40; i++) acc[i] = p[i][0] * (float)i;
+        float t = 0;
+#pragma unroll
+        for (int i = 0; i < 40; i++) t += acc[i] * acc[(i * 7) % 40];
+        dyn[threadIdx.x] = (char)t;
+        __syncthreads();
+        if (dyn[(threadIdx.x + 1) & 255] == 3) return;
+    }
+    v4f z = { 0, 0, 0, 0 };
+    size_t b = (size_t)blockIdx.x * chunk4;
+    size_t e = b + chunk4 < n4 ? b + chunk4 : n4;
+    for (size_t i = b + threadIdx.x; i < e; i += 256) ST(p[i], z);
+}
 // V3: WG (chunk, band) writes `passes` x 4 KB in each of `planes` planes (plane stride = plane4 float4)
 __global__ __launch_bounds__(256) void fill_planes(v4f* p, size_t plane4, int planes, int band4, int passes)
 {
@@ -107,6 +127,11 @@ int main()
         int chunk4 = kb * 1024 / 16; int G = (int)((n4 + chunk4 - 1) / chunk4);
         char nm[64]; snprintf(nm, 64, "chunk %d KB/WG (G=%d)", kb, G);
         timeit(nm, [&] { hipLaunchKernelGGL(fill_chunk, dim3(G), dim3(256), 0, 0, d, n4, chunk4); });
+    }
+    for (int lds : { 0, 5120, 16384 }) {
+        int chunk4 = 4 * 1024 / 16; int G = (int)((n4 + chunk4 - 1) / chunk4);
+        char nm[64]; snprintf(nm, 64, "chunk 4 KB/WG, %d B dynamic LDS, ~50 VGPR", lds);
+        timeit(nm, [&] { hipLaunchKernelGGL(fill_chunk_dynlds, dim3(G), dim3(256), lds, 0, d, n4, chunk4, 0); });
     }
     unsigned* dcover;
     CK(hipMalloc(&dcover, 4096));

@@ -23,7 +23,7 @@ for name, fn in (("tensor.zero_()", lambda b: b.zero_()), ("tensor.fill_(1)", la
     print(f"{name}: median {ts[len(ts)//2]:.1f} us, min {ts[0]:.1f} us  ({288e6/ts[len(ts)//2]/1e3:.0f} GB/s)")
 
 from skelsplat_amd import _lib
-for name, tune in (("sks fwd normal", 0), ("sks fwd no-cover-lookup", 1 << 16), ("sks fwd no-composite", 1 << 17), ("sks fwd neither", (1 << 16) | (1 << 17))):
+for name, tune in (("sks fwd normal", 0), ("sks fwd shell + trivial linear fill", 1 << 16)):
     _lib.prof_enable(True); _lib.prof_read(0)
     for it in range(40):
         c, i, r, st2 = R.forward_views(views, *params, tune_flags=tune)

@@ -37,9 +37,9 @@ if __name__ == "__main__":
   for dataset, V in (("h36m", 4), ("h36m", 16), ("panoptic", 8), ("panoptic", 31)):
       scene, views, params, dL = setup(dataset, V)
       nbytes = 4.0 * scene.H * scene.W * (scene.n_joints + 1) * V
-      for nt in (0, 16, 0, 16):
-          f, b, tot = run(views, params, dL, nt)
-          print(f"{dataset} V={V} plain_stores={nt>0}: fwd {f:7.1f} us ({nbytes/f/1e3:6.0f} GB/s)  bwd {b:6.1f} us  step wall {tot:7.1f} us", flush=True)
+      for pb in (1, 2, 3, 4, 6, 8, 16):
+          f, b, tot = run(views, params, dL, pb << 8)
+          print(f"{dataset} V={V} passes/block={pb}: fwd {f:7.1f} us ({nbytes/f/1e3:6.0f} GB/s)  bwd {b:6.1f} us  step wall {tot:7.1f} us", flush=True)
 
   # host-side enqueue cost (no sync inside): is the step CPU-bound?
   import time
