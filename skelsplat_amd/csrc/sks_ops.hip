@@ -95,135 +95,239 @@ __constant__ float c_gauss[11] = { 0.001028380123898387f, 0.0075987582094967365f
                                    0.10936068743467331f,  0.21300552785396576f,  0.26601171493530273f,
                                    0.21300552785396576f,  0.10936068743467331f,  0.036000773310661316f,
                                    0.0075987582094967365f, 0.001028380123898387f };  // ssim.cu:9-19
-constexpr int ST = 32, SH = ST + 10;
+constexpr int ST = 32, SH = ST + 10;   // 32x32 outputs per block, 42x42 inputs with the 5-pixel halo
+constexpr int SP = 44;                  // LDS row pitch of the input tiles (floats): 16-byte aligned rows
 
 __device__ __forceinline__ float pix_or_zero(const float* __restrict__ img, int y, int x, int H, int W)
 {
     return (x >= 0 && y >= 0 && x < W && y < H) ? img[(size_t)y * W + x] : 0.0f;
 }
 
+// Register-blocked separable convolution: the horizontal pass produces 4 adjacent outputs per work item from 14
+// inputs read as four 16-byte LDS loads; the vertical pass produces 4 vertically adjacent outputs per thread from
+// 14 rows.  ~4x fewer LDS instructions than one-output-per-read; tap order per output is still the reference's
+// left-to-right / top-to-bottom accumulation (ssim.cu:100-185).
 template <int NQ>
-__device__ __forceinline__ void conv_y(const float (*hx)[SH][ST], int ly, int lx, float (&out)[NQ])
+__device__ __forceinline__ void conv_y4(const float (*hx)[SH][ST], int ly0, int lx, float (&out)[4][NQ])
 {
 #pragma unroll
     for (int q = 0; q < NQ; q++) {
-        float val = 0.0f;
+        float col[14];
 #pragma unroll
-        for (int t = 0; t < 11; t++) val += c_gauss[t] * hx[q][ly + t][lx];
-        out[q] = val;
+        for (int r = 0; r < 14; r++) col[r] = hx[q][ly0 + r][lx];
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+            float val = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 11; t++) val += c_gauss[t] * col[o + t];
+            out[o][q] = val;
+        }
     }
 }
 
-__global__ __launch_bounds__(256) void k_ssim_fwd(int H, int W, float C1, float C2, const float* __restrict__ img1,
-                                                   const float* __restrict__ img2, float* __restrict__ ssim_map,
-                                                   float* __restrict__ dm_dmu1, float* __restrict__ dm_dsigma1_sq,
-                                                   float* __restrict__ dm_dsigma12)
+__device__ __forceinline__ void load14(const float* row, float (&v)[16])
 {
-    __shared__ float p1[SH][SH + 1], p2[SH][SH + 1];
-    __shared__ float hx[5][SH][ST];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const float4 t = reinterpret_cast<const float4*>(row)[i];
+        v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w;
+    }
+}
+
+// A block runs a sequence of jobs = (channel, x-tile) for its (tile row, batch); the next job's halo tile is
+// prefetched into registers while the current one is convolved, so the global-load latency overlaps the LDS/VALU work
+// (with one job per block the kernel ran at the speed of its load latency: 3 blocks per CU, ~2.3 us each).
+constexpr int NLD = (SH * SP + 255) / 256;   // halo elements per thread (8)
+
+struct SsimJob {
+    int c, tx;
+};
+__device__ __forceinline__ SsimJob ssim_job(int j, int txb, int tiles_x)
+{
+    SsimJob jb;
+    jb.c = j / txb;
+    jb.tx = blockIdx.x * txb + (j - jb.c * txb);
+    if (jb.tx >= tiles_x) jb.tx = -1;
+    return jb;
+}
+
+__global__ __launch_bounds__(256) void k_ssim_fwd(int H, int W, int CH, int txb, float C1, float C2,
+                                                   const float* __restrict__ img1, const float* __restrict__ img2,
+                                                   float* __restrict__ ssim_map, float* __restrict__ dm_dmu1,
+                                                   float* __restrict__ dm_dsigma1_sq, float* __restrict__ dm_dsigma12)
+{
+    __shared__ __attribute__((aligned(16))) float p1[SH][SP], p2[SH][SP];
+    __shared__ __attribute__((aligned(16))) float hx[5][SH][ST];
     const int tid = threadIdx.x;
-    const size_t plane = (size_t)blockIdx.z * H * W;
-    const float* a = img1 + plane;
-    const float* b = img2 + plane;
-    const int x0 = blockIdx.x * ST, y0 = blockIdx.y * ST;
-    for (int i = tid; i < SH * SH; i += 256) {
-        const int ly = i / SH, lx = i - ly * SH;
-        p1[ly][lx] = pix_or_zero(a, y0 + ly - 5, x0 + lx - 5, H, W);
-        p2[ly][lx] = pix_or_zero(b, y0 + ly - 5, x0 + lx - 5, H, W);
-    }
-    __syncthreads();
-    for (int i = tid; i < SH * ST; i += 256) {  // horizontal pass (ssim.cu:100-164)
-        const int ly = i / ST, lx = i - ly * ST;
-        float m1 = 0.0f, m2 = 0.0f, s11 = 0.0f, s22 = 0.0f, s12 = 0.0f;
+    const int tiles_x = (W + ST - 1) / ST;
+    const int y0 = blockIdx.y * ST;
+    const int njobs = CH * txb;
+    float r1[NLD], r2[NLD];
+    auto fetch = [&](int j) {
+        const SsimJob jb = ssim_job(j, txb, tiles_x);
+        const size_t plane = ((size_t)blockIdx.z * CH + jb.c) * H * W;
 #pragma unroll
-        for (int t = 0; t < 11; t++) {
-            const float u = p1[ly][lx + t], w = p2[ly][lx + t], gk = c_gauss[t];
-            m1 += gk * u;
-            m2 += gk * w;
-            s11 += gk * (u * u);
-            s22 += gk * (w * w);
-            s12 += gk * (u * w);
+        for (int k = 0; k < NLD; k++) {
+            const int i = tid + k * 256;
+            const int ly = i / SP, lx = i - ly * SP;
+            const bool in = jb.tx >= 0 && i < SH * SP && lx < SH;
+            r1[k] = in ? pix_or_zero(img1 + plane, y0 + ly - 5, jb.tx * ST + lx - 5, H, W) : 0.0f;
+            r2[k] = in ? pix_or_zero(img2 + plane, y0 + ly - 5, jb.tx * ST + lx - 5, H, W) : 0.0f;
         }
-        hx[0][ly][lx] = m1; hx[1][ly][lx] = m2; hx[2][ly][lx] = s11; hx[3][ly][lx] = s22; hx[4][ly][lx] = s12;
-    }
-    __syncthreads();
-    const int lx = tid & 31;
+    };
+    fetch(0);
+    for (int j = 0; j < njobs; j++) {
+        const SsimJob jb = ssim_job(j, txb, tiles_x);
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const int ly = (tid >> 5) + 8 * r;
-        const int x = x0 + lx, y = y0 + ly;
-        float q[5];
-        conv_y<5>(hx, ly, lx, q);
-        const float mu1 = q[0], mu2 = q[1];
-        const float sigma1_sq = q[2] - mu1 * mu1;
-        const float sigma2_sq = q[3] - mu2 * mu2;
-        const float sigma12 = q[4] - mu1 * mu2;
-        // ssim.cu:262-283
-        const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu1_mu2 = mu1 * mu2;
-        const float Cc = (2.0f * mu1_mu2 + C1);
-        const float D = (2.0f * sigma12 + C2);
-        const float A = (mu1_sq + mu2_sq + C1);
-        const float B = (sigma1_sq + sigma2_sq + C2);
-        const float m = (Cc * D) / (A * B);
-        if (x < W && y < H) {
-            const size_t gi = plane + (size_t)y * W + x;
-            ssim_map[gi] = m;
-            if (dm_dmu1) {
-                dm_dmu1[gi] = ((mu2 * 2.0f * D) / (A * B) - (mu2 * 2.0f * Cc) / (A * B) - (mu1 * 2.0f * Cc * D) / (A * A * B) +
-                               (mu1 * 2.0f * Cc * D) / (A * B * B));
-                dm_dsigma1_sq[gi] = ((-Cc * D) / (A * B * B));
-                dm_dsigma12[gi] = ((2 * Cc) / (A * B));
+        for (int k = 0; k < NLD; k++) {
+            const int i = tid + k * 256;
+            if (i < SH * SP) { (&p1[0][0])[i] = r1[k]; (&p2[0][0])[i] = r2[k]; }
+        }
+        __syncthreads();
+        if (j + 1 < njobs) fetch(j + 1);   // in flight during the two passes below
+        if (jb.tx >= 0) {
+            for (int i = tid; i < SH * (ST / 4); i += 256) {  // horizontal pass (ssim.cu:100-164), 4 outputs per item
+                const int ly = i / (ST / 4), g4 = (i - ly * (ST / 4)) * 4;
+                float u[16], w[16];
+                load14(&p1[ly][g4], u);
+                load14(&p2[ly][g4], w);
+                float4 o[5];
+                float* of = reinterpret_cast<float*>(o);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    float m1 = 0.0f, m2 = 0.0f, s11 = 0.0f, s22 = 0.0f, s12 = 0.0f;
+#pragma unroll
+                    for (int t = 0; t < 11; t++) {
+                        const float uu = u[k + t], ww = w[k + t], gk = c_gauss[t];
+                        m1 += gk * uu;
+                        m2 += gk * ww;
+                        s11 += gk * (uu * uu);
+                        s22 += gk * (ww * ww);
+                        s12 += gk * (uu * ww);
+                    }
+                    of[0 * 4 + k] = m1; of[1 * 4 + k] = m2; of[2 * 4 + k] = s11; of[3 * 4 + k] = s22; of[4 * 4 + k] = s12;
+                }
+#pragma unroll
+                for (int q = 0; q < 5; q++) *reinterpret_cast<float4*>(&hx[q][ly][g4]) = o[q];
             }
         }
+        __syncthreads();
+        if (jb.tx >= 0) {
+            const size_t plane = ((size_t)blockIdx.z * CH + jb.c) * H * W;
+            const int x0 = jb.tx * ST;
+            const int lx = tid & 31, ly0 = (tid >> 5) * 4;
+            float q4[4][5];
+            conv_y4<5>(hx, ly0, lx, q4);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int x = x0 + lx, y = y0 + ly0 + r;
+                const float mu1 = q4[r][0], mu2 = q4[r][1];
+                const float sigma1_sq = q4[r][2] - mu1 * mu1;
+                const float sigma2_sq = q4[r][3] - mu2 * mu2;
+                const float sigma12 = q4[r][4] - mu1 * mu2;
+                // ssim.cu:262-283
+                const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu1_mu2 = mu1 * mu2;
+                const float Cc = (2.0f * mu1_mu2 + C1);
+                const float D = (2.0f * sigma12 + C2);
+                const float A = (mu1_sq + mu2_sq + C1);
+                const float B = (sigma1_sq + sigma2_sq + C2);
+                const float m = (Cc * D) / (A * B);
+                if (x < W && y < H) {
+                    const size_t gi = plane + (size_t)y * W + x;
+                    ssim_map[gi] = m;
+                    if (dm_dmu1) {
+                        dm_dmu1[gi] = ((mu2 * 2.0f * D) / (A * B) - (mu2 * 2.0f * Cc) / (A * B) - (mu1 * 2.0f * Cc * D) / (A * A * B) +
+                                       (mu1 * 2.0f * Cc * D) / (A * B * B));
+                        dm_dsigma1_sq[gi] = ((-Cc * D) / (A * B * B));
+                        dm_dsigma12[gi] = ((2 * Cc) / (A * B));
+                    }
+                }
+            }
+        }
+        // the next iteration's LDS writes are ordered behind this barrier-free region by the barrier at its top...
+        __syncthreads();
     }
 }
 
 // backward (ssim.cu:288-366): dL/dimg1 = G*(dL_dmap dm_dmu1) + 2 img1 G*(dL_dmap dm_dsigma1_sq) + img2 G*(dL_dmap dm_dsigma12)
-__global__ __launch_bounds__(256) void k_ssim_bwd(int H, int W, const float* __restrict__ img1, const float* __restrict__ img2,
-                                                   const float* __restrict__ dL_dmap, const float* __restrict__ dm_dmu1,
-                                                   const float* __restrict__ dm_dsigma1_sq, const float* __restrict__ dm_dsigma12,
-                                                   float* __restrict__ dL_dimg1)
+__global__ __launch_bounds__(256) void k_ssim_bwd(int H, int W, int CH, int txb, const float* __restrict__ img1,
+                                                   const float* __restrict__ img2, const float* __restrict__ dL_dmap,
+                                                   const float* __restrict__ dm_dmu1, const float* __restrict__ dm_dsigma1_sq,
+                                                   const float* __restrict__ dm_dsigma12, float* __restrict__ dL_dimg1)
 {
-    __shared__ float pq[3][SH][SH + 1];
-    __shared__ float hx[3][SH][ST];
+    __shared__ __attribute__((aligned(16))) float pq[3][SH][SP];
+    __shared__ __attribute__((aligned(16))) float hx[3][SH][ST];
     const int tid = threadIdx.x;
-    const size_t plane = (size_t)blockIdx.z * H * W;
-    const int x0 = blockIdx.x * ST, y0 = blockIdx.y * ST;
-    for (int i = tid; i < SH * SH; i += 256) {
-        const int ly = i / SH, lx = i - ly * SH;
-        const int y = y0 + ly - 5, x = x0 + lx - 5;
-        const float d = pix_or_zero(dL_dmap + plane, y, x, H, W);
-        pq[0][ly][lx] = pix_or_zero(dm_dmu1 + plane, y, x, H, W) * d;
-        pq[1][ly][lx] = pix_or_zero(dm_dsigma1_sq + plane, y, x, H, W) * d;
-        pq[2][ly][lx] = pix_or_zero(dm_dsigma12 + plane, y, x, H, W) * d;
-    }
-    __syncthreads();
-    for (int i = tid; i < SH * ST; i += 256) {
-        const int ly = i / ST, lx = i - ly * ST;
+    const int tiles_x = (W + ST - 1) / ST;
+    const int y0 = blockIdx.y * ST;
+    const int njobs = CH * txb;
+    float r0[NLD], r1[NLD], r2[NLD];
+    auto fetch = [&](int j) {
+        const SsimJob jb = ssim_job(j, txb, tiles_x);
+        const size_t plane = ((size_t)blockIdx.z * CH + jb.c) * H * W;
 #pragma unroll
-        for (int q = 0; q < 3; q++) {
-            float val = 0.0f;
-#pragma unroll
-            for (int t = 0; t < 11; t++) val += c_gauss[t] * pq[q][ly][lx + t];
-            hx[q][ly][lx] = val;
+        for (int k = 0; k < NLD; k++) {
+            const int i = tid + k * 256;
+            const int ly = i / SP, lx = i - ly * SP;
+            const bool in = jb.tx >= 0 && i < SH * SP && lx < SH;
+            const int y = y0 + ly - 5, x = jb.tx * ST + lx - 5;
+            const float d = in ? pix_or_zero(dL_dmap + plane, y, x, H, W) : 0.0f;
+            r0[k] = in ? pix_or_zero(dm_dmu1 + plane, y, x, H, W) * d : 0.0f;
+            r1[k] = in ? pix_or_zero(dm_dsigma1_sq + plane, y, x, H, W) * d : 0.0f;
+            r2[k] = in ? pix_or_zero(dm_dsigma12 + plane, y, x, H, W) * d : 0.0f;
         }
-    }
-    __syncthreads();
-    const int lx = tid & 31;
+    };
+    fetch(0);
+    for (int j = 0; j < njobs; j++) {
+        const SsimJob jb = ssim_job(j, txb, tiles_x);
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const int ly = (tid >> 5) + 8 * r;
-        const int x = x0 + lx, y = y0 + ly;
-        float q[3];
-        conv_y<3>(hx, ly, lx, q);
-        if (x < W && y < H) {
-            const size_t gi = plane + (size_t)y * W + x;
-            float dL_dpix = 0.0f;
-            dL_dpix += q[0];
-            dL_dpix += img1[gi] * 2.0f * q[1];
-            dL_dpix += img2[gi] * q[2];
-            dL_dimg1[gi] = dL_dpix;
+        for (int k = 0; k < NLD; k++) {
+            const int i = tid + k * 256;
+            if (i < SH * SP) { (&pq[0][0][0])[i] = r0[k]; (&pq[1][0][0])[i] = r1[k]; (&pq[2][0][0])[i] = r2[k]; }
         }
+        __syncthreads();
+        if (j + 1 < njobs) fetch(j + 1);
+        if (jb.tx >= 0) {
+            for (int i = tid; i < SH * (ST / 4); i += 256) {
+                const int ly = i / (ST / 4), g4 = (i - ly * (ST / 4)) * 4;
+#pragma unroll
+                for (int q = 0; q < 3; q++) {
+                    float u[16];
+                    load14(&pq[q][ly][g4], u);
+                    float4 o;
+                    float* of = reinterpret_cast<float*>(&o);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        float val = 0.0f;
+#pragma unroll
+                        for (int t = 0; t < 11; t++) val += c_gauss[t] * u[k + t];
+                        of[k] = val;
+                    }
+                    *reinterpret_cast<float4*>(&hx[q][ly][g4]) = o;
+                }
+            }
+        }
+        __syncthreads();
+        if (jb.tx >= 0) {
+            const size_t plane = ((size_t)blockIdx.z * CH + jb.c) * H * W;
+            const int x0 = jb.tx * ST;
+            const int lx = tid & 31, ly0 = (tid >> 5) * 4;
+            float q4[4][3];
+            conv_y4<3>(hx, ly0, lx, q4);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int x = x0 + lx, y = y0 + ly0 + r;
+                if (x < W && y < H) {
+                    const size_t gi = plane + (size_t)y * W + x;
+                    float dL_dpix = 0.0f;
+                    dL_dpix += q4[r][0];
+                    dL_dpix += img1[gi] * 2.0f * q4[r][1];
+                    dL_dpix += img2[gi] * q4[r][2];
+                    dL_dimg1[gi] = dL_dpix;
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -263,6 +367,16 @@ __global__ __launch_bounds__(256) void k_knn3(int P, const float* __restrict__ p
 
 }  // namespace
 
+namespace {
+// x-tiles per block: every block runs CH * txb pipelined jobs; keep >= ~3000 blocks on the chip when the image allows
+int ssim_tiles_per_block(int tiles_x, int tiles_y, int B, int CH)
+{
+    int txb = 1;
+    while (txb < 8 && CH * txb < 4 && (long long)((tiles_x + 2 * txb - 1) / (2 * txb)) * tiles_y * B >= 3000) txb *= 2;
+    return txb;
+}
+}  // namespace
+
 extern "C" {
 
 int sks_masked_l2(int V, size_t n_per_view, const float* render, const float* gt, float* dL_unscaled, double* sums,
@@ -288,9 +402,11 @@ int sks_fused_ssim_fwd(int B, int CH, int H, int W, float C1, float C2, const fl
     if (!img1 || !img2 || !ssim_map) return fail2(-2, "ssim: missing pointer");
     if ((dm_dmu1 != nullptr) != (dm_dsigma1_sq != nullptr) || (dm_dmu1 != nullptr) != (dm_dsigma12 != nullptr))
         return fail2(-2, "ssim: provide all three partial-derivative maps or none");
-    dim3 grid((W + ST - 1) / ST, (H + ST - 1) / ST, B * CH);
-    hipLaunchKernelGGL(k_ssim_fwd, grid, dim3(256), 0, (hipStream_t)stream, H, W, C1, C2, img1, img2, ssim_map, dm_dmu1,
-                       dm_dsigma1_sq, dm_dsigma12);
+    const int tiles_x = (W + ST - 1) / ST, tiles_y = (H + ST - 1) / ST;
+    const int txb = ssim_tiles_per_block(tiles_x, tiles_y, B, CH);
+    dim3 grid((tiles_x + txb - 1) / txb, tiles_y, B);
+    hipLaunchKernelGGL(k_ssim_fwd, grid, dim3(256), 0, (hipStream_t)stream, H, W, CH, txb, C1, C2, img1, img2, ssim_map,
+                       dm_dmu1, dm_dsigma1_sq, dm_dsigma12);
     HIP_TRY2(hipGetLastError());
     return 0;
 }
@@ -304,8 +420,10 @@ int sks_fused_ssim_bwd(int B, int CH, int H, int W, float C1, float C2, const fl
     if (B * CH == 0) return 0;
     if (!img1 || !img2 || !dL_dmap || !dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12 || !dL_dimg1)
         return fail2(-2, "ssim backward: missing pointer");
-    dim3 grid((W + ST - 1) / ST, (H + ST - 1) / ST, B * CH);
-    hipLaunchKernelGGL(k_ssim_bwd, grid, dim3(256), 0, (hipStream_t)stream, H, W, img1, img2, dL_dmap, dm_dmu1,
+    const int tiles_x = (W + ST - 1) / ST, tiles_y = (H + ST - 1) / ST;
+    const int txb = ssim_tiles_per_block(tiles_x, tiles_y, B, CH);
+    dim3 grid((tiles_x + txb - 1) / txb, tiles_y, B);
+    hipLaunchKernelGGL(k_ssim_bwd, grid, dim3(256), 0, (hipStream_t)stream, H, W, CH, txb, img1, img2, dL_dmap, dm_dmu1,
                        dm_dsigma1_sq, dm_dsigma12, dL_dimg1);
     HIP_TRY2(hipGetLastError());
     return 0;
