@@ -848,11 +848,6 @@ __global__ __launch_bounds__(256) void k_render_bwd_gather(BwdArgs a)
     __syncthreads();
     int kg = 0;
     for (int k = 0; k < n; k++) kg = L.id[k] == g ? k : kg;
-    if (a.flags & (1u << 18)) {  // EXPERIMENT: prologue only
-        if (tid < NVS) out[tid * BWD_SPLITS] = (float)(n + nc + kg) * 0.0f;
-        return;
-    }
-
     const bool do_clamp = a.flags & SKS_CLAMP01;
     const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);  // backward.cu:527-528
     float sum[NV];
@@ -891,7 +886,6 @@ __global__ __launch_bounds__(256) void k_render_bwd_gather(BwdArgs a)
             klast = k;
         }
         if (klast < kg) continue;  // g is behind the last contributor (or nothing contributes) at this pixel
-        if (a.flags & (1u << 19)) { sum[0] += T; continue; }  // EXPERIMENT: prepass only
         // upstream gradient of this pixel: only now, only the active channels (most rect pixels never get here)
         const size_t pix = (size_t)y * W + x;
         float dLraw[CG];

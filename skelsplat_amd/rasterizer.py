@@ -6,6 +6,8 @@ plus the batched multi-view entry points the MI355X loop uses.
 """
 from typing import NamedTuple, Optional
 
+import weakref
+
 import torch
 import torch.nn as nn
 
@@ -170,6 +172,33 @@ def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotati
     return color, invdepth, radii, st
 
 
+_BG_CACHE = {}
+
+
+def _bg_channels(bg, C, dev):
+    """The background as C floats, or None when it is absent or all zero (the reference's default `[0, 0, 0]`,
+    train.py:112-113): a zero background contributes nothing to the backward (backward.cu:612-615), and passing NULL
+    selects the faster kernels.  The reference reads C floats from its 3-float bg tensor (backward.cu:613-614); pad
+    with zeros instead.  One host read per (tensor, version), cached."""
+    if bg is None or bg.numel() == 0:
+        return None
+    key = (id(bg), C, str(dev))
+    hit = _BG_CACHE.get(key)
+    if hit is not None and (hit[0]() is not bg or hit[1] != bg._version):
+        hit = None     # another tensor at a recycled id, or modified in place since
+    if hit is None:
+        if len(_BG_CACHE) > 64:
+            _BG_CACHE.clear()
+        bgC = None
+        if bool((bg != 0).any()):
+            bgC = torch.zeros(C, dtype=torch.float32, device=dev)
+            k = min(C, bg.numel())
+            bgC[:k] = bg.reshape(-1)[:k].to(device=dev, dtype=torch.float32)
+        hit = (weakref.ref(bg), bg._version, bgC)
+        _BG_CACHE[key] = hit
+    return hit[2]
+
+
 def backward_views(st: ForwardState, means3D, features, opacities, scales, rotations, cov3D_precomp, dL_dcolor,
                    dL_dinvdepth=None, bg=None, want_dfeatures=False, tune_flags=0):
     """Raw batched backward: per-view gradients, dict of (V,P,...) tensors."""
@@ -190,12 +219,7 @@ def backward_views(st: ForwardState, means3D, features, opacities, scales, rotat
     dL_dinvdepth = _f32c(dL_dinvdepth, "dL_dout_invdepth")
     if dL_dcolor.numel() != V * C * H * W:
         raise RuntimeError("dL_dout_color has the wrong number of elements")
-    bgC = None
-    if bg is not None and bg.numel() > 0:
-        # the reference reads C floats from its 3-float bg tensor (backward.cu:613-614); pad with zeros instead
-        bgC = torch.zeros(C, dtype=torch.float32, device=dev)
-        k = min(C, bg.numel())
-        bgC[:k] = bg.reshape(-1)[:k].to(device=dev, dtype=torch.float32)
+    bgC = _bg_channels(bg, C, dev)
     e = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
     out = dict(means3D=e(V, P, 3), means2D=e(V, P, 3), opacities=e(V, P, 1), cov3D=e(V, P, 6),
                scales=e(V, P, 3) if scales is not None else None,
@@ -444,11 +468,7 @@ def backward_fused_loss(st: ForwardState, stats: GtStats, means3D, features, opa
     feat2 = _f32c(features, "features").reshape(P, -1)
     opacities = _f32c(opacities, "opacities")
     scales, rotations, cov3D_precomp = _f32c(scales, "scales"), _f32c(rotations, "rotations"), _f32c(cov3D_precomp, "cov3D_precomp")
-    bgC = None
-    if bg is not None and bg.numel() > 0 and bool((bg != 0).any()):
-        bgC = torch.zeros(C, dtype=torch.float32, device=dev)
-        k = min(C, bg.numel())
-        bgC[:k] = bg.reshape(-1)[:k].to(device=dev, dtype=torch.float32)
+    bgC = _bg_channels(bg, C, dev)
     e = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
     out = dict(means3D=e(V, P, 3), means2D=e(V, P, 3), opacities=e(V, P, 1), cov3D=e(V, P, 6),
                scales=e(V, P, 3) if scales is not None else None, rotations=e(V, P, 4) if rotations is not None else None)

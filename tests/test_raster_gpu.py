@@ -91,6 +91,51 @@ def test_backward_vs_oracle(device, kw, binned, aa):
             util.assert_close("lds-vs-wave " + k, g3[k].cpu(), g[k].cpu(), rtol=1e-4, atol_scale=1e-6)
 
 
+@pytest.mark.parametrize("kw", CASES, ids=lambda k: f"seed{k['seed']}")
+@pytest.mark.parametrize("clamp", [False, True], ids=["noclamp", "clamp"])
+def test_backward_no_background(device, kw, clamp):
+    """Without a background (None, or the reference's default all-zero tensor) and without dL/dfeatures the backward
+    skips channels no overlapping Gaussian has a feature for; checked against the oracle, and the zero-tensor and None
+    forms give identical bits."""
+    c = util.make_case(**kw)
+    dev = device
+    views = R.ViewBatch.from_cameras([cam.to(dev) for cam in c.cams])
+    args = (t(c.means, dev), t(c.feat, dev), t(c.opac, dev), t(c.scales, dev), t(c.quats, dev), None)
+    if clamp:   # make a share of the pixels fall outside [0, 1] so that the clamp mask matters
+        args = (args[0], args[1] * 3.0 - 0.5, *args[2:])
+    color, inv, radii, st = R.forward_views(views, *args, clamp01=clamp)
+    dLc = t(c.dL_color, dev)
+    g = R.backward_views(st, *args, dLc, t(c.dL_inv, dev))
+    gz = R.backward_views(st, *args, dLc, t(c.dL_inv, dev), bg=torch.zeros(3, device=dev))
+    gd = R.backward_views(st, *args, dLc, t(c.dL_inv, dev), want_dfeatures=True)   # all channels visited
+    for k in ("means3D", "means2D", "opacities", "scales", "rotations", "cov3D"):
+        assert torch.equal(g[k], gz[k])
+        util.assert_close("skip-vs-all " + k, g[k].cpu(), gd[k].cpu(), rtol=1e-4, atol_scale=1e-6)
+    if not clamp:
+        for v in range(len(c.cams)):
+            o = util.oracle_forward(c, v)
+            b = util.oracle_backward(c, v, o)
+            util.assert_close("dL_dmeans3D", g["means3D"][v].cpu(), b["dL_dmeans3D"])
+            util.assert_close("dL_dmeans2D", g["means2D"][v].cpu(), b["dL_dmeans2D"])
+            util.assert_close("dL_dopacity", g["opacities"][v].cpu(), b["dL_dopacity"])
+            util.assert_close("dL_dscales", g["scales"][v].cpu(), b["dL_dscales"])
+            util.assert_close("dL_drotations", g["rotations"][v].cpu(), b["dL_drotations"])
+
+
+def test_bg_cache_identity(device):
+    """The all-zero-background test is cached per tensor object: a new tensor at a recycled address or an in-place
+    update must not see a stale answer."""
+    dev = device
+    a = torch.tensor([0.3, 0.5, 0.2], device=dev)
+    assert R._bg_channels(a, 17, a.device) is not None
+    del a
+    z = torch.zeros(3, device=dev)
+    assert R._bg_channels(z, 17, z.device) is None
+    z[1] = 0.25
+    got = R._bg_channels(z, 17, z.device)
+    assert got is not None and got.shape == (17,) and float(got[1]) == 0.25 and float(got[5]) == 0.0
+
+
 def test_autograd_single_view_api(device):
     """The reference's call shape: GaussianRasterizer(settings)(means3D=..., shs=(P,1,C), ...) -> (color, radii, invdepth)."""
     import math
