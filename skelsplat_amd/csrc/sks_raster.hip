@@ -84,7 +84,8 @@ struct ProfScope {  // records begin at construction, end at destruction, around
     }
 };
 
-constexpr int LCAP = 256;         // LDS list capacity == SKS_SMALL_P == binned batch size
+constexpr int LCAP = 64;          // binned path: entries staged in LDS per batch (short lists are the norm; the
+                                  // smaller the footprint, the more tile blocks a CU keeps in flight)
 constexpr int NACC = 8;           // per-Gaussian accumulators before the feature block:
                                   // 0,1 dL_dmean2D.xy  2,3,4 dL_dconic.{x,y,w}  5 dL_dopacity  6 dL_dinvdepth  7 pad
 constexpr int BWD_SPLITS = 16;    // small path backward: partial-sum slots (workgroups) per (view, Gaussian)
@@ -568,7 +569,7 @@ struct BwdPix {
 template <int CG, bool XF, bool DFEAT>
 __device__ __forceinline__ void bwd_sweep(const List<CG>& L, int n, int klast /* last accepted LDS index or -1 */,
                                           float pxf, float pyf, int tx, float ddelx_dx, float ddely_dy,
-                                          BwdPix<CG>& s, float* s_acc)
+                                          BwdPix<CG>& s, float* s_acc, int nc = CG /* staged (compacted) channels */)
 {
     constexpr int NVL = NACC + (DFEAT ? CG : 0);
     const int lane = threadIdx.x & 63;
@@ -605,6 +606,7 @@ __device__ __forceinline__ void bwd_sweep(const List<CG>& L, int n, int klast /*
             float dL_dalpha = 0.0f;
 #pragma unroll
             for (int ch = 0; ch < CG; ch++) {
+                if (ch >= nc) break;  // wave-uniform
                 const float c = L.feat[k * CG + ch];
                 s.accum_rec[ch] = s.last_alpha * s.last_color[ch] + (1.f - s.last_alpha) * s.accum_rec[ch];
                 s.last_color[ch] = c;
@@ -1616,11 +1618,12 @@ __global__ void k_export_lists(int NT, size_t cap, const uint2* __restrict__ ran
     if (i < cap) point_list[(size_t)v * cap + i] = i < (size_t)nrend[v] ? (uint32_t)keys[(size_t)v * cap + i] : 0u;
 }
 
-// stage one batch of a tile's sorted entries into LDS (forward.cu:335-343 / backward.cu:536-548)
+// stage one batch of a tile's sorted entries into LDS (forward.cu:335-343 / backward.cu:536-548).
+// chan != nullptr: only the nc listed channels are staged, compacted to positions 0..nc-1 (rest zero).
 template <int CG>
 __device__ __forceinline__ void stage_batch(List<CG>& L, int cnt, const unsigned long long* __restrict__ keys, int P, int C,
                                             const float4* __restrict__ gco, const float4* __restrict__ gxyd,
-                                            const float* __restrict__ features)
+                                            const float* __restrict__ features, const int* chan = nullptr, int nc = 0)
 {
     const int tid = threadIdx.x;
     if (tid < cnt) {
@@ -1630,8 +1633,13 @@ __device__ __forceinline__ void stage_batch(List<CG>& L, int cnt, const unsigned
         L.co[tid] = gco[id];
         L.invd[tid] = xyd.w;
         L.id[tid] = id;
+        if (chan) {
 #pragma unroll
-        for (int ch = 0; ch < CG; ch++) L.feat[tid * CG + ch] = ch < C ? features[id * C + ch] : 0.0f;
+            for (int j = 0; j < CG; j++) L.feat[tid * CG + j] = j < nc ? features[id * C + chan[j]] : 0.0f;
+        } else {
+#pragma unroll
+            for (int ch = 0; ch < CG; ch++) L.feat[tid * CG + ch] = ch < C ? features[id * C + ch] : 0.0f;
+        }
     }
 }
 
@@ -1682,13 +1690,25 @@ __global__ __launch_bounds__(256) void k_render_fwd_binned(FwdArgs a, BinView b)
     }
 }
 
-// binned backward: grid (Tx, Ty, V), thread = pixel (backward.cu:452-638)
-template <int CG, bool DFEAT>
+// binned backward: grid (Tx, Ty, V), thread = pixel (backward.cu:452-638).
+// Only the channels some entry of the tile's list has a non-zero feature for can contribute to the per-Gaussian sums
+// when neither dL/dfeatures nor a background term is wanted (see k_render_bwd_gather): they are found first
+// (one light pass over the list) and processed BWD_NB at a time with the features staged compacted -- with one-hot
+// skeleton features that is one group of 1-3 planes of dL/d(render) instead of 17-19.  Every per-Gaussian sum is
+// linear in dL/dalpha, which is a sum over channels (+ the inverse-depth and background terms, kept in group 0 / split
+// like the channels), so groups simply accumulate; T, alpha and the last contributor do not depend on the channel.
+// The per-pixel register arrays have BWD_NB entries instead of C, which is what the occupancy of this kernel hinges on.
+constexpr int BWD_NB = 8;
+
+template <bool DFEAT>
 __global__ __launch_bounds__(256) void k_render_bwd_binned(BwdArgs a, BinView b)
 {
-    constexpr int NVL = NACC + (DFEAT ? CG : 0);
-    __shared__ List<CG> L;
+    constexpr int NB = BWD_NB;
+    constexpr int NVL = NACC + (DFEAT ? NB : 0);
+    __shared__ List<NB> L;
     __shared__ float s_acc[LCAP * NVL];
+    __shared__ unsigned s_chm;
+    __shared__ int s_chan[SKS_MAX_CHANNELS];
     const int v = blockIdx.z, tid = threadIdx.x;
     const int P = a.P, C = a.C, W = a.W, H = a.H;
     const size_t HW = (size_t)H * W;
@@ -1705,41 +1725,90 @@ __global__ __launch_bounds__(256) void k_render_bwd_binned(BwdArgs a, BinView b)
     const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);
     const int NVS = NACC + C;
 
-    // pass 1: re-composite front to back to recover T_final and the last contributor
-    float T = 1.0f, col[CG];
-#pragma unroll
-    for (int ch = 0; ch < CG; ch++) col[ch] = 0.0f;
-    int glast = -1;  // global (tile-list) index of the last accepted entry
-    bool done = !inside;
-    for (int off = 0; off < total; off += LCAP) {
-        if (__syncthreads_count(done) == 256) break;
-        const int cnt = min(LCAP, total - off);
-        stage_batch<CG>(L, cnt, keys + off, P, C, a.g.co + go, a.g.xyd + go, a.features);
+    // pass 0: the active channels of this tile's list -> s_chan[0..nc)
+    const bool all_ch = DFEAT || a.bg != nullptr;
+    if (tid == 0) s_chm = 0u;
+    __syncthreads();
+    if (!all_ch) {
+        unsigned m = 0u;
+        for (int i = tid; i < total; i += 256) {
+            const float* f = a.features + (size_t)(unsigned)keys[i] * C;
+            for (int ch = 0; ch < C; ch++) m |= f[ch] != 0.0f ? (1u << ch) : 0u;
+        }
+        if (m) atomicOr(&s_chm, m);
         __syncthreads();
-        int klast = -1;
-        bwd_prepass<CG, false>(L, cnt, (float)x, (float)y, 0, T, col, do_clamp, klast, done);
-        if (klast >= 0) glast = off + klast;
+    }
+    const unsigned chm = all_ch ? (C >= 32 ? 0xffffffffu : (1u << C) - 1u) : s_chm;
+    const int nc = __popc(chm);
+    if (tid < SKS_MAX_CHANNELS) {
+        unsigned r = chm;
+        for (int j = 0; j < tid && r; j++) r &= r - 1;
+        s_chan[tid] = r ? __builtin_ctz(r) : 0;
     }
     __syncthreads();
-    BwdPix<CG> s;
-    if (glast >= 0) bwd_load_pixel<CG>(s, a, v, pix, HW, col, do_clamp, T);
-    // pass 2: back to front over the batches
+
     const int nb = (total + LCAP - 1) / LCAP;
-    for (int bi = nb - 1; bi >= 0; bi--) {
-        const int off = bi * LCAP;
-        const int cnt = min(LCAP, total - off);
-        stage_batch<CG>(L, cnt, keys + off, P, C, a.g.co + go, a.g.xyd + go, a.features);
-        for (int i = tid; i < cnt * NVL; i += 256) s_acc[i] = 0.0f;
-        __syncthreads();
-        bwd_sweep<CG, false, DFEAT>(L, cnt, glast - off, (float)x, (float)y, 0, ddelx_dx, ddely_dy, s, s_acc);
-        __syncthreads();
-        for (int i = tid; i < cnt * NVL; i += 256) {
-            const int k = i / NVL, j = i - k * NVL;
-            if (j >= NACC + C) continue;
-            const float val = s_acc[i];
-            if (val != 0.0f) atomicAdd(&a.accum[((size_t)v * P + L.id[k]) * NVS + j], val);
+    const int ngroups = nc > 0 ? (nc + NB - 1) / NB : 1;  // all-zero features: the inverse-depth terms still flow
+    float T_final = 1.0f;
+    int glast = -1;   // global (tile-list) index of the last accepted entry
+    int staged = -1;  // (group, batch) currently in LDS
+    for (int grp = 0; grp < ngroups; grp++) {
+        const int* chan = s_chan + grp * NB;
+        const int ncg = min(NB, nc - grp * NB);
+        // pass 1: re-composite front to back: T_final and the last contributor (group 0), this group's colours (clamp)
+        float col[NB];
+#pragma unroll
+        for (int j = 0; j < NB; j++) col[j] = 0.0f;
+        if (grp == 0 || do_clamp) {
+            float T = 1.0f;
+            int gl = -1;
+            bool done = !inside;
+            for (int off = 0; off < total; off += LCAP) {
+                if (__syncthreads_count(done) == 256) break;
+                const int cnt = min(LCAP, total - off);
+                stage_batch<NB>(L, cnt, keys + off, P, C, a.g.co + go, a.g.xyd + go, a.features, chan, ncg);
+                staged = grp * nb + off / LCAP;
+                __syncthreads();
+                int klast = -1;
+                bwd_prepass<NB, false>(L, cnt, (float)x, (float)y, 0, T, col, do_clamp, klast, done);
+                if (klast >= 0) gl = off + klast;
+            }
+            __syncthreads();
+            if (grp == 0) {
+                T_final = T;
+                glast = gl;
+                if (__syncthreads_count(glast >= 0) == 0) return;   // nothing was accepted anywhere in the tile
+            }
         }
-        __syncthreads();
+        BwdPix<NB> s;
+        if (glast >= 0) {
+            bwd_load_pixel<NB>(s, a, v, pix, HW, col, do_clamp, T_final, chan, ncg);
+            if (grp > 0) s.dLi = 0.0f;   // the inverse-depth terms belong to group 0
+        }
+        // pass 2: back to front over the batches
+        for (int bi = nb - 1; bi >= 0; bi--) {
+            const int off = bi * LCAP;
+            const int cnt = min(LCAP, total - off);
+            if (staged != grp * nb + bi) {
+                stage_batch<NB>(L, cnt, keys + off, P, C, a.g.co + go, a.g.xyd + go, a.features, chan, ncg);
+                staged = grp * nb + bi;
+            }
+            for (int i = tid; i < cnt * NVL; i += 256) s_acc[i] = 0.0f;
+            __syncthreads();
+            bwd_sweep<NB, false, DFEAT>(L, cnt, glast - off, (float)x, (float)y, 0, ddelx_dx, ddely_dy, s, s_acc, ncg);
+            __syncthreads();
+            for (int i = tid; i < cnt * NVL; i += 256) {
+                const int k = i / NVL, j = i - k * NVL;
+                int slot = j;
+                if (j >= NACC) {
+                    if (j - NACC >= ncg) continue;
+                    slot = NACC + chan[j - NACC];
+                }
+                const float val = s_acc[i];
+                if (val != 0.0f) atomicAdd(&a.accum[((size_t)v * P + L.id[k]) * NVS + slot], val);
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -1931,16 +2000,8 @@ int sks_backward(int V, int P, int C, int W, int H, const float* viewmatrix, con
         BinView bv{ b.ranges, b.keys, bin_capacity, NT };
         dim3 grid(gx, gy, V);
         ProfScope prof(1, st);
-#define SKS_BWD_BINNED(CGV)                                                                                         \
-    if (dfeat) hipLaunchKernelGGL((k_render_bwd_binned<CGV, true>), grid, dim3(256), 0, st, a, bv);                 \
-    else hipLaunchKernelGGL((k_render_bwd_binned<CGV, false>), grid, dim3(256), 0, st, a, bv)
-        switch (cg) {
-            case 4: SKS_BWD_BINNED(4); break;
-            case 16: SKS_BWD_BINNED(16); break;
-            case 20: SKS_BWD_BINNED(20); break;
-            default: SKS_BWD_BINNED(32); break;
-        }
-#undef SKS_BWD_BINNED
+        if (dfeat) hipLaunchKernelGGL((k_render_bwd_binned<true>), grid, dim3(256), 0, st, a, bv);
+        else hipLaunchKernelGGL((k_render_bwd_binned<false>), grid, dim3(256), 0, st, a, bv);
         STAGE_CHECK("render-backward(binned)");
     }
     GeomBwdArgs ga{ P, C, W, H, flags, viewmatrix, projmatrix, means3D, opacities, scales, rotations, cov3D_precomp,

@@ -322,6 +322,32 @@ def test_binned_capacity_grows_on_overflow(device):
     assert np.array_equal(color[0].cpu().numpy(), o["color"])
 
 
+def test_binned_long_tile_lists(device):
+    """Hundreds of faint Gaussians stacked on the same pixels: tile lists several times longer than the LDS batch of the
+    binned kernels (multi-batch compositing, early termination across batches, multi-batch backward)."""
+    dev = device
+    rng = np.random.default_rng(5)
+    c = util.make_case(seed=11, W=96, H=80, scale_log=4.4, n_views=1, n_skeletons=18, pitch=30.0, opac=0.05)
+    assert c.P == 306
+    views = R.ViewBatch.from_cameras([cam.to(dev) for cam in c.cams])
+    for opac in (0.05, 0.6):   # 0.6: pixels saturate (T < 1e-4) part-way through the list
+        c.opac = np.full((c.P, 1), opac, np.float32)
+        args = (t(c.means, dev), t(c.feat, dev), t(c.opac, dev), t(c.scales, dev), t(c.quats, dev), None)
+        color, inv, radii, st, final_T, n_contrib = R.forward_views(views, *args, want_aux=True, force_binned=True)
+        o = util.oracle_forward(c, 0)
+        lens = o["ranges"][:, 1].astype(np.int64) - o["ranges"][:, 0].astype(np.int64)
+        assert lens.max() > 200, lens.max()
+        assert np.array_equal(color[0].cpu().numpy(), o["color"])
+        assert np.array_equal(n_contrib[0].cpu().numpy().astype(np.uint32), o["n_contrib"])
+        assert np.array_equal(final_T[0].cpu().numpy(), o["final_T"])
+        g = R.backward_views(st, *args, t(c.dL_color, dev), t(c.dL_inv, dev), want_dfeatures=True)
+        b = util.oracle_backward(c, 0, o)
+        util.assert_close("dL_dmeans3D", g["means3D"][0].cpu(), b["dL_dmeans3D"])
+        util.assert_close("dL_dopacity", g["opacities"][0].cpu(), b["dL_dopacity"])
+        util.assert_close("dL_dscales", g["scales"][0].cpu(), b["dL_dscales"])
+        util.assert_close("dL_dfeatures", g["features"][0].cpu(), b["dL_dcolors"])
+
+
 def test_edge_cases(device):
     dev = device
     c = util.make_case(seed=2, W=100, H=60, scale_log=3.5, n_views=2)

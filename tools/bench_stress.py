@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Timing of BASELINE config 5 (stress: 256 skeletons, P = 4352, C = 17, V = 8 views at 2048x2048) on the binned path.
+Informational -- bench.py's headline stays the H36M configuration."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+import util
+from skelsplat_amd import rasterizer as R, _lib
+
+dev = torch.device("cuda", 0)
+t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev) if a is not None else None
+V = int(os.environ.get("V", "8"))
+big = util.make_case(seed=42, W=2048, H=2048, n_views=V, scale_log=3.0, n_skeletons=256, pitch=1500.0, ring=20000.0,
+                     fxmul=2300.0 / (1145.0 * 2.048), onehot=True, opac=1.0)
+views = R.ViewBatch.from_cameras([cam.to(dev) for cam in big.cams])
+args = (t(big.means), t(big.feat), t(big.opac), t(big.scales), t(big.quats), None)
+C, H, W = 17, 2048, 2048
+dL = torch.randn((V, C, H, W), device=dev)
+color, inv, radii, st = R.forward_views(views, *args, bin_capacity=400000)
+print("P", big.P, "num_rendered per view", st.num_rendered_dev[:V].cpu().tolist(), "visible", int((radii > 0).sum()) / V)
+for name, fn in (("forward", lambda: R.forward_views(views, *args, bin_capacity=400000)),
+                 ("backward", lambda: R.backward_views(st, *args, dL)),
+                 ("fwd+bwd", lambda: R.backward_views(R.forward_views(views, *args, bin_capacity=400000)[3], *args, dL))):
+    for _ in range(3): fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    n = 20
+    for _ in range(n): fn()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
+    alg = 4.0 * H * W * (C + 1) * V * (2 if name == "fwd+bwd" else 1)
+    print(f"{name}: {dt*1e3:.3f} ms per {V}-view call, {V/dt:.0f} views/s, algorithmic {alg/dt/1e9:.0f} GB/s")
+
+# dispatch floor of the tile-per-block kernels: every Gaussian culled -> every tile empty
+far = (torch.tensor([[0.0, 0.0, 1e9]], device=dev).repeat(big.P, 1),) + args[1:]
+c2, i2, r2, st2 = R.forward_views(views, *far, force_binned=True, bin_capacity=400000)
+for name, fn in (("forward, all tiles empty", lambda: R.forward_views(views, *far, force_binned=True, bin_capacity=400000)),
+                 ("backward, all tiles empty", lambda: R.backward_views(st2, *far, dL))):
+    for _ in range(3): fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(20): fn()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 20
+    print(f"{name}: {dt*1e3:.3f} ms")
+nonempty = (st.binning is not None)
+pl, rg, nr = R.export_lists(st)
+ne = (rg[..., 1] > rg[..., 0]).sum(dim=1)
+print("non-empty tiles per view", ne.cpu().tolist(), "of", rg.shape[1])
