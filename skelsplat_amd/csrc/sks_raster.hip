@@ -149,6 +149,10 @@ inline Geom geom_from(void* base, int V, int P, int W, int H)
     g.cover = cover_enabled(P, W, H) ? (uint32_t*)p : nullptr;
     return g;
 }
+inline uint32_t* geom_cover_ptr(void* base, int V, int P)   // the cover region exists for every P (geom_bytes)
+{
+    return (uint32_t*)((char*)base + 3 * align256((size_t)V * P * sizeof(float4)));
+}
 inline size_t geom_bytes(int V, int P, int W, int H)
 {
     return 3 * align256((size_t)V * P * 16) + align256((size_t)V * ((H + TILE - 1) / TILE) * cover_cw(W) * 4);
@@ -391,6 +395,77 @@ struct DynList {
     static size_t bytes(int cap, int cg) { return (size_t)cap * (16 + 16 + 8 + 8 + 4 + 4 * (size_t)cg); }
 };
 
+// ------------------------------------------------------------------------------------------------------------
+// fill role shared by the two forward kernels (fill + sparse composite): block (q, band, zid = view * (C+1) + plane)
+// streams zeros over pb passes of its plane's 16-row band, skipping the tile columns whose bit is set in the
+// band's `cover` row (those tiles are written by a composite block).
+// One block = ONE pass: 256 threads x 16 B = 4 KB of one plane.  On MI355X a dispatch of many 4 KB blocks is the
+// fastest fill shape measured (tools/fill_bench.hip: 44-47 us for 288 MB vs 48-55 us with 16 KB per block), but only
+// if nothing VECTOR-memory sits in front of the store: a dependent global_load queues behind the chip-wide flood of
+// stores (measured: 2.4 TB/s).  The band's cover words written by k_geom_fwd are therefore read through the SCALAR
+// cache (s_load: `cover` is a const __restrict__ kernel argument and the address is made wave-uniform).
+// block order = memory order (pass, band, plane, view): concurrently running blocks write one contiguous window
+// ------------------------------------------------------------------------------------------------------------
+template <int PPT, bool NT>
+__device__ __forceinline__ void fwd_fill_role(const FwdArgs& a, int q, int band, int zid, int gy, int pb,
+                                              const uint32_t* __restrict__ cover)
+{
+    const int tid = threadIdx.x;
+    const int P = a.P, C = a.C, W = a.W, H = a.H;
+    const size_t HW = (size_t)H * W;
+    const int v = zid / (C + 1);
+    const int plane = zid - v * (C + 1);
+    const bool is_inv = plane == C;
+    const int cw = cover_cw(W);
+    constexpr int PASS = 256 * PPT;
+    const int rows = min(TILE, H - band * TILE);
+    const int Nb = rows * W;  // this band of this plane: Nb contiguous floats
+    const int base0 = q * PASS * pb + tid * PPT;     // this block covers passes q*pb .. q*pb + pb - 1 of the band
+    const size_t band0 = (size_t)band * TILE * W;
+    float* out = (is_inv ? a.out_invdepth + (size_t)v * HW : a.out_color + ((size_t)v * C + plane) * HW) + band0;
+    float* outT = (is_inv && a.final_T) ? a.final_T + (size_t)v * HW + band0 : nullptr;
+    uint32_t* outN = (is_inv && a.n_contrib) ? a.n_contrib + (size_t)v * HW + band0 : nullptr;
+    bool any = false;
+    const uint32_t* __restrict__ cwp = cover;
+    if (cover) {
+        const int wo = __builtin_amdgcn_readfirstlane((v * gy + band) * cw);
+        cwp = cover + wo;
+        any = cwp[0] != 0u;   // wave-uniform scalar load; only bands some rect crosses look at the tile bits
+    }
+    uint32_t w0 = 0u, w1 = 0u, w2 = 0u, w3 = 0u;
+    if (any && cw <= 5) {  // W <= 2048: the band's <= 4 bit words via the scalar cache, selected per lane below
+        w0 = cwp[1]; w1 = cw > 2 ? cwp[2] : 0u; w2 = cw > 3 ? cwp[3] : 0u; w3 = cw > 4 ? cwp[4] : 0u;
+    }
+    for (int k = 0; k < pb; k++) {
+        const int base = base0 + k * PASS;
+        if (base >= Nb) break;
+        bool skip0 = false;  // does a composite block write this thread's tile?
+        if (any) {
+            const int tx = (base % W) >> 4;  // PPT == 4: W % 4 == 0, the 4 pixels share one tile column
+            const int wi = tx >> 5;
+            const uint32_t word = cw <= 5 ? (wi == 0 ? w0 : wi == 1 ? w1 : wi == 2 ? w2 : w3) : cwp[1 + wi];
+            skip0 = (word >> (tx & 31)) & 1u;
+        } else if (!cover) {  // cover not precomputed (very large images): test the rects directly
+            const uint4* grect = a.g.rect + (size_t)v * P;
+            const int tx = (base % W) >> 4;
+            for (int i = 0; i < P; i++) {
+                const uint4 r = grect[i];
+                skip0 = skip0 || ((int)r.y <= band && band < (int)r.w && (int)r.x <= tx && tx < (int)r.z);
+            }
+        }
+        if (skip0) continue;
+        if (PPT == 4) store4<NT>(out + base, 0.0f, 0.0f, 0.0f, 0.0f);
+        else out[base] = 0.0f;
+        if (outT || outN) {  // debug planes of the reference's ImageState: T = 1, no contributor outside covered tiles
+#pragma unroll
+            for (int p = 0; p < PPT; p++) {
+                if (outT) outT[base + p] = 1.0f;
+                if (outN) outN[base + p] = 0u;
+            }
+        }
+    }
+}
+
 template <int CG, int PPT, bool NT>
 __global__ __launch_bounds__(256) void k_render_fwd_sparse(FwdArgs a, int ncomp, int gy, int fsplit, int pb,
                                                            const uint32_t* __restrict__ cover)
@@ -495,64 +570,7 @@ __global__ __launch_bounds__(256) void k_render_fwd_sparse(FwdArgs a, int ncomp,
         return;
     }
     // ---------------- fill role ----------------
-    // One block = ONE pass: 256 threads x 16 B = 4 KB of one plane.  On MI355X a dispatch of many 4 KB blocks is the
-    // fastest fill shape measured (tools/fill_bench.hip: 44-47 us for 288 MB vs 48-55 us with 16 KB per block), but only
-    // if nothing VECTOR-memory sits in front of the store: a dependent global_load queues behind the chip-wide flood of
-    // stores (measured: 2.4 TB/s).  The band's cover words written by k_geom_fwd are therefore read through the SCALAR
-    // cache (s_load: `cover` is a const __restrict__ kernel argument and the address is made wave-uniform).
-    // block order = memory order (pass, band, plane, view): concurrently running blocks write one contiguous window
-    const int q = xq, band = band_id;
-    const int v = zid / (C + 1);
-    const int plane = zid - v * (C + 1);
-    const bool is_inv = plane == C;
-    const int cw = cover_cw(W);
-    constexpr int PASS = 256 * PPT;
-    const int rows = min(TILE, H - band * TILE);
-    const int Nb = rows * W;  // this band of this plane: Nb contiguous floats
-    const int base0 = q * PASS * pb + tid * PPT;     // this block covers passes q*pb .. q*pb + pb - 1 of the band
-    const size_t band0 = (size_t)band * TILE * W;
-    float* out = (is_inv ? a.out_invdepth + (size_t)v * HW : a.out_color + ((size_t)v * C + plane) * HW) + band0;
-    float* outT = (is_inv && a.final_T) ? a.final_T + (size_t)v * HW + band0 : nullptr;
-    uint32_t* outN = (is_inv && a.n_contrib) ? a.n_contrib + (size_t)v * HW + band0 : nullptr;
-    bool any = false;
-    const uint32_t* __restrict__ cwp = cover;
-    if (cover) {
-        const int wo = __builtin_amdgcn_readfirstlane((v * gy + band) * cw);
-        cwp = cover + wo;
-        any = cwp[0] != 0u;   // wave-uniform scalar load; only bands some rect crosses look at the tile bits
-    }
-    uint32_t w0 = 0u, w1 = 0u, w2 = 0u, w3 = 0u;
-    if (any && cw <= 5) {  // W <= 2048: the band's <= 4 bit words via the scalar cache, selected per lane below
-        w0 = cwp[1]; w1 = cw > 2 ? cwp[2] : 0u; w2 = cw > 3 ? cwp[3] : 0u; w3 = cw > 4 ? cwp[4] : 0u;
-    }
-    for (int k = 0; k < pb; k++) {
-        const int base = base0 + k * PASS;
-        if (base >= Nb) break;
-        bool skip0 = false;  // does a composite block write this thread's tile?
-        if (any) {
-            const int tx = (base % W) >> 4;  // PPT == 4: W % 4 == 0, the 4 pixels share one tile column
-            const int wi = tx >> 5;
-            const uint32_t word = cw <= 5 ? (wi == 0 ? w0 : wi == 1 ? w1 : wi == 2 ? w2 : w3) : cwp[1 + wi];
-            skip0 = (word >> (tx & 31)) & 1u;
-        } else if (!cover) {  // cover not precomputed (very large images): test the rects directly
-            const uint4* grect = a.g.rect + (size_t)v * P;
-            const int tx = (base % W) >> 4;
-            for (int i = 0; i < P; i++) {
-                const uint4 r = grect[i];
-                skip0 = skip0 || ((int)r.y <= band && band < (int)r.w && (int)r.x <= tx && tx < (int)r.z);
-            }
-        }
-        if (skip0) continue;
-        if (PPT == 4) store4<NT>(out + base, 0.0f, 0.0f, 0.0f, 0.0f);
-        else out[base] = 0.0f;
-        if (outT || outN) {  // debug planes of the reference's ImageState: T = 1, no contributor outside covered tiles
-#pragma unroll
-            for (int p = 0; p < PPT; p++) {
-                if (outT) outT[base + p] = 1.0f;
-                if (outN) outN[base + p] = 0u;
-            }
-        }
-    }
+    fwd_fill_role<PPT, NT>(a, xq, band_id, zid, gy, pb, cover);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1650,21 +1668,62 @@ struct BinView {
     int NT;
 };
 
-// binned forward: grid (Tx, Ty, V), thread = pixel (forward.cu:278-401)
-template <int CG>
-__global__ __launch_bounds__(256) void k_render_fwd_binned(FwdArgs a, BinView b)
+// cover rows of the binned path: bit (view, band, tile column) = "the tile's list is not empty" (same layout as the
+// rows k_geom_fwd writes for the small path: word 0 = any, then one bit per tile column).  grid (gy, V), one wavefront.
+__global__ __launch_bounds__(64) void k_bin_cover(int NT, int gx, int cw, size_t cap, const uint2* __restrict__ ranges,
+                                                  uint32_t* __restrict__ cover)
+{
+    const int band = blockIdx.x, v = blockIdx.y, lane = threadIdx.x;
+    uint32_t* row = cover + ((size_t)v * gridDim.x + band) * cw;
+    unsigned long long any = 0ull;
+    for (int w = 0; w * 64 < gx; w++) {
+        const int tx = w * 64 + lane;
+        bool ne = false;
+        if (tx < gx) {
+            const uint2 r = ranges[(size_t)v * NT + (size_t)band * gx + tx];
+            ne = min((size_t)r.y, cap) > min((size_t)r.x, cap);
+        }
+        const unsigned long long m = __ballot(ne);
+        any |= m;
+        if (lane == 0) {
+            if (1 + 2 * w < cw) row[1 + 2 * w] = (uint32_t)m;
+            if (2 + 2 * w < cw) row[2 + 2 * w] = (uint32_t)(m >> 32);
+        }
+    }
+    if (lane == 0) row[0] = any ? 1u : 0u;
+}
+
+// binned forward, "fill + sparse composite" like k_render_fwd_sparse: grid (fsplit + xc, gy, (C+1) * V).
+//   * fill role (x < fsplit): fwd_fill_role over the cover rows of k_bin_cover -- empty tiles (the vast majority
+//     of a skeleton scene) are zero-filled in long contiguous rows instead of 64-byte tile rows;
+//   * composite role (the xc extra blocks of every row): block -> (view, tile); a non-empty tile is composited
+//     thread-per-pixel over its sorted list exactly like forward.cu:278-401 and writes all C+1 planes.
+template <int CG, int PPT, bool NT>
+__global__ __launch_bounds__(256) void k_render_fwd_binned(FwdArgs a, BinView b, int gx, int gy, int fsplit, int pb,
+                                                           const uint32_t* __restrict__ cover)
 {
     __shared__ List<CG> L;
-    const int v = blockIdx.z, tid = threadIdx.x;
+    const int tid = threadIdx.x;
+    const int xq = blockIdx.x, band_id = blockIdx.y, zid = blockIdx.z;
+    if (xq < fsplit) {
+        fwd_fill_role<PPT, NT>(a, xq, band_id, zid, gy, pb, cover);
+        return;
+    }
+    const int xc = gridDim.x - fsplit;
+    const int cb = (zid * gy + band_id) * xc + (xq - fsplit);
+    const int v = cb / b.NT;
+    if (v >= (int)(gridDim.z / (a.C + 1))) return;
+    const int tile = cb - v * b.NT;
+    const int ty = tile / gx, tx = tile - ty * gx;
+    const uint2 range = b.ranges[(size_t)v * b.NT + tile];
+    const int total = (int)(min((size_t)range.y, b.cap) - min((size_t)range.x, b.cap));
+    if (total == 0) return;  // a fill block zeroes this tile
     const int P = a.P, C = a.C, W = a.W, H = a.H;
     const size_t HW = (size_t)H * W;
     const size_t go = (size_t)v * P;
-    const int gx = gridDim.x;
-    const int x = blockIdx.x * TILE + (tid & 15), y = blockIdx.y * TILE + (tid >> 4);
+    const int x = tx * TILE + (tid & 15), y = ty * TILE + (tid >> 4);
     const bool inside = x < W && y < H;
-    const uint2 range = b.ranges[(size_t)v * b.NT + blockIdx.y * gx + blockIdx.x];
     const unsigned long long* keys = b.keys + (size_t)v * b.cap;
-    const int total = (int)(min((size_t)range.y, b.cap) - min((size_t)range.x, b.cap));
     float T = 1.0f, inv = 0.0f, acc[CG];
 #pragma unroll
     for (int ch = 0; ch < CG; ch++) acc[ch] = 0.0f;
@@ -1850,6 +1909,25 @@ void launch_fwd_small(const FwdArgs& a, int V, int gy, hipStream_t st)
 }
 
 template <int CG>
+void launch_fwd_binned(const FwdArgs& a, const BinView& bv, int V, int gx, int gy, const uint32_t* cover, hipStream_t st)
+{
+    const int ppt = a.W % 4 == 0 ? 4 : 1;
+    const int passes = (TILE * a.W + 256 * ppt - 1) / (256 * ppt);
+    int pb = (int)((a.flags >> 8) & 0xff);
+    if (pb <= 0) pb = passes / 8 > 2 ? (passes + 4) / 8 : 2;
+    const int fsplit = (passes + pb - 1) / pb;
+    const int xc = (gx + a.C) / (a.C + 1);                            // (view, tile) composite blocks spread over the rows
+    dim3 grid(fsplit + xc, gy, (a.C + 1) * V);
+    const bool nt = !(a.flags & SKS_NO_NT_STORES);
+    if (a.W % 4 == 0) {
+        if (nt) hipLaunchKernelGGL((k_render_fwd_binned<CG, 4, true>), grid, dim3(256), 0, st, a, bv, gx, gy, fsplit, pb, cover);
+        else hipLaunchKernelGGL((k_render_fwd_binned<CG, 4, false>), grid, dim3(256), 0, st, a, bv, gx, gy, fsplit, pb, cover);
+    } else {
+        hipLaunchKernelGGL((k_render_fwd_binned<CG, 1, false>), grid, dim3(256), 0, st, a, bv, gx, gy, fsplit, pb, cover);
+    }
+}
+
+template <int CG>
 void launch_bwd_small(const BwdArgs& a, int V, int gy, bool dfeat, hipStream_t st)
 {
     (void)gy;
@@ -1947,14 +2025,16 @@ int sks_forward(int V, int P, int C, int W, int H, const float* viewmatrix, cons
     hipLaunchKernelGGL(k_bin_sort, dim3(NT, V), dim3(256), 0, st, NT, bin_capacity, b.ranges, b.keys);
     STAGE_CHECK("binning");
     BinView bv{ b.ranges, b.keys, bin_capacity, NT };
-    dim3 grid(gx, gy, V);
+    uint32_t* cover = geom_cover_ptr(geom, V, P);
+    const int cw = cover_cw(W);
+    hipLaunchKernelGGL(k_bin_cover, dim3(gy, V), dim3(64), 0, st, NT, gx, cw, bin_capacity, b.ranges, cover);
     {
         ProfScope prof(0, st);
         switch (cg) {
-            case 4: hipLaunchKernelGGL((k_render_fwd_binned<4>), grid, dim3(256), 0, st, a, bv); break;
-            case 16: hipLaunchKernelGGL((k_render_fwd_binned<16>), grid, dim3(256), 0, st, a, bv); break;
-            case 20: hipLaunchKernelGGL((k_render_fwd_binned<20>), grid, dim3(256), 0, st, a, bv); break;
-            default: hipLaunchKernelGGL((k_render_fwd_binned<32>), grid, dim3(256), 0, st, a, bv); break;
+            case 4: launch_fwd_binned<4>(a, bv, V, gx, gy, cover, st); break;
+            case 16: launch_fwd_binned<16>(a, bv, V, gx, gy, cover, st); break;
+            case 20: launch_fwd_binned<20>(a, bv, V, gx, gy, cover, st); break;
+            default: launch_fwd_binned<32>(a, bv, V, gx, gy, cover, st); break;
         }
     }
     STAGE_CHECK("render(binned)");
