@@ -1528,16 +1528,25 @@ __global__ __launch_bounds__(256) void k_geom_bwd(GeomBwdArgs a, ViewTan vt)
 // identifyTileRanges (rasterizer_impl.cu:70-138, 280-320).  Per tile the reference's sorted order is
 // (depth bits, Gaussian index) ascending (stable LSD sort, index-major emission), reproduced exactly.
 // ------------------------------------------------------------------------------------------------------------
+// BIN_SUB lanes share one Gaussian and stride over the tiles of its rect, so that the atomics of a rect are in flight
+// together instead of one after the other (the scatter's atomics return a value: ~1-2 us each when serialised).
+constexpr int BIN_SUB = 8;
+
 __global__ void k_bin_count(int P, int NT, int gx, const uint4* __restrict__ rect, uint32_t* __restrict__ count)
 {
-    const int idx = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y;
+    const int idx = t / BIN_SUB, sub = t % BIN_SUB;
     if (idx >= P) return;
     const uint4 r = rect[(size_t)v * P + idx];
-    for (unsigned y = r.y; y < r.w; y++)
-        for (unsigned x = r.x; x < r.z; x++) atomicAdd(&count[(size_t)v * NT + y * gx + x], 1u);
+    const int wt = (int)(r.z - r.x), n = wt * (int)(r.w - r.y);
+    for (int i = sub; i < n; i += BIN_SUB) {
+        const int yy = i / wt;
+        atomicAdd(&count[(size_t)v * NT + (r.y + yy) * gx + r.x + (i - yy * wt)], 1u);
+    }
 }
 
-// one 1024-thread workgroup per view: exclusive scan over tiles in tile-id order
+// one 1024-thread workgroup per view: exclusive scan over tiles in tile-id order.  Thread t owns the `per`
+// consecutive tiles starting at t * per (per a multiple of 4: 16-byte loads and stores).
 __global__ __launch_bounds__(1024) void k_bin_scan(int NT, const uint32_t* __restrict__ count, uint32_t* __restrict__ cursor,
                                                     uint2* __restrict__ ranges, int* __restrict__ nrend, int V,
                                                     int* __restrict__ nrend_user)
@@ -1545,10 +1554,18 @@ __global__ __launch_bounds__(1024) void k_bin_scan(int NT, const uint32_t* __res
     __shared__ uint32_t s_part[1024];
     const int v = blockIdx.x, tid = threadIdx.x;
     const uint32_t* cnt = count + (size_t)v * NT;
-    const int per = (NT + 1023) / 1024;
-    const int b = tid * per, e = min(NT, b + per);
+    const int per = (((NT + 1023) / 1024) + 3) & ~3;
+    const int b = min(NT, tid * per), e = min(NT, b + per);
+    const bool vec = (NT & 3) == 0;   // rows stay 16-byte aligned
     uint32_t sum = 0;
-    for (int i = b; i < e; i++) sum += cnt[i];
+    if (vec) {
+        for (int i = b; i < e; i += 4) {
+            const uint4 c = *reinterpret_cast<const uint4*>(cnt + i);
+            sum += c.x + c.y + c.z + c.w;
+        }
+    } else {
+        for (int i = b; i < e; i++) sum += cnt[i];
+    }
     s_part[tid] = sum;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
@@ -1558,11 +1575,25 @@ __global__ __launch_bounds__(1024) void k_bin_scan(int NT, const uint32_t* __res
         __syncthreads();
     }
     uint32_t run = tid ? s_part[tid - 1] : 0;
-    for (int i = b; i < e; i++) {
-        const uint32_t c = cnt[i];
-        cursor[(size_t)v * NT + i] = run;
-        ranges[(size_t)v * NT + i] = c ? make_uint2(run, run + c) : make_uint2(0, 0);  // memset-0 for empty tiles
-        run += c;
+    uint32_t* cur = cursor + (size_t)v * NT;
+    uint2* rng = ranges + (size_t)v * NT;
+    if (vec) {
+        for (int i = b; i < e; i += 4) {
+            const uint4 c = *reinterpret_cast<const uint4*>(cnt + i);
+            const uint32_t r0 = run, r1 = r0 + c.x, r2 = r1 + c.y, r3 = r2 + c.z;
+            run = r3 + c.w;
+            *reinterpret_cast<uint4*>(cur + i) = make_uint4(r0, r1, r2, r3);
+            // (0, 0) for empty tiles, like the reference's zero-initialised ranges
+            *reinterpret_cast<uint4*>(rng + i) = make_uint4(c.x ? r0 : 0u, c.x ? r1 : 0u, c.y ? r1 : 0u, c.y ? r2 : 0u);
+            *reinterpret_cast<uint4*>(rng + i + 2) = make_uint4(c.z ? r2 : 0u, c.z ? r3 : 0u, c.w ? r3 : 0u, c.w ? run : 0u);
+        }
+    } else {
+        for (int i = b; i < e; i++) {
+            const uint32_t c = cnt[i];
+            cur[i] = run;
+            rng[i] = c ? make_uint2(run, run + c) : make_uint2(0, 0);
+            run += c;
+        }
     }
     if (tid == 1023) {
         nrend[v] = (int)s_part[1023];
@@ -1574,53 +1605,79 @@ __global__ void k_bin_scatter(int P, int NT, int gx, size_t cap, const uint4* __
                               const float4* __restrict__ xyd, uint32_t* __restrict__ cursor,
                               unsigned long long* __restrict__ keys, int* __restrict__ overflow)
 {
-    const int idx = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y;
+    const int idx = t / BIN_SUB, sub = t % BIN_SUB;
     if (idx >= P) return;
     const size_t o = (size_t)v * P + idx;
     const uint4 r = rect[o];
     const unsigned long long key = ((unsigned long long)__float_as_uint(xyd[o].z) << 32) | (unsigned)idx;
-    for (unsigned y = r.y; y < r.w; y++)
-        for (unsigned x = r.x; x < r.z; x++) {
-            const uint32_t slot = atomicAdd(&cursor[(size_t)v * NT + y * gx + x], 1u);
-            if (slot < cap) keys[(size_t)v * cap + slot] = key;
-            else *overflow = 1;
-        }
+    const int wt = (int)(r.z - r.x), n = wt * (int)(r.w - r.y);
+    for (int i = sub; i < n; i += BIN_SUB) {
+        const int yy = i / wt;
+        const uint32_t slot = atomicAdd(&cursor[(size_t)v * NT + (r.y + yy) * gx + r.x + (i - yy * wt)], 1u);
+        if (slot < cap) keys[(size_t)v * cap + slot] = key;
+        else *overflow = 1;
+    }
 }
 
-// per-tile ascending sort of 64-bit keys; all-ascending bitonic network with virtual +inf padding.
+// per-tile ascending sort of the 64-bit keys.  One workgroup takes 4 consecutive tiles: a wavefront rank-sorts a list
+// of up to 64 keys in registers (one key per lane; the rank of a key is the number of smaller ones -- keys are
+// distinct, the low word is the Gaussian index); longer lists go through the whole workgroup's all-ascending
+// bitonic network with virtual +inf padding (in LDS up to SORT_LDS keys, else in place).
 constexpr int SORT_LDS = 2048;
 __global__ __launch_bounds__(256) void k_bin_sort(int NT, size_t cap, const uint2* __restrict__ ranges,
                                                    unsigned long long* __restrict__ keys)
 {
     __shared__ unsigned long long s[SORT_LDS];
-    const int t = blockIdx.x, v = blockIdx.y, tid = threadIdx.x;
-    const uint2 r = ranges[(size_t)v * NT + t];
-    if (r.y <= r.x + 1 || r.y > cap) return;
-    const int n = (int)(r.y - r.x);
-    unsigned long long* g = keys + (size_t)v * cap + r.x;
-    unsigned long long* a = g;
-    const bool in_lds = n <= SORT_LDS;
-    if (in_lds) {
-        for (int i = tid; i < n; i += 256) s[i] = g[i];
-        a = s;
-        __syncthreads();
-    }
-    int N = 1;
-    while (N < n) N <<= 1;
-    for (int k = 2; k <= N; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < N; i += 256) {
-                const int p = (j == (k >> 1)) ? (i ^ (k - 1)) : (i ^ j);  // flip on the first sub-step, then disperse
-                if (p > i && p < n) {
-                    const unsigned long long x = a[i], y = a[p];
-                    if (x > y) { a[i] = y; a[p] = x; }
-                }
+    const int v = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int t_w = blockIdx.x * 4 + wv;
+    if (t_w < NT) {
+        const uint2 r = ranges[(size_t)v * NT + t_w];
+        const int n = (int)(r.y - r.x);
+        if (r.y > r.x + 1 && r.y <= cap && n <= 64) {
+            unsigned long long* g = keys + (size_t)v * cap + r.x;
+            const unsigned long long key = lane < n ? g[lane] : ~0ull;
+            int rank = 0;
+            for (int j = 0; j < n; j++) {
+                const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)key, j);
+                const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(key >> 32), j);
+                rank += ((((unsigned long long)hi) << 32) | lo) < key ? 1 : 0;
             }
-            __syncthreads();
+            if (lane < n) g[rank] = key;
         }
     }
-    if (in_lds)
-        for (int i = tid; i < n; i += 256) g[i] = s[i];
+    for (int q = 0; q < 4; q++) {   // the long lists among this workgroup's 4 tiles (uniform control flow)
+        const int t = blockIdx.x * 4 + q;
+        if (t >= NT) break;
+        const uint2 r = ranges[(size_t)v * NT + t];
+        if (r.y > cap || r.y <= r.x + 64) continue;
+        const int n = (int)(r.y - r.x);
+        unsigned long long* g = keys + (size_t)v * cap + r.x;
+        unsigned long long* a = g;
+        const bool in_lds = n <= SORT_LDS;
+        __syncthreads();
+        if (in_lds) {
+            for (int i = tid; i < n; i += 256) s[i] = g[i];
+            a = s;
+            __syncthreads();
+        }
+        int N = 1;
+        while (N < n) N <<= 1;
+        for (int k = 2; k <= N; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = tid; i < N; i += 256) {
+                    const int p = (j == (k >> 1)) ? (i ^ (k - 1)) : (i ^ j);  // flip on the first sub-step, then disperse
+                    if (p > i && p < n) {
+                        const unsigned long long x = a[i], y = a[p];
+                        if (x > y) { a[i] = y; a[p] = x; }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        if (in_lds)
+            for (int i = tid; i < n; i += 256) g[i] = s[i];
+    }
 }
 
 __global__ void k_export_lists(int NT, size_t cap, const uint2* __restrict__ ranges, const unsigned long long* __restrict__ keys,
@@ -2018,11 +2075,11 @@ int sks_forward(int V, int P, int C, int W, int H, const float* viewmatrix, cons
     Bin b = bin_from(binning, V, NT, bin_capacity);
     HIP_TRY(hipMemsetAsync(b.count, 0, (size_t)V * NT * 4, st));
     HIP_TRY(hipMemsetAsync(b.nrend + V, 0, 4, st));
-    hipLaunchKernelGGL(k_bin_count, dim3((P + 255) / 256, V), dim3(256), 0, st, P, NT, gx, g.rect, b.count);
+    hipLaunchKernelGGL(k_bin_count, dim3((P * BIN_SUB + 255) / 256, V), dim3(256), 0, st, P, NT, gx, g.rect, b.count);
     hipLaunchKernelGGL(k_bin_scan, dim3(V), dim3(1024), 0, st, NT, b.count, b.cursor, b.ranges, b.nrend, V, num_rendered_dev);
-    hipLaunchKernelGGL(k_bin_scatter, dim3((P + 255) / 256, V), dim3(256), 0, st, P, NT, gx, bin_capacity, g.rect, g.xyd,
+    hipLaunchKernelGGL(k_bin_scatter, dim3((P * BIN_SUB + 255) / 256, V), dim3(256), 0, st, P, NT, gx, bin_capacity, g.rect, g.xyd,
                        b.cursor, b.keys, b.nrend + V);
-    hipLaunchKernelGGL(k_bin_sort, dim3(NT, V), dim3(256), 0, st, NT, bin_capacity, b.ranges, b.keys);
+    hipLaunchKernelGGL(k_bin_sort, dim3((NT + 3) / 4, V), dim3(256), 0, st, NT, bin_capacity, b.ranges, b.keys);
     STAGE_CHECK("binning");
     BinView bv{ b.ranges, b.keys, bin_capacity, NT };
     uint32_t* cover = geom_cover_ptr(geom, V, P);

@@ -346,6 +346,21 @@ def test_binned_long_tile_lists(device):
         util.assert_close("dL_dopacity", g["opacities"][0].cpu(), b["dL_dopacity"])
         util.assert_close("dL_dscales", g["scales"][0].cpu(), b["dL_dscales"])
         util.assert_close("dL_dfeatures", g["features"][0].cpu(), b["dL_dcolors"])
+    # a list longer than the sort kernel's LDS capacity (2048 keys): sorted in place in global memory
+    c = util.make_case(seed=12, W=32, H=32, scale_log=5.0, n_views=1, n_skeletons=130, pitch=5.0, opac=0.01, fxmul=0.2)
+    views = R.ViewBatch.from_cameras([cam.to(dev) for cam in c.cams])
+    args = (t(c.means, dev), t(c.feat, dev), t(c.opac, dev), t(c.scales, dev), t(c.quats, dev), None)
+    color, inv, radii, st = R.forward_views(views, *args)      # P = 2210 > 256: binned path
+    o = util.oracle_forward(c, 0)
+    lens = o["ranges"][:, 1].astype(np.int64) - o["ranges"][:, 0].astype(np.int64)
+    assert lens.max() > 2048, lens
+    pl, rg, nr = R.export_lists(st)
+    assert np.array_equal(pl[0, :o["R"]].cpu().numpy().astype(np.uint32), o["point_list"])
+    assert np.array_equal(color[0].cpu().numpy(), o["color"])
+    g = R.backward_views(st, *args, t(c.dL_color, dev), t(c.dL_inv, dev))
+    b = util.oracle_backward(c, 0, o)
+    util.assert_close("dL_dmeans3D", g["means3D"][0].cpu(), b["dL_dmeans3D"])
+    util.assert_close("dL_dopacity", g["opacities"][0].cpu(), b["dL_dopacity"])
 
 
 def test_edge_cases(device):
