@@ -147,11 +147,53 @@ __device__ __forceinline__ void cov2d(const float mean[3], float fx, float fy, f
     c.cov = m3mul(m3mul(m3T(c.T), m3T(c.Vrk)), c.T);
 }
 
+// Sum over the 64 lanes of a wavefront, returned in EVERY lane.  Inside each row of 16 lanes the partial sums move
+// with DPP modifiers (VALU speed; a __shfl is a ds_bpermute through the LDS crossbar, ~10x the latency, and a
+// reduction is a chain of them); the four row sums are read with v_readlane.  Fixed order -> reproducible.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v)
 {
+    v += dpp_move<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_move<0x124>(v);   // row_ror:4
+    v += dpp_move<0x128>(v);   // row_ror:8  -> every lane holds the sum of its row of 16
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
+// Eight sums over the wavefront at once: on return lane L (L < 8) -- in fact every lane with L % 8 == idx -- holds the
+// total of v[idx] over the 64 lanes.  Each of the first three steps halves the number of live values (a lane keeps
+// the value its lane-index bit selects and hands the other to its partner), so the whole thing costs ~25 VALU ops and
+// two cross-row shuffles instead of eight full reductions.
+__device__ __forceinline__ float wave_sum8(const float (&v)[8])
+{
+    const int lane = threadIdx.x & 63;
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
+    float w[4];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    return v;  // valid in lane 0
+    for (int p = 0; p < 4; p++) {   // partner = lane ^ 1
+        const float keep = b0 ? v[2 * p + 1] : v[2 * p], give = b0 ? v[2 * p] : v[2 * p + 1];
+        w[p] = keep + dpp_move<0xB1>(give);
+    }
+    float x[2];
+#pragma unroll
+    for (int p = 0; p < 2; p++) {   // partner = lane ^ 2
+        const float keep = b1 ? w[2 * p + 1] : w[2 * p], give = b1 ? w[2 * p] : w[2 * p + 1];
+        x[p] = keep + dpp_move<0x4E>(give);
+    }
+    // lane i now holds value (i & 3) of x[0] (values 0..3) / x[1] (values 4..7), summed over its quad
+    float z = (b2 ? x[1] : x[0]) + dpp_move<0x124>(b2 ? x[0] : x[1]);   // from lane i - 4 (mod 16): the other bit-2 class
+    z += dpp_move<0x128>(z);                                             // from lane i - 8 (mod 16): the row's other two quads
+    z += __shfl_xor(z, 16, 64);
+    z += __shfl_xor(z, 32, 64);
+    return z;
 }
 
 }  // namespace sks

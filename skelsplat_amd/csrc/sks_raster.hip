@@ -651,11 +651,14 @@ __device__ __forceinline__ void bwd_sweep(const List<CG>& L, int n, int klast /*
             vals[4] = -0.5f * gdy * dy * dL_dG;
             vals[5] = G * dL_dalpha;
         }
+        static_assert(NVL % 8 == 0 && NACC == 8, "wave_sum8 works on groups of eight values");
 #pragma unroll
-        for (int j = 0; j < NVL; j++) {
-            if (j == 7) continue;
-            const float r = wave_sum(vals[j]);
-            if (lane == 0) atomicAdd(&s_acc[k * NVL + j], r);
+        for (int j0 = 0; j0 < NVL; j0 += 8) {   // eight sums at a time; lane j of 0..7 ends up with the total of value j0 + j
+            float grp[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) grp[j] = vals[j0 + j];
+            const float r = wave_sum8(grp);
+            if (lane < 8 && !(j0 == 0 && lane == 7)) atomicAdd(&s_acc[k * NVL + j0 + lane], r);
         }
     }
 }
@@ -1825,6 +1828,7 @@ __global__ __launch_bounds__(256) void k_render_bwd_binned(BwdArgs a, BinView b)
     __shared__ float s_acc[LCAP * NVL];
     __shared__ unsigned s_chm;
     __shared__ int s_chan[SKS_MAX_CHANNELS];
+    __shared__ float s_full[LCAP * SKS_MAX_CHANNELS];   // full feature rows of a single-batch list
     const int v = blockIdx.z, tid = threadIdx.x;
     const int P = a.P, C = a.C, W = a.W, H = a.H;
     const size_t HW = (size_t)H * W;
@@ -1841,11 +1845,33 @@ __global__ __launch_bounds__(256) void k_render_bwd_binned(BwdArgs a, BinView b)
     const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);
     const int NVS = NACC + C;
 
-    // pass 0: the active channels of this tile's list -> s_chan[0..nc)
+    // pass 0: the active channels of this tile's list -> s_chan[0..nc).  A list that fits one LDS batch (the norm) is
+    // fetched from global memory exactly once: records into L, full feature rows into s_full, from which every
+    // channel group below is compacted; longer lists take a light extra pass over the features and are staged per
+    // batch and group.
     const bool all_ch = DFEAT || a.bg != nullptr;
+    const bool single = total <= LCAP;
     if (tid == 0) s_chm = 0u;
     __syncthreads();
-    if (!all_ch) {
+    if (single) {
+        if (tid < total) {
+            const int id = (int)(unsigned)keys[tid];
+            const float4 xyd = a.g.xyd[go + id];
+            L.xy[tid] = make_float2(xyd.x, xyd.y);
+            L.co[tid] = a.g.co[go + id];
+            L.invd[tid] = xyd.w;
+            L.id[tid] = id;
+            const float* f = a.features + (size_t)id * C;
+            unsigned m = 0u;
+            for (int ch = 0; ch < C; ch++) {
+                const float fv = f[ch];
+                s_full[tid * C + ch] = fv;
+                m |= fv != 0.0f ? (1u << ch) : 0u;
+            }
+            if (m && !all_ch) atomicOr(&s_chm, m);
+        }
+        __syncthreads();
+    } else if (!all_ch) {
         unsigned m = 0u;
         for (int i = tid; i < total; i += 256) {
             const float* f = a.features + (size_t)(unsigned)keys[i] * C;
@@ -1882,7 +1908,16 @@ __global__ __launch_bounds__(256) void k_render_bwd_binned(BwdArgs a, BinView b)
             for (int off = 0; off < total; off += LCAP) {
                 if (__syncthreads_count(done) == 256) break;
                 const int cnt = min(LCAP, total - off);
-                stage_batch<NB>(L, cnt, keys + off, P, C, a.g.co + go, a.g.xyd + go, a.features, chan, ncg);
+                if (single) {
+                    if (staged != grp) {   // (the group's features are still in place when pass 2 of it follows)
+                        if (tid < cnt) {
+#pragma unroll
+                            for (int j = 0; j < NB; j++) L.feat[tid * NB + j] = j < ncg ? s_full[tid * C + chan[j]] : 0.0f;
+                        }
+                    }
+                } else {
+                    stage_batch<NB>(L, cnt, keys + off, P, C, a.g.co + go, a.g.xyd + go, a.features, chan, ncg);
+                }
                 staged = grp * nb + off / LCAP;
                 __syncthreads();
                 int klast = -1;
@@ -1906,7 +1941,14 @@ __global__ __launch_bounds__(256) void k_render_bwd_binned(BwdArgs a, BinView b)
             const int off = bi * LCAP;
             const int cnt = min(LCAP, total - off);
             if (staged != grp * nb + bi) {
-                stage_batch<NB>(L, cnt, keys + off, P, C, a.g.co + go, a.g.xyd + go, a.features, chan, ncg);
+                if (single) {
+                    if (tid < cnt) {
+#pragma unroll
+                        for (int j = 0; j < NB; j++) L.feat[tid * NB + j] = j < ncg ? s_full[tid * C + chan[j]] : 0.0f;
+                    }
+                } else {
+                    stage_batch<NB>(L, cnt, keys + off, P, C, a.g.co + go, a.g.xyd + go, a.features, chan, ncg);
+                }
                 staged = grp * nb + bi;
             }
             for (int i = tid; i < cnt * NVL; i += 256) s_acc[i] = 0.0f;
