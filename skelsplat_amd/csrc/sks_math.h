@@ -168,6 +168,31 @@ __device__ __forceinline__ float wave_sum(float v)
     return (r0 + r1) + (r2 + r3);
 }
 
+template <int CTRL>
+__device__ __forceinline__ double dpp_move_d(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)((unsigned long long)b >> 32), CTRL, 0xf, 0xf, false);
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+__device__ __forceinline__ double readlane_d(double v, int lane)
+{
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)b >> 32), lane);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// double-precision twin of wave_sum (same scheme, returned in every lane)
+__device__ __forceinline__ double wave_sum_d(double v)
+{
+    v += dpp_move_d<0xB1>(v);
+    v += dpp_move_d<0x4E>(v);
+    v += dpp_move_d<0x124>(v);
+    v += dpp_move_d<0x128>(v);
+    return (readlane_d(v, 0) + readlane_d(v, 16)) + (readlane_d(v, 32) + readlane_d(v, 48));
+}
+
 // Eight sums over the wavefront at once: on return lane L (L < 8) -- in fact every lane with L % 8 == idx -- holds the
 // total of v[idx] over the 64 lanes.  Each of the first three steps halves the number of live values (a lane keeps
 // the value its lane-index bit selects and hands the other to its partner), so the whole thing costs ~25 VALU ops and

@@ -9,6 +9,7 @@
 #include <stdio.h>
 
 #include "../../include/skelsplat_hip.h"
+#include "sks_math.h"
 
 // the error text lives in sks_raster.hip's thread-local buffer (sks_last_error); this TU reports through it
 extern "C" void sks_set_error_(const char* msg);
@@ -33,12 +34,7 @@ int fail2(int code, const char* fmt, ...)
         if (e_ != hipSuccess) return fail2((int)e_, "%s: %s", #expr, hipGetErrorString(e_));  \
     } while (0)
 
-__device__ __forceinline__ double wave_sum_d(double v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    return v;
-}
+using sks::wave_sum_d;
 
 // ------------------------------------------------------------------------------------------------------------
 // masked L2: per view  N = #{gt > 0 or render > 0},  S = sum over that mask of (render - gt)^2,

@@ -1336,8 +1336,8 @@ __global__ __launch_bounds__(256) void k_geom_bwd(GeomBwdArgs a, ViewTan vt)
                 pN += (double)acc[8 * a.nsplit + sp];
             }
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { pS += __shfl_down(pS, off, 64); pN += __shfl_down(pN, off, 64); }
+        pS = wave_sum_d(pS);
+        pN = wave_sum_d(pN);
         if ((threadIdx.x & 63) == 0) { s_l[0][threadIdx.x >> 6] = pS; s_l[1][threadIdx.x >> 6] = pN; }
         __syncthreads();
         if (threadIdx.x == 0) {
