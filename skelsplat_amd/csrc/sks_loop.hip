@@ -9,6 +9,7 @@
 //                 (exp / normalize / sigmoid Jacobians), times the per-view 1/N of the masked-L2 loss;
 //   k_loop_adam : slot update + mean over the V view slots + limb-symmetry gradient + LR schedule + Adam, in place.
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
 
@@ -72,6 +73,7 @@ struct AdamArgs {
     int* counters;             // [0] iteration (advanced by acc_steps), [1] Adam step count
     int acc_steps;
     double lr_init, lr_final, lr_delay_mult; int lr_delay_steps, lr_max_steps;  // xyz schedule (general_utils.py:38-71)
+    double log_lr_init, log_lr_final;   // np.log of the two, taken on the host like the reference does
     double lr_scaling, lr_rotation, lr_opacity;
     double beta1, beta2, eps;
     float lambda_consistency;
@@ -102,25 +104,39 @@ __global__ __launch_bounds__(256) void k_loop_adam(AdamArgs a)
     if (live) {
         s_xyz[3 * p] = a.xyz[3 * p]; s_xyz[3 * p + 1] = a.xyz[3 * p + 1]; s_xyz[3 * p + 2] = a.xyz[3 * p + 2];
     }
-    // LR schedule + bias corrections, in double like the host code (train.py:134, quirk Q9); one thread computes them
+    // LR schedule + bias corrections, in double like the host code (train.py:134, quirk Q9).  The four double
+    // transcendentals are a few hundred dependent instructions each; one lane of each of the four wavefronts takes
+    // one of them so that they run side by side (different lanes of ONE wavefront would serialise).
     __shared__ float s_hyp[6];  // step sizes xyz / scaling / rotation / opacity, sqrt(bias_correction2), spare
-    if (p == 0) {
-        double lr_xyz = 0.0;
-        if (!(a.lr_init == 0.0 && a.lr_final == 0.0)) {
+    __shared__ double s_d[4];   // delay factor, exp(interpolated log lr), beta1^step, beta2^step
+    if ((p & 63) == 0) {
+        const int w = p >> 6;
+        const bool sched = !(a.lr_init == 0.0 && a.lr_final == 0.0);
+        if (w == 0) {
             double delay = 1.0;
-            if (a.lr_delay_steps > 0) {
+            if (sched && a.lr_delay_steps > 0) {
                 const double c = fmin(fmax((double)it1 / (double)a.lr_delay_steps, 0.0), 1.0);
                 delay = a.lr_delay_mult + (1.0 - a.lr_delay_mult) * sin(0.5 * 3.14159265358979323846 * c);
             }
+            s_d[0] = delay;
+        } else if (w == 1) {
             const double t = fmin(fmax((double)it1 / (double)a.lr_max_steps, 0.0), 1.0);
-            lr_xyz = delay * exp(log(a.lr_init) * (1.0 - t) + log(a.lr_final) * t);
+            s_d[1] = sched ? exp(a.log_lr_init * (1.0 - t) + a.log_lr_final * t) : 0.0;
+        } else if (w == 2) {
+            s_d[2] = pow(a.beta1, (double)step);
+        } else {
+            s_d[3] = pow(a.beta2, (double)step);
         }
-        const double bc1 = 1.0 - pow(a.beta1, (double)step);
+    }
+    __syncthreads();
+    if (p == 0) {
+        const double lr_xyz = s_d[0] * s_d[1];
+        const double bc1 = 1.0 - s_d[2];
         s_hyp[0] = (float)(lr_xyz / bc1);
         s_hyp[1] = (float)(a.lr_scaling / bc1);
         s_hyp[2] = (float)(a.lr_rotation / bc1);
         s_hyp[3] = (float)(a.lr_opacity / bc1);
-        s_hyp[4] = (float)sqrt(1.0 - pow(a.beta2, (double)step));
+        s_hyp[4] = (float)sqrt(1.0 - s_d[3]);
     }
     __syncthreads();
     // limb-symmetry loss gradient: L = lambda * (| |la| - |ra| | + | |ll| - |rl| |)  (loss_utils.py:226-250);
@@ -214,6 +230,8 @@ int sks_loop_adam_step(int V, int P, const float* grads, float* slots, unsigned 
     a.xyz = xyz; a.scaling = scaling; a.rotation = rotation; a.opacity = opacity; a.m = exp_avg; a.vv = exp_avg_sq;
     a.counters = counters; a.acc_steps = acc_steps;
     a.lr_init = lr_sched[0]; a.lr_final = lr_sched[1]; a.lr_delay_mult = lr_sched[2];
+    a.log_lr_init = lr_sched[0] > 0.0 ? log(lr_sched[0]) : 0.0;
+    a.log_lr_final = lr_sched[1] > 0.0 ? log(lr_sched[1]) : 0.0;
     a.lr_delay_steps = (int)lr_sched[3]; a.lr_max_steps = (int)lr_sched[4];
     a.lr_scaling = lrs[0]; a.lr_rotation = lrs[1]; a.lr_opacity = lrs[2];
     a.beta1 = adam[0]; a.beta2 = adam[1]; a.eps = adam[2];

@@ -1,0 +1,21 @@
+#!/bin/bash
+# Collects the evidence kept under profiles/: per-kernel durations (rocprofv3 --kernel-trace --stats) and HBM
+# traffic (PMC WRITE_SIZE / FETCH_SIZE, each in its own pass, never combined with tracing domains other than
+# --kernel-trace).  Run on the GPU box from the repo root:  bash tools/profile_round.sh r01
+# Outputs land in gpurun_out/prof/; tools/make_profiles.py turns them into profiles/<round>_*.
+set -u
+R=${1:-r01}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/prof
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+for WL in h36m panoptic; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${WL}_stats" -o stats -- python3 "$ROOT/bench.py" --workload $WL --steps 50 --warmup 5 --no-cpu-baseline > "$OUT/${WL}_bench_under_rocprof.json" 2> "$OUT/${WL}_stats.log"
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/${WL}_w" -o w -- python3 "$ROOT/bench.py" --workload $WL --steps 20 --warmup 3 --no-cpu-baseline --no-prof > /dev/null 2> "$OUT/${WL}_w.log"
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/${WL}_f" -o f -- python3 "$ROOT/bench.py" --workload $WL --steps 20 --warmup 3 --no-cpu-baseline --no-prof > /dev/null 2> "$OUT/${WL}_f.log"
+done
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stress_stats" -o stats -- python3 "$ROOT/tools/bench_stress.py" > "$OUT/stress.log" 2>&1
+cd "$ROOT"
+python3 bench.py > "$OUT/h36m_bench.json" 2> "$OUT/h36m_bench.log"
+python3 bench.py --workload panoptic --steps 50 --warmup 5 > "$OUT/panoptic_bench.json" 2> "$OUT/panoptic_bench.log"
+find "$OUT" -name "*.csv" | head -40
