@@ -210,6 +210,19 @@ def main():
             extras["scene_500it_ms_hipgraph"] = 1e3 * ts
             extras["loop_views_per_s_scene_hipgraph"] = 500 / ts
             extras["grad_step_ms_scene_hipgraph"] = 1e3 * ts / (500 / V)
+            # frames streamed through one loop object (train.py:74-99 per frame: re-initialise the Gaussians, generate the
+            # heat-maps from the 2D detections, 500 iterations), everything in place so the hipGraphs are reused
+            p2d = torch.tensor(ref_scene.poses_2d, device=dev)
+            pts = torch.tensor(ref_scene.pose_3d_init, device=dev, dtype=torch.float32)
+            loop.new_scene(pts, poses_2d=p2d)
+            loop.run(500)
+            torch.cuda.synchronize()
+            tf = time.perf_counter()
+            for _ in range(5):
+                loop.new_scene(pts, poses_2d=p2d)
+                loop.run(500)
+            torch.cuda.synchronize()
+            extras["frame_stream_ms"] = 1e3 * (time.perf_counter() - tf) / 5
         except Exception as e:
             extras["loop_error"] = repr(e)[:200]
 

@@ -45,15 +45,13 @@ def main():
     loop.run(args.iters)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    # a second scene reuses the captured graphs (what a dataset-scale run sees per frame)
-    gm2 = GaussianModel().create_from_points(init, sc.spatial_lr_scale, sc.n_joints, scene_type=args.dataset, device=dev)
-    with torch.no_grad():
-        for a, b in zip((gm._xyz, gm._scaling, gm._rotation, gm._opacity), (gm2._xyz, gm2._scaling, gm2._rotation, gm2._opacity)):
-            keep = a.detach().clone(); a.copy_(b); b.copy_(keep)     # gm <- fresh parameters, gm2 <- result
-        loop.exp_avg.zero_(); loop.exp_avg_sq.zero_(); loop.counters.zero_(); loop.accumulated_grads.zero_()
-    loop.iteration = 0
+    # a second frame seen by the same cameras reuses the captured graphs (what a dataset-scale run sees per frame):
+    # parameters, optimiser state, heat-maps and tile statistics are re-initialised in place
+    result = [p.detach().clone() for p in (gm._xyz, gm._scaling, gm._rotation, gm._opacity)]
+    gm2 = type("R", (), dict(_xyz=result[0], _scaling=result[1], _rotation=result[2], _opacity=result[3]))
     torch.cuda.synchronize()
     t1 = time.perf_counter()
+    loop.new_scene(init, poses_2d=sc.poses_2d)
     loop.run(args.iters)
     torch.cuda.synchronize()
     dt2 = time.perf_counter() - t1

@@ -116,6 +116,16 @@ int sks_export_lists(int V, int W, int H, const void* binning, size_t bin_capaci
 int sks_masked_l2(int V, size_t n_per_view, const float* render, const float* gt, float* dL_unscaled, double* sums,
                   void* stream);
 
+/* Pseudo-GT heat-maps of a scene (utils/general_utils.py:175-304 generate_heatmaps + normalize_heatmaps).  The
+ * reference filters one 255 impulse per joint plane with cupyx gaussian_filter (V*J full-resolution calls) and
+ * min-max normalises each plane; the filtered impulse is separable, so a plane is
+ *   out[y][x] = (row[y] * col[x] - cmin) / den
+ * with row = 255 * (1-D impulse response along y), col = the one along x, cmin = min(row) * min(col) and
+ * den = max(row) * max(col) - cmin + 1e-8 (all fp32, in this order).  One pass, one write of (V,J,H,W).
+ * row (V,J,H), col (V,J,W), cmin (V,J), den (V,J), out (V,J,H,W). */
+int sks_heatmaps(int V, int J, int W, int H, const float* row, const float* col, const float* cmin, const float* den,
+                 float* out, void* stream);
+
 /* Replaces fusedssim (submodules/fused-ssim/ssim.cu:368-404, binding ext.cpp): img1, img2, ssim_map and the three
  * optional partial-derivative maps (train == true) are (B,CH,H,W) fp32; "same" zero padding. */
 int sks_fused_ssim_fwd(int B, int CH, int H, int W, float C1, float C2, const float* img1, const float* img2,

@@ -37,6 +37,7 @@ SIGNATURES = {
     "sks_fused_ssim_fwd": (_i, [_i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sks_fused_ssim_bwd": (_i, [_i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sks_knn3_meandist2": (_i, [_i, _vp, _vp, _vp]),
+    "sks_heatmaps": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sks_gt_tile_stats": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "sks_geometry": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _u, _vp, _vp, _vp]),
     "sks_backward_fused_loss": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _u,

@@ -371,6 +371,41 @@ int ssim_tiles_per_block(int tiles_x, int tiles_y, int B, int CH)
     while (txb < 8 && CH * txb < 4 && (long long)((tiles_x + 2 * txb - 1) / (2 * txb)) * tiles_y * B >= 3000) txb *= 2;
     return txb;
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// heat-map planes: out[y][x] = (row[y] * col[x] - cmin) / den, one streaming write.  grid (x chunks of 1024 px,
+// 16-row bands, V*J); a thread keeps its 4 column weights in registers and walks the band's rows (the row weight is
+// wave-uniform -> scalar load); 16-byte non-temporal stores.
+// ------------------------------------------------------------------------------------------------------------
+typedef float hm_v4f __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void k_heatmaps(int W, int H, const float* __restrict__ row, const float* __restrict__ col,
+                                                   const float* __restrict__ cmin, const float* __restrict__ den,
+                                                   float* __restrict__ out)
+{
+    const int vj = blockIdx.z, y0 = blockIdx.y * 16, x = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (x >= W) return;
+    const float lo = cmin[vj], d = den[vj];
+    const float* r = row + (size_t)vj * H;
+    const float* c = col + (size_t)vj * W + x;
+    float* o = out + (size_t)vj * H * W + x;
+    const int rows = min(16, H - y0);
+    if ((W & 3) == 0) {
+        const float4 k = *reinterpret_cast<const float4*>(c);
+        for (int i = 0; i < rows; i++) {
+            const float a = r[y0 + i];
+            hm_v4f v = { (a * k.x - lo) / d, (a * k.y - lo) / d, (a * k.z - lo) / d, (a * k.w - lo) / d };
+            __builtin_nontemporal_store(v, reinterpret_cast<hm_v4f*>(o + (size_t)(y0 + i) * W));
+        }
+    } else {
+        const int n = min(4, W - x);
+        for (int i = 0; i < rows; i++) {
+            const float a = r[y0 + i];
+            for (int k = 0; k < n; k++) o[(size_t)(y0 + i) * W + k] = (a * c[k] - lo) / d;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -431,6 +466,17 @@ int sks_knn3_meandist2(int P, const float* points, float* mean_dist2, void* stre
     if (P == 0) return 0;
     if (!points || !mean_dist2) return fail2(-2, "knn: missing pointer");
     hipLaunchKernelGGL(k_knn3, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, points, mean_dist2);
+    HIP_TRY2(hipGetLastError());
+    return 0;
+}
+
+int sks_heatmaps(int V, int J, int W, int H, const float* row, const float* col, const float* cmin, const float* den,
+                 float* out, void* stream)
+{
+    if (V < 1 || J < 1 || W < 1 || H < 1 || (long long)V * J > 65535) return fail2(-1, "heatmaps: bad shape");
+    if (!row || !col || !cmin || !den || !out) return fail2(-2, "heatmaps: missing pointer");
+    dim3 grid((W + 1023) / 1024, (H + 15) / 16, V * J);
+    hipLaunchKernelGGL(k_heatmaps, grid, dim3(256), 0, (hipStream_t)stream, W, H, row, col, cmin, den, out);
     HIP_TRY2(hipGetLastError());
     return 0;
 }

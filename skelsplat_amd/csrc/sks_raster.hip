@@ -1228,32 +1228,64 @@ __global__ __launch_bounds__(256) void k_render_bwd_wave(BwdArgs a)
 
 // per (view, tile, channel) statistics of the constant pseudo-GT heat-maps, once per scene: sum of gt^2 and count of
 // gt > 0 (what the masked-L2 loss sees wherever the render is zero), and their per-view totals.
+// Streaming layout: block (band, channel, view); a thread owns one 4-pixel column of a tile and walks the tile's 16
+// rows (16 independent 16-byte loads; a wavefront reads 1 KB contiguous per row), the four threads of a tile are
+// combined with DPP quad permutes in a fixed order -- one pass over the heat-maps at streaming rate, reproducible sums.
 __global__ __launch_bounds__(256) void k_gt_tile_stats(int C, int W, int H, const float* __restrict__ gt, float* __restrict__ tile_S,
                                                         float* __restrict__ tile_N, double* __restrict__ totals)
 {
-    __shared__ float s_r[2][4];
-    const int tx = blockIdx.x, ty = blockIdx.y, v = blockIdx.z, tid = threadIdx.x;
-    const int x = tx * TILE + (tid & 15), y = ty * TILE + (tid >> 4);
-    const bool in = x < W && y < H;
+    __shared__ double s_t[2][4];
+    const int band = blockIdx.x, ch = blockIdx.y, v = blockIdx.z, tid = threadIdx.x;
+    const int gx = (W + TILE - 1) / TILE, gy = gridDim.x;
     const size_t HW = (size_t)H * W;
-    const size_t tb = (((size_t)v * gridDim.y + ty) * gridDim.x + tx) * C;
+    const float* plane = gt + ((size_t)v * C + ch) * HW;
+    const int y0 = band * TILE, rows = min(TILE, H - y0);
+    const bool vec = (W & 3) == 0;
     double tS = 0.0, tN = 0.0;
-    for (int ch = 0; ch < C; ch++) {
-        const float g = in ? gt[((size_t)v * C + ch) * HW + (size_t)y * W + x] : 0.0f;
-        const float S = wave_sum(g * g), N = wave_sum(g > 0.0f ? 1.0f : 0.0f);
-        __syncthreads();
-        if ((tid & 63) == 0) { s_r[0][tid >> 6] = S; s_r[1][tid >> 6] = N; }
-        __syncthreads();
-        if (tid == 0) {
-            const float fs = (s_r[0][0] + s_r[0][1]) + (s_r[0][2] + s_r[0][3]);
-            const float fn = (s_r[1][0] + s_r[1][1]) + (s_r[1][2] + s_r[1][3]);
-            tile_S[tb + ch] = fs;
-            tile_N[tb + ch] = fn;
-            tS += (double)fs;
-            tN += (double)fn;
+    for (int t0 = 0; t0 < gx; t0 += 64) {
+        const int tx = t0 + (tid >> 2), x = tx * TILE + (tid & 3) * 4;
+        float S = 0.0f, N = 0.0f;
+        if (tx < gx && x < W) {
+            if (vec) {
+                float4 g[TILE];
+#pragma unroll
+                for (int r = 0; r < TILE; r++)   // all loads first: 16 independent requests in flight per lane
+                    g[r] = r < rows ? *reinterpret_cast<const float4*>(plane + (size_t)(y0 + r) * W + x) : make_float4(0, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < TILE; r++) {
+                    S += (g[r].x * g[r].x + g[r].y * g[r].y) + (g[r].z * g[r].z + g[r].w * g[r].w);
+                    N += ((g[r].x > 0.0f ? 1.0f : 0.0f) + (g[r].y > 0.0f ? 1.0f : 0.0f)) +
+                         ((g[r].z > 0.0f ? 1.0f : 0.0f) + (g[r].w > 0.0f ? 1.0f : 0.0f));
+                }
+            } else {
+                for (int r = 0; r < rows; r++)
+                    for (int k = 0; k < 4; k++)
+                        if (x + k < W) {
+                            const float g = plane[(size_t)(y0 + r) * W + x + k];
+                            S += g * g;
+                            N += g > 0.0f ? 1.0f : 0.0f;
+                        }
+            }
+        }
+        // the four 4-pixel columns of the tile
+        S += dpp_move<0xB1>(S); N += dpp_move<0xB1>(N);
+        S += dpp_move<0x4E>(S); N += dpp_move<0x4E>(N);
+        if ((tid & 3) == 0 && tx < gx) {
+            const size_t tb = (((size_t)v * gy + band) * gx + tx) * C + ch;
+            tile_S[tb] = S;
+            tile_N[tb] = N;
+            tS += (double)S;
+            tN += (double)N;
         }
     }
-    if (tid == 0) { atomicAdd(&totals[2 * v], tS); atomicAdd(&totals[2 * v + 1], tN); }
+    tS = wave_sum_d(tS);
+    tN = wave_sum_d(tN);
+    if ((tid & 63) == 0) { s_t[0][tid >> 6] = tS; s_t[1][tid >> 6] = tN; }
+    __syncthreads();
+    if (tid == 0) {
+        atomicAdd(&totals[2 * v], (s_t[0][0] + s_t[0][1]) + (s_t[0][2] + s_t[0][3]));
+        atomicAdd(&totals[2 * v + 1], (s_t[1][0] + s_t[1][1]) + (s_t[1][2] + s_t[1][3]));
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -2197,7 +2229,7 @@ int sks_gt_tile_stats(int V, int C, int W, int H, const float* gt, float* tile_S
     if (!gt || !tile_S || !tile_N || !totals) return fail(-2, "gt_tile_stats: missing pointer");
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipMemsetAsync(totals, 0, (size_t)V * 2 * sizeof(double), st));
-    dim3 grid((W + TILE - 1) / TILE, (H + TILE - 1) / TILE, V);
+    dim3 grid((H + TILE - 1) / TILE, C, V);
     hipLaunchKernelGGL(k_gt_tile_stats, grid, dim3(256), 0, st, C, W, H, gt, tile_S, tile_N, totals);
     HIP_TRY(hipGetLastError());
     return 0;

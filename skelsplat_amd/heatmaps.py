@@ -38,6 +38,34 @@ def ewa_lambdas(means, cov3D, cam, W, H):
     return mid + root, mid - root
 
 
+def ewa_lambdas_views(means, cov3D, cameras, W, H):
+    """ewa_lambdas for all cameras at once: (V, P) tensors (same arithmetic, batched over the view axis)."""
+    dt = torch.float32
+    dev = means.device
+    means = means.to(dt)
+    P = means.shape[0]
+    Vt = torch.stack([cam.world_view_transform.to(device=dev, dtype=dt) for cam in cameras], 0)          # (V,4,4)
+    tanx = torch.tensor([math.tan(cam.FoVx * 0.5) for cam in cameras], dtype=dt, device=dev)[:, None]
+    tany = torch.tensor([math.tan(cam.FoVy * 0.5) for cam in cameras], dtype=dt, device=dev)[:, None]
+    fx = torch.tensor([W / (2.0 * math.tan(cam.FoVx * 0.5)) for cam in cameras], dtype=dt, device=dev)[:, None]
+    fy = torch.tensor([H / (2.0 * math.tan(cam.FoVy * 0.5)) for cam in cameras], dtype=dt, device=dev)[:, None]
+    ph = torch.cat([means, torch.ones(P, 1, dtype=dt, device=dev)], 1)
+    t = ph[None] @ Vt[:, :, :3]                                          # (V,P,3)
+    tz = t[..., 2]
+    tx = torch.minimum(torch.maximum(t[..., 0] / tz, -1.3 * tanx), 1.3 * tanx) * tz
+    ty = torch.minimum(torch.maximum(t[..., 1] / tz, -1.3 * tany), 1.3 * tany) * tz
+    z = torch.zeros_like(tz)
+    J = torch.stack([fx / tz, z, -(fx * tx) / (tz * tz), z, fy / tz, -(fy * ty) / (tz * tz), z, z, z], -1).reshape(-1, P, 3, 3)
+    Wm = Vt[:, :3, :3].transpose(1, 2)[:, None]                          # (V,1,3,3)
+    JW = J @ Wm
+    cov = JW @ cov3D.to(dt)[None] @ JW.transpose(-1, -2)
+    cx, cy, cz = cov[..., 0, 0] + 0.3, cov[..., 0, 1], cov[..., 1, 1] + 0.3
+    det = cx * cz - cy * cy
+    mid = 0.5 * (cx + cz)
+    root = torch.sqrt(torch.clamp_min(mid * mid - det, 0.1))
+    return mid + root, mid - root
+
+
 def covariance_from_scaling_rotation(scaling, rotation_raw, modifier=1.0):
     """scene/gaussian_model.py:33-37 + general_utils.py:87-119: Sigma = R S S^T R^T with the *normalised* quaternion."""
     q = rotation_raw / rotation_raw.norm(dim=1, keepdim=True)
@@ -73,23 +101,54 @@ def _impulse_response_1d(pos, sigma, n, device):
     return (out / norm).to(torch.float32)
 
 
-def generate_heatmaps(means, scaling, rotation_raw, poses_2d, cameras, scaling_modifier=1.0):
-    """(V, J, H, W) normalised heat-maps; all cameras must share (W, H).  poses_2d: (V, J, 2) pixel (x, y).
-    general_utils.py:175-304 with dropout=False."""
+def heatmap_factors(means, scaling, rotation_raw, poses_2d, cameras, scaling_modifier=1.0):
+    """The separable description of the (V, J, H, W) heat-maps: row (V,J,H) = 255 * impulse response along y,
+    col (V,J,W) = impulse response along x, cmin (V,J), den (V,J) with
+    plane = (row[:, None] * col[None, :] - cmin) / den.
+    The plane minimum / maximum are the products of the factor minima / maxima (everything is non-negative and fp32
+    multiplication is monotone), so the min-max normalisation of normalize_heatmaps (:300-304) needs no image pass."""
     dev = means.device
-    V = len(cameras)
     W, H = int(cameras[0].image_width), int(cameras[0].image_height)
     cov3D = covariance_from_scaling_rotation(scaling, rotation_raw, scaling_modifier)
     poses_2d = torch.as_tensor(poses_2d, device=dev)
-    out = []
-    for v, cam in enumerate(cameras):
-        l1, l2 = ewa_lambdas(means, cov3D, cam, W, H)
-        xs = torch.clamp(poses_2d[v, :, 0].long(), 0, W - 1)   # .long() truncates like the reference (:275-278)
-        ys = torch.clamp(poses_2d[v, :, 1].long(), 0, H - 1)
-        ky = _impulse_response_1d(ys, torch.sqrt(l1), H, dev)  # sigma1 filters axis 0 (rows)
-        kx = _impulse_response_1d(xs, torch.sqrt(l2), W, dev)  # sigma2 filters axis 1 (columns)
-        hm = 255.0 * ky[:, :, None] * kx[:, None, :]
-        cmin = hm.amin(dim=(1, 2), keepdim=True)
-        cmax = hm.amax(dim=(1, 2), keepdim=True)
-        out.append((hm - cmin) / (cmax - cmin + 1e-8))          # normalize_heatmaps (:300-304)
-    return torch.stack(out, 0)
+    V = len(cameras)
+    for cam in cameras:
+        if int(cam.image_width) != W or int(cam.image_height) != H:
+            raise ValueError("generate_heatmaps: all cameras must share (W, H)")
+    l1, l2 = ewa_lambdas_views(means, cov3D, cameras, W, H)           # (V, J) each
+    J = l1.shape[1]
+    xs = torch.clamp(poses_2d[:, :, 0].long(), 0, W - 1)              # .long() truncates like the reference (:275-278)
+    ys = torch.clamp(poses_2d[:, :, 1].long(), 0, H - 1)
+    # sigma1 filters axis 0 (rows), sigma2 axis 1 (columns); all V*J one-dimensional responses in one go
+    row = (255.0 * _impulse_response_1d(ys.reshape(-1), torch.sqrt(l1).reshape(-1), H, dev)).reshape(V, J, H).contiguous()
+    col = _impulse_response_1d(xs.reshape(-1), torch.sqrt(l2).reshape(-1), W, dev).reshape(V, J, W).contiguous()
+    cmin = row.amin(dim=2) * col.amin(dim=2)
+    cmax = row.amax(dim=2) * col.amax(dim=2)
+    den = cmax - cmin + 1e-8
+    return row, col, cmin.contiguous(), den.contiguous()
+
+
+def generate_heatmaps(means, scaling, rotation_raw, poses_2d, cameras, scaling_modifier=1.0, out=None):
+    """(V, J, H, W) normalised heat-maps; all cameras must share (W, H).  poses_2d: (V, J, 2) pixel (x, y).
+    general_utils.py:175-304 with dropout=False.  On a ROCm device the planes are written by one streaming kernel
+    (sks_heatmaps); on CPU tensors (tests against scipy) by the same formula in tensor ops.  `out`: optional
+    (V,J,H,W) fp32 buffer to write into (scene streaming: same storage for every frame)."""
+    row, col, cmin, den = heatmap_factors(means, scaling, rotation_raw, poses_2d, cameras, scaling_modifier)
+    V, J, H = row.shape
+    W = col.shape[2]
+    if row.is_cuda:
+        from . import _lib
+        if out is None:
+            out = torch.empty((V, J, H, W), dtype=torch.float32, device=row.device)
+        elif out.shape != (V, J, H, W) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != row.device:
+            raise ValueError("generate_heatmaps: `out` must be a contiguous fp32 (V,J,H,W) tensor on the parameters' device")
+        with torch.cuda.device(row.device):
+            rc = _lib.load().sks_heatmaps(V, J, W, H, row.data_ptr(), col.data_ptr(), cmin.data_ptr(), den.data_ptr(),
+                                          out.data_ptr(), torch.cuda.current_stream(row.device).cuda_stream)
+        _lib.check(rc, "sks_heatmaps")
+        return out
+    res = (row[:, :, :, None] * col[:, :, None, :] - cmin[:, :, None, None]) / den[:, :, None, None]
+    if out is not None:
+        out.copy_(res)
+        return out
+    return res

@@ -146,6 +146,41 @@ class MultiViewLoop:
             self.exp_avg_sq = torch.zeros((P, 11), device=dev)
             self.counters = torch.zeros(2, dtype=torch.int32, device=dev)
 
+    # -- scene streaming ---------------------------------------------------------------------------------------
+    def new_scene(self, points, poses_2d=None, heatmaps=None):
+        """Next frame seen by the SAME cameras (the reference's outer loop, train.py:74-99: new GaussianModel, new
+        heat-maps, iteration counter back to 0).  Everything is re-initialised in place -- parameters, Adam moments,
+        step counters, V-slot buffer, heat-maps and their tile statistics keep their storage -- so the hipGraphs
+        captured for the previous frame are replayed as they are.  Give either `poses_2d` (V,J,2) (the heat-maps are
+        generated from the re-initialised Gaussians like general_utils.py:175-304) or ready `heatmaps`."""
+        from .heatmaps import generate_heatmaps
+        gm = self.gm
+        gm.reset_from_points(points)
+        with torch.no_grad():
+            self.accumulated_grads.zero_()
+            if self.device_tail:
+                self.exp_avg.zero_()
+                self.exp_avg_sq.zero_()
+                self.counters.zero_()
+            elif gm.optimizer is not None:
+                gm.training_setup()
+            for grp in self.size_groups:
+                slots, vb, gt, stats = grp
+                ids = [self.local_ids[k] for k in slots]
+                if heatmaps is not None:
+                    for i, v in enumerate(ids):
+                        gt[i].copy_(heatmaps[v])
+                elif poses_2d is not None:
+                    p2d = torch.as_tensor(poses_2d, device=self.device)[ids]
+                    generate_heatmaps(gm._xyz.detach(), gm.get_scaling.detach(), gm._rotation.detach(), p2d,
+                                      [self.cameras[v] for v in ids], out=gt)
+                else:
+                    raise ValueError("new_scene needs poses_2d or heatmaps")
+                if stats is not None:
+                    R.gt_tile_stats(gt, out=stats)
+        self.iteration = 0    # (last_losses keeps pointing at the buffers the captured graphs write)
+        return self
+
     # -- one accumulation group --------------------------------------------------------------------------
     def _local_view_grads(self):
         """Renders this rank's views and returns (V_local, P, 11) raw-parameter gradients + per-view losses."""

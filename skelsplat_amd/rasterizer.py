@@ -410,16 +410,22 @@ class GtStats:
     __slots__ = ("gt", "tile_S", "tile_N", "totals")
 
 
-def gt_tile_stats(gt):
+def gt_tile_stats(gt, out=None):
+    """`out`: a GtStats of the same shape to refill in place (scene streaming keeps every pointer stable)."""
     gt = _f32c(gt, "gt")
     V, C, H, W = gt.shape
     NT = ((W + 15) // 16) * ((H + 15) // 16)
     dev = gt.device
-    st = GtStats()
+    if out is not None:
+        if out.tile_S.shape != (V, NT, C) or out.tile_S.device != dev:
+            raise ValueError("gt_tile_stats: `out` was made for another shape / device")
+        st = out
+    else:
+        st = GtStats()
+        st.tile_S = torch.empty((V, NT, C), dtype=torch.float32, device=dev)
+        st.tile_N = torch.empty((V, NT, C), dtype=torch.float32, device=dev)
+        st.totals = torch.empty((V, 2), dtype=torch.float64, device=dev)
     st.gt = gt
-    st.tile_S = torch.empty((V, NT, C), dtype=torch.float32, device=dev)
-    st.tile_N = torch.empty((V, NT, C), dtype=torch.float32, device=dev)
-    st.totals = torch.empty((V, 2), dtype=torch.float64, device=dev)
     with torch.cuda.device(dev):
         rc = _lib.load().sks_gt_tile_stats(V, C, W, H, gt.data_ptr(), st.tile_S.data_ptr(), st.tile_N.data_ptr(),
                                            st.totals.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)

@@ -261,6 +261,19 @@ class GaussianModel:
         self._scaling = torch.nn.Parameter(scales.requires_grad_(True))
         self._rotation = torch.nn.Parameter(rots.requires_grad_(True))
         self._opacity = torch.nn.Parameter(opacities.requires_grad_(opacity_on))
+        self._initial = (scales.detach().clone(), rots.detach().clone(), opacities.detach().clone())
+        return self
+
+    def reset_from_points(self, points):
+        """Next frame of the same sequence: the reference builds a fresh GaussianModel per scene (train.py:86-99);
+        here the parameter tensors are re-initialised IN PLACE (same storage), so captured hipGraphs and every
+        pointer held by a MultiViewLoop stay valid."""
+        with torch.no_grad():
+            pts = points if torch.is_tensor(points) else torch.as_tensor(np.asarray(points))
+            self._xyz.copy_(pts.to(device=self._xyz.device, dtype=self._xyz.dtype))
+            self._scaling.copy_(self._initial[0])
+            self._rotation.copy_(self._initial[1])
+            self._opacity.copy_(self._initial[2])
         return self
 
     get_xyz = property(lambda self: self._xyz)

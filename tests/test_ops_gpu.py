@@ -264,3 +264,83 @@ def test_loop_with_mixed_image_sizes(device):
     assert moved > 1.0
     for o in outs:
         assert (o - ref).norm(dim=1).max().item() < 5e-3 * moved
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 48, 64), (1, 17, 50, 70), (2, 2, 33, 1030), (1, 5, 16, 4100)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_gt_tile_stats(device, shape):
+    """sks_gt_tile_stats: per (view, tile, channel) sum of gt^2 and count of gt > 0, and the per-view totals; ragged
+    tiles, widths that are not multiples of 4, more than 64 / 256 tile columns."""
+    from skelsplat_amd import rasterizer as R
+    V, C, H, W = shape
+    g = torch.Generator().manual_seed(3)
+    gt = torch.rand(shape, generator=g)
+    gt = torch.where(torch.rand(shape, generator=g) < 0.6, torch.zeros(()), gt).to(device)
+    st = R.gt_tile_stats(gt)
+    gy, gx = (H + 15) // 16, (W + 15) // 16
+    pad = torch.zeros((V, C, gy * 16, gx * 16), dtype=torch.float64)
+    pad[:, :, :H, :W] = gt.cpu().double()
+    t = pad.reshape(V, C, gy, 16, gx, 16)
+    S = (t * t).sum(dim=(3, 5)).permute(0, 2, 3, 1).reshape(V, gy * gx, C)
+    N = (t > 0).double().sum(dim=(3, 5)).permute(0, 2, 3, 1).reshape(V, gy * gx, C)
+    assert torch.equal(st.tile_N.cpu().double(), N)
+    torch.testing.assert_close(st.tile_S.cpu().double(), S, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(st.totals.cpu()[:, 0], S.sum(dim=(1, 2)), rtol=1e-6, atol=1e-6)
+    assert torch.equal(st.totals.cpu()[:, 1], N.sum(dim=(1, 2)))
+    st2 = R.gt_tile_stats(gt)
+    assert torch.equal(st2.tile_S, st.tile_S)   # fixed summation order
+
+
+@pytest.mark.parametrize("W,H", [(200, 160), (130, 77), (1030, 40)], ids=["200x160", "130x77", "1030x40"])
+def test_heatmap_kernel_equals_formula(device, W, H):
+    """sks_heatmaps writes exactly what the tensor-op formula of skelsplat_amd/heatmaps.py gives (which the CPU suite
+    pins against scipy.ndimage.gaussian_filter): same fp32 operations, IEEE division."""
+    from skelsplat_amd.scene import SyntheticScene, GaussianModel
+    from skelsplat_amd import heatmaps as hmod
+    sc = SyntheticScene("h36m", n_views=3, seed=4, W=W, H=H, device=device)
+    gm = GaussianModel().create_from_points(sc.pose_3d_init, sc.spatial_lr_scale, sc.n_joints, scene_type="h36m", device=device)
+    p2d = torch.tensor(sc.poses_2d, device=device)
+    args = (gm._xyz.detach(), gm.get_scaling.detach(), gm._rotation.detach(), p2d, sc.cameras)
+    out = hmod.generate_heatmaps(*args)
+    row, col, cmin, den = hmod.heatmap_factors(*args)
+    ref = (row[:, :, :, None] * col[:, :, None, :] - cmin[:, :, None, None]) / den[:, :, None, None]
+    assert out.shape == (3, 17, H, W) and torch.equal(out, ref)
+    # and the factor shortcut for the plane minimum / maximum is exact
+    hm = row[:, :, :, None] * col[:, :, None, :]
+    assert torch.equal(hm.amin(dim=(2, 3)), cmin) and torch.equal(hm.amax(dim=(2, 3)) - cmin + 1e-8, den)
+    assert float(out.max()) <= 1.0 and float(out.min()) >= 0.0
+
+
+@pytest.mark.parametrize("sparse", [True, False], ids=["sparse", "dense"])
+def test_scene_streaming_reuses_graphs(device, sparse):
+    """MultiViewLoop.new_scene re-initialises parameters, optimiser state, heat-maps and tile statistics in place, so a
+    second frame replays the hipGraphs captured for the first one and ends exactly where a freshly built loop ends."""
+    from skelsplat_amd.loop import MultiViewLoop
+    from skelsplat_amd.heatmaps import generate_heatmaps
+    from skelsplat_amd.scene import GaussianModel
+    sc, model = _make_loop_scene(device, seed=21)
+    rng = np.random.default_rng(0)
+    pose2 = (np.asarray(sc.pose_3d_init) + rng.normal(0, 25.0, np.asarray(sc.pose_3d_init).shape)).astype(np.float32)
+    p2d2 = (np.asarray(sc.poses_2d) + rng.normal(0, 2.0, np.asarray(sc.poses_2d).shape)).astype(np.float32)
+
+    def fresh(points, p2d):
+        gm = GaussianModel().create_from_points(points, sc.spatial_lr_scale, sc.n_joints, scaling=3.9, device=device)
+        gm.training_setup()
+        hm = generate_heatmaps(gm._xyz.detach(), gm.get_scaling.detach(), gm._rotation.detach(),
+                               torch.tensor(p2d, device=device), sc.cameras)
+        return gm, MultiViewLoop(gm, sc.cameras, hm, dataset="h36m", sparse=sparse, use_graph=True)
+
+    gmA, loopA = fresh(sc.pose_3d_init, sc.poses_2d)
+    loopA.run(120, groups_per_graph=10)
+    first = gmA._xyz.detach().clone()
+    ptrs = (gmA._xyz.data_ptr(), loopA.size_groups[0][2].data_ptr())
+    graph = loopA._multi[1]
+    loopA.new_scene(pose2, poses_2d=p2d2)
+    assert loopA.iteration == 0 and int(loopA.counters.sum()) == 0
+    loopA.run(120, groups_per_graph=10)
+    assert loopA._multi[1] is graph and ptrs == (gmA._xyz.data_ptr(), loopA.size_groups[0][2].data_ptr())
+    gmB, loopB = fresh(pose2, p2d2)
+    loopB.run(120, groups_per_graph=10)
+    assert not torch.equal(first, gmA._xyz)
+    for a, b in ((gmA._xyz, gmB._xyz), (gmA._scaling, gmB._scaling), (gmA._rotation, gmB._rotation), (gmA._opacity, gmB._opacity)):
+        assert torch.equal(a.detach(), b.detach())

@@ -59,3 +59,20 @@ def torch_l2():
     loss.backward()
 tt = timeit(torch_l2, iters=5)
 print(f"masked_l2 (4,17,1000,1000): {t:.3f} ms ({3*n/t/1e6:.0f} GB/s alg: 2 reads + 1 write) vs torch ops + autograd {tt:.3f} ms ({tt/t:.1f}x)")
+
+# per-scene preparation of the sparse fused loop: closed-form heat-maps + their per-tile statistics
+from skelsplat_amd import rasterizer as R
+from skelsplat_amd.scene import SyntheticScene, GaussianModel
+from skelsplat_amd.heatmaps import generate_heatmaps
+for ds, V in (("h36m", 4), ("panoptic", 31)):
+    sc = SyntheticScene(ds, n_views=V, seed=0, device=dev)
+    gm = GaussianModel().create_from_points(sc.pose_3d_init, sc.spatial_lr_scale, sc.n_joints, scene_type=ds, device=dev)
+    p2d = torch.tensor(sc.poses_2d, device=dev)
+    mk = lambda: generate_heatmaps(gm._xyz.detach(), gm.get_scaling.detach(), gm._rotation.detach(), p2d, sc.cameras)
+    hm = mk()
+    hm = hm if torch.is_tensor(hm) else torch.stack(list(hm))
+    th = timeit(mk, iters=5)
+    ts = timeit(lambda: R.gt_tile_stats(hm), iters=10)
+    nb = hm.numel() * 4
+    print(f"{ds} V={V}: generate_heatmaps {th:.3f} ms ({nb/th/1e6:.0f} GB/s written), gt_tile_stats {ts:.3f} ms ({nb/ts/1e6:.0f} GB/s read)")
+    del hm
