@@ -143,14 +143,17 @@ int sks_knn3_meandist2(int P, const float* points, float* mean_dist2, void* stre
 
 /* Sparse fused training step (no dense image, no dense gradient).  In the loop the render is only ever compared with the
  * constant pseudo-GT heat-maps (train.py:148-152), and it is exactly zero outside the tiles some Gaussian rect covers,
- * so render + clamp + masked-L2 + backward can be evaluated on the covered tiles alone:
- *  sks_gt_tile_stats (once per scene): per (view, tile, channel) sum of gt^2 and count of gt > 0 -> tile_S, tile_N
- *      (V, Ty*Tx, C) floats, and per-view totals (V x 2 doubles);
+ * so render + clamp + masked-L2 + backward can be evaluated on the covered tiles alone.  Where the render is zero the
+ * loss only sees the heat-maps (mask gt > 0, error gt^2): a per-frame constant; where it is positive the exact term
+ * replaces that constant.
+ *  sks_gt_tile_stats (once per frame): per-view totals {sum of gt^2, count of gt > 0} (V x 2 doubles); optionally
+ *      (tile_S / tile_N non-NULL) the same per (view, tile, channel) as (V, Ty*Tx, C) floats;
  *  sks_geometry: the geometry stage of sks_forward alone (fills `geom` and `radii`);
  *  sks_backward_fused_loss: like sks_backward, but takes the heat-maps `gt` (V,C,H,W) instead of dL/d(render):
  *      re-composites each covered pixel, forms 2 (clamp(r) - gt) on the mask {gt > 0 or r > 0} on the fly, and
- *      returns per-view {S, N} (loss_v = S/N) in loss_sums; gradients are UNSCALED (multiply by 1/N_v, e.g. with
- *      sks_loop_pack_grads).  P <= 64. */
+ *      returns per-view {S, N} (loss_v = S/N) in loss_sums = gt_totals + the corrections of the pixels with a
+ *      positive render; gradients are UNSCALED (multiply by 1/N_v, e.g. with sks_loop_pack_grads).  P <= 64.
+ *      tile_S / tile_N are not read (may be NULL). */
 int sks_gt_tile_stats(int V, int C, int W, int H, const float* gt, float* tile_S, float* tile_N, double* totals, void* stream);
 int sks_geometry(int V, int P, int C, int W, int H, const float* viewmatrix, const float* projmatrix,
                  const float* tanfovx /*HOST V*/, const float* tanfovy /*HOST V*/, const float* means3D,

@@ -672,8 +672,8 @@ struct BwdArgs {
     const float* dL_color;     // fused-loss mode: the pseudo-GT heat-maps (V,C,H,W) instead of dL/d(render)
     const float* dL_invdepth;
     float* accum;  // (V,P,NACC+C)
-    const float* tile_S;       // fused-loss mode: per (view, tile, channel) sum of gt^2 and count of gt > 0
-    const float* tile_N;
+    const float* tile_S;       // (unused since the loss corrections are taken where the render is positive; kept
+    const float* tile_N;       //  for the ABI's argument list)
 };
 
 // prepass of one pixel over an LDS batch: same walk as the forward; records the LDS index of the last accepted
@@ -1008,9 +1008,9 @@ __device__ __forceinline__ unsigned rlu(unsigned x, int lane) { return (unsigned
 // LOSS = true fuses the loop's masked-L2 loss (utils/loss_utils.py:86-100 on the clamped render, train.py:150) into
 // this kernel: a.dL_color holds the pseudo-GT heat-maps; dL/d(render) = 2 (r - gt) on the mask {gt > 0 or r > 0} is
 // formed per pixel from the re-composited colours, so neither the rendered image nor a dense gradient ever exists.
-// The loss sums over the WHOLE image are (precomputed per-tile sums of the constant heat-maps) - (those sums for the
-// tiles some rect covers) + (exact sums over the covered tiles), the latter two accumulated here by each tile's owner
-// (lowest-index covering Gaussian) into slots 7 (S) and 8 (N); outside covered tiles the render is exactly zero.
+// The loss sums over the WHOLE image are (per-view totals of the constant heat-maps: sum gt^2 and count over gt > 0,
+// i.e. the loss of an all-zero render) + (corrections where the render is positive), the latter accumulated here by
+// each tile's owner (lowest-index covering Gaussian) into slots 7 (S) and 8 (N).
 template <int CG, bool DFEAT, bool LOSS>
 __global__ __launch_bounds__(256) void k_render_bwd_wave(BwdArgs a)
 {
@@ -1115,7 +1115,14 @@ __global__ __launch_bounds__(256) void k_render_bwd_wave(BwdArgs a)
             if (stop) alive = false;
         }
         const bool need = in && klast >= kg;  // g is at or in front of the last contributor at this pixel
-        const bool own = LOSS && in && minid == g;  // this block accounts for the loss at this pixel
+        // LOSS: the pixel's loss terms are accounted by the tile's owner, and only where the render is positive:
+        // everywhere else the masked-L2 sees render = 0, which the per-view heat-map totals already contain
+        bool own = false;
+        if (LOSS && in && minid == g) {
+#pragma unroll
+            for (int ch = 0; ch < CG; ch++)
+                if (chmask & (1u << ch)) own = own || col[ch] > 0.0f;
+        }
         if (!__any(need || own)) continue;
         // upstream gradient of this pixel: only the active channels, only the lanes that need it
         const size_t pix = (size_t)y * W + x;
@@ -1129,11 +1136,13 @@ __global__ __launch_bounds__(256) void k_render_bwd_wave(BwdArgs a)
                 float d = 0.0f;
                 if (chmask & (1u << ch)) {
                     if (LOSS) {
-                        const float gtv = (need || own) ? dLc[(size_t)ch * HW] : 0.0f;
+                        const bool rpos = col[ch] > 0.0f;          // clamp01(col) > 0
+                        const float gtv = (need || (own && rpos)) ? dLc[(size_t)ch * HW] : 0.0f;
                         const float r = clamp01(col[ch]);          // gaussian_renderer/__init__.py:129
                         const bool msk = gtv > 0.0f || r > 0.0f;   // loss_utils.py:88-91
                         const float e = r - gtv;
-                        if (own && msk) { sum[7] += e * e; sum[8] += 1.0f; }
+                        // correction to the heat-map-only totals: (r - gt)^2 replaces gt^2 [gt > 0], 1 replaces [gt > 0]
+                        if (own && rpos) { sum[7] += e * e - (gtv > 0.0f ? gtv * gtv : 0.0f); sum[8] += gtv > 0.0f ? 0.0f : 1.0f; }
                         d = msk ? 2.0f * e : 0.0f;
                         if (!(col[ch] >= 0.0f && col[ch] <= 1.0f)) d = 0.0f;   // clamp backward
                         if (!need) d = 0.0f;
@@ -1147,15 +1156,6 @@ __global__ __launch_bounds__(256) void k_render_bwd_wave(BwdArgs a)
                 s.dL[ch] = d;
                 s.accum_rec[ch] = 0;
                 s.last_color[ch] = 0;
-            }
-        }
-        if (LOSS && own && (x & 15) == 0 && (y & 15) == 0) {
-            // the owned tile's precomputed heat-map sums are replaced by the exact sums accumulated above
-            const int gxt = (W + TILE - 1) / TILE;
-            const size_t tb = (((size_t)v * ((H + TILE - 1) / TILE) + ty) * gxt + tx) * C;
-#pragma unroll
-            for (int ch = 0; ch < CG; ch++) {
-                if (chmask & (1u << ch)) { sum[7] -= a.tile_S[tb + ch]; sum[8] -= a.tile_N[tb + ch]; }
             }
         }
         if (!__any(need)) continue;
@@ -1272,8 +1272,8 @@ __global__ __launch_bounds__(256) void k_gt_tile_stats(int C, int W, int H, cons
         S += dpp_move<0x4E>(S); N += dpp_move<0x4E>(N);
         if ((tid & 3) == 0 && tx < gx) {
             const size_t tb = (((size_t)v * gy + band) * gx + tx) * C + ch;
-            tile_S[tb] = S;
-            tile_N[tb] = N;
+            if (tile_S) tile_S[tb] = S;
+            if (tile_N) tile_N[tb] = N;
             tS += (double)S;
             tN += (double)N;
         }
@@ -2226,7 +2226,7 @@ int sks_backward(int V, int P, int C, int W, int H, const float* viewmatrix, con
 int sks_gt_tile_stats(int V, int C, int W, int H, const float* gt, float* tile_S, float* tile_N, double* totals, void* stream)
 {
     if (int rc = check_common(V, 1, C, W, H)) return rc;
-    if (!gt || !tile_S || !tile_N || !totals) return fail(-2, "gt_tile_stats: missing pointer");
+    if (!gt || !totals) return fail(-2, "gt_tile_stats: missing pointer");
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipMemsetAsync(totals, 0, (size_t)V * 2 * sizeof(double), st));
     dim3 grid((H + TILE - 1) / TILE, C, V);
@@ -2248,7 +2248,7 @@ int sks_backward_fused_loss(int V, int P, int C, int W, int H, const float* view
     if (P < 1 || P > 64) return fail(-1, "fused-loss backward needs 1 <= P <= 64 (got %d)", P);
     hipStream_t st = (hipStream_t)stream;
     if (!viewmatrix || !projmatrix || !tanfovx || !tanfovy || !means3D || !features || !opacities || !radii || !geom || !gt ||
-        !tile_S || !tile_N || !gt_totals || !accum || !dL_dmeans3D || !dL_dmeans2D || !dL_dopacity || !loss_sums)
+        !gt_totals || !accum || !dL_dmeans3D || !dL_dmeans2D || !dL_dopacity || !loss_sums)
         return fail(-2, "missing required pointer");
     if (!cov3D_precomp && (!scales || !rotations)) return fail(-2, "need scales+rotations or cov3D_precomp");
     ViewTan vt;

@@ -410,24 +410,26 @@ class GtStats:
     __slots__ = ("gt", "tile_S", "tile_N", "totals")
 
 
-def gt_tile_stats(gt, out=None):
-    """`out`: a GtStats of the same shape to refill in place (scene streaming keeps every pointer stable)."""
+def gt_tile_stats(gt, out=None, tiles=False):
+    """Per-view heat-map totals (what the masked-L2 loss is for an all-zero render); `tiles=True` also fills the per
+    (view, tile, channel) arrays.  `out`: a GtStats of the same shape to refill in place (scene streaming keeps every
+    pointer stable)."""
     gt = _f32c(gt, "gt")
     V, C, H, W = gt.shape
     NT = ((W + 15) // 16) * ((H + 15) // 16)
     dev = gt.device
     if out is not None:
-        if out.tile_S.shape != (V, NT, C) or out.tile_S.device != dev:
+        if out.totals.shape != (V, 2) or out.totals.device != dev or out.gt.shape != gt.shape:
             raise ValueError("gt_tile_stats: `out` was made for another shape / device")
         st = out
     else:
         st = GtStats()
-        st.tile_S = torch.empty((V, NT, C), dtype=torch.float32, device=dev)
-        st.tile_N = torch.empty((V, NT, C), dtype=torch.float32, device=dev)
+        st.tile_S = torch.empty((V, NT, C), dtype=torch.float32, device=dev) if tiles else None
+        st.tile_N = torch.empty((V, NT, C), dtype=torch.float32, device=dev) if tiles else None
         st.totals = torch.empty((V, 2), dtype=torch.float64, device=dev)
     st.gt = gt
     with torch.cuda.device(dev):
-        rc = _lib.load().sks_gt_tile_stats(V, C, W, H, gt.data_ptr(), st.tile_S.data_ptr(), st.tile_N.data_ptr(),
+        rc = _lib.load().sks_gt_tile_stats(V, C, W, H, gt.data_ptr(), _lib.ptr(st.tile_S), _lib.ptr(st.tile_N),
                                            st.totals.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
     _lib.check(rc, "sks_gt_tile_stats")
     return st
@@ -486,7 +488,7 @@ def backward_fused_loss(st: ForwardState, stats: GtStats, means3D, features, opa
                                          st.views.tanfovx, st.views.tanfovy, _lib.ptr(bgC), _lib.ptr(means3D), _lib.ptr(feat2),
                                          _lib.ptr(opacities), _lib.ptr(scales), _lib.ptr(rotations), _lib.ptr(cov3D_precomp),
                                          st.scale_modifier, st.flags, st.radii.data_ptr(), st.geom.data_ptr(),
-                                         stats.gt.data_ptr(), stats.tile_S.data_ptr(), stats.tile_N.data_ptr(),
+                                         stats.gt.data_ptr(), _lib.ptr(stats.tile_S), _lib.ptr(stats.tile_N),
                                          stats.totals.data_ptr(), accum.data_ptr(), _lib.ptr(out["means3D"]),
                                          _lib.ptr(out["means2D"]), _lib.ptr(out["opacities"]), _lib.ptr(out["scales"]),
                                          _lib.ptr(out["rotations"]), _lib.ptr(out["cov3D"]), sums.data_ptr(),

@@ -276,7 +276,7 @@ def test_gt_tile_stats(device, shape):
     g = torch.Generator().manual_seed(3)
     gt = torch.rand(shape, generator=g)
     gt = torch.where(torch.rand(shape, generator=g) < 0.6, torch.zeros(()), gt).to(device)
-    st = R.gt_tile_stats(gt)
+    st = R.gt_tile_stats(gt, tiles=True)
     gy, gx = (H + 15) // 16, (W + 15) // 16
     pad = torch.zeros((V, C, gy * 16, gx * 16), dtype=torch.float64)
     pad[:, :, :H, :W] = gt.cpu().double()
@@ -287,8 +287,11 @@ def test_gt_tile_stats(device, shape):
     torch.testing.assert_close(st.tile_S.cpu().double(), S, rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(st.totals.cpu()[:, 0], S.sum(dim=(1, 2)), rtol=1e-6, atol=1e-6)
     assert torch.equal(st.totals.cpu()[:, 1], N.sum(dim=(1, 2)))
-    st2 = R.gt_tile_stats(gt)
+    st2 = R.gt_tile_stats(gt, tiles=True)
     assert torch.equal(st2.tile_S, st.tile_S)   # fixed summation order
+    st3 = R.gt_tile_stats(gt)                   # totals only
+    assert st3.tile_S is None and torch.equal(st3.totals[:, 1], st.totals[:, 1])
+    torch.testing.assert_close(st3.totals[:, 0], st.totals[:, 0], rtol=1e-12, atol=0)
 
 
 @pytest.mark.parametrize("W,H", [(200, 160), (130, 77), (1030, 40)], ids=["200x160", "130x77", "1030x40"])
