@@ -190,6 +190,22 @@ int sks_loop_adam_step(int V, int P, const float* grads, float* slots, unsigned 
                        const double* lrs /*HOST 3: scaling, rotation, opacity*/, const double* adam /*HOST 3: beta1, beta2, eps*/,
                        float lambda_consistency, const int* limb /*HOST 8 ints or NULL*/, void* stream);
 
+/* One accumulation group of the sparse loop on ONE GPU in two launches (train.py:130-222 for acc_steps views):
+ * the fused-loss compositing backward (as sks_backward_fused_loss) and a single-workgroup tail that runs the geometry
+ * backward of every view, the optimiser step (as sks_loop_adam_step) and the geometry forward of the UPDATED parameters.
+ * Precondition: `geom` / `radii` hold the geometry of the current parameters (sks_geometry with SKS_RAW_PARAMS, or the
+ * previous sks_loop_fused_step); on return they hold the geometry of the updated ones.  xyz / scaling / rotation / opacity
+ * are the RAW leaf parameters (updated in place); packed: (V,P,11) scratch (the group's raw-parameter gradients on
+ * return); loss_sums: out, V x {S, N}.  P <= 64.  Results are bit-identical to the separate calls. */
+int sks_loop_fused_step(int V, int P, int C, int W, int H, const float* viewmatrix, const float* projmatrix,
+                        const float* tanfovx /*HOST V*/, const float* tanfovy /*HOST V*/, const float* features,
+                        float scale_modifier, unsigned flags, int* radii, void* geom, const float* gt,
+                        const double* gt_totals, void* accum, double* loss_sums, float* packed, float* slots,
+                        unsigned long long group_mask, int last_view, float* xyz, float* scaling, float* rotation,
+                        float* opacity, float* exp_avg, float* exp_avg_sq, int* counters, int acc_steps,
+                        const double* lr_sched /*HOST 5*/, const double* lrs /*HOST 3*/, const double* adam /*HOST 3*/,
+                        float lambda_consistency, const int* limb /*HOST 8 or NULL*/, void* stream);
+
 /* Measurement hook used by bench.py (no reference counterpart): while enabled, the dominant kernel of sks_forward
  * (kind 0: forward compositor) and of sks_backward (kind 1: backward compositor) is bracketed by hipEvents recorded
  * on the caller's stream.  sks_prof_read waits for the recorded events, returns the summed kernel time in

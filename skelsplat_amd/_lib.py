@@ -45,6 +45,8 @@ SIGNATURES = {
     "sks_loop_pack_grads": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sks_loop_adam_step": (_i, [_i, _i, _vp, _vp, C.c_ulonglong, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp,
                                 _f, _vp, _vp]),
+    "sks_loop_fused_step": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _u, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                 _vp, C.c_ulonglong, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _f, _vp, _vp]),
     "sks_prof_enable": (_i, [_i]),
     "sks_prof_read": (_i, [_i, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
 }

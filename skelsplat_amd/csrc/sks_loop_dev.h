@@ -1,0 +1,170 @@
+// sks_loop_dev.h -- device side of the optimiser step of the multi-view loop (train.py:160-222), shared by
+// k_loop_adam (sks_loop.hip) and the fused step tail k_step_tail (sks_raster.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+namespace sksloop {
+
+struct AdamArgs {
+    int V, P;
+    const float* grads;        // (V,P,11) raw-parameter gradients of every view (this group)
+    float* slots;              // (V,P,3) persistent per-view xyz gradient slots (train.py:121,175)
+    unsigned long long group_mask;  // views rendered in this group (bit v)
+    int last_view;             // view of the group's last iteration: its scaling/rotation/opacity grads win (Q7)
+    float* xyz; float* scaling; float* rotation; float* opacity;     // raw leaf parameters, updated in place
+    float* m; float* vv;       // Adam moments, (P,11) each, same packing as the gradients
+    int* counters;             // [0] iteration (advanced by acc_steps), [1] Adam step count
+    int acc_steps;
+    double lr_init, lr_final, lr_delay_mult; int lr_delay_steps, lr_max_steps;  // xyz schedule (general_utils.py:38-71)
+    double log_lr_init, log_lr_final;   // np.log of the two, taken on the host like the reference does
+    double lr_scaling, lr_rotation, lr_opacity;
+    double beta1, beta2, eps;
+    float lambda_consistency;
+    int limb[8];               // l_arm, r_arm, l_leg, r_leg joint index pairs (loss_utils.py:226-250); limb[0] < 0: none
+    int n_joints;              // joints per skeleton (limb indices address the first skeleton, like the reference)
+};
+
+// torch.optim.Adam single-tensor path (python scalars are doubles, tensor math is fp32):
+//   exp_avg.lerp_(grad, 1-beta1); exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2);
+//   denom = (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps); param.addcdiv_(exp_avg, denom, value=-lr/bias_correction1)
+__device__ __forceinline__ void adam_update(float& param, float g, float& m, float& v, float w1, float b2, float w2,
+                                            float eps, float step_size, float bc2_sqrt)
+{
+    m = m + w1 * (g - m);
+    v = v * b2 + w2 * (g * g);
+    const float denom = sqrtf(v) / bc2_sqrt + eps;
+    param = param - step_size * (m / denom);
+}
+
+// One optimiser step by one 256-thread workgroup (thread p < P owns Gaussian p).  Every thread of the workgroup must
+// call it (it synchronises).  s_xyz: 768 floats, s_hyp: 6 floats, s_d: 4 doubles of LDS.
+__device__ __forceinline__ void adam_block_step(const AdamArgs& a, float* s_xyz, float* s_hyp, double* s_d)
+{
+    const int p = threadIdx.x;
+    const int P = a.P, V = a.V;
+    const bool live = p < P;
+    const int it1 = a.counters[0] + a.acc_steps;   // iteration at which the optimiser steps (train.py:182)
+    const int step = a.counters[1] + 1;            // (read before the barrier; thread 0 advances them at the end)
+    if (live) {
+        s_xyz[3 * p] = a.xyz[3 * p]; s_xyz[3 * p + 1] = a.xyz[3 * p + 1]; s_xyz[3 * p + 2] = a.xyz[3 * p + 2];
+    }
+    // LR schedule + bias corrections, in double like the host code (train.py:134, quirk Q9).  The four double
+    // transcendentals are a few hundred dependent instructions each; one lane of each of the four wavefronts takes
+    // one of them so that they run side by side (different lanes of ONE wavefront would serialise).
+    // s_hyp: step sizes xyz / scaling / rotation / opacity, sqrt(bias_correction2), spare
+    // s_d:   delay factor, exp(interpolated log lr), beta1^step, beta2^step
+    if ((p & 63) == 0) {
+        const int w = p >> 6;
+        const bool sched = !(a.lr_init == 0.0 && a.lr_final == 0.0);
+        if (w == 0) {
+            double delay = 1.0;
+            if (sched && a.lr_delay_steps > 0) {
+                const double c = fmin(fmax((double)it1 / (double)a.lr_delay_steps, 0.0), 1.0);
+                delay = a.lr_delay_mult + (1.0 - a.lr_delay_mult) * sin(0.5 * 3.14159265358979323846 * c);
+            }
+            s_d[0] = delay;
+        } else if (w == 1) {
+            const double t = fmin(fmax((double)it1 / (double)a.lr_max_steps, 0.0), 1.0);
+            s_d[1] = sched ? exp(a.log_lr_init * (1.0 - t) + a.log_lr_final * t) : 0.0;
+        } else if (w == 2) {
+            s_d[2] = pow(a.beta1, (double)step);
+        } else {
+            s_d[3] = pow(a.beta2, (double)step);
+        }
+    }
+    __syncthreads();
+    if (p == 0) {
+        const double lr_xyz = s_d[0] * s_d[1];
+        const double bc1 = 1.0 - s_d[2];
+        s_hyp[0] = (float)(lr_xyz / bc1);
+        s_hyp[1] = (float)(a.lr_scaling / bc1);
+        s_hyp[2] = (float)(a.lr_rotation / bc1);
+        s_hyp[3] = (float)(a.lr_opacity / bc1);
+        s_hyp[4] = (float)sqrt(1.0 - s_d[3]);
+    }
+    __syncthreads();
+    // limb-symmetry loss gradient: L = lambda * (| |la| - |ra| | + | |ll| - |rl| |)  (loss_utils.py:226-250);
+    // every view's loss contains it, so every slot carries it (train.py:150-152,175)
+    float gc[3] = { 0, 0, 0 };
+    if (live && a.lambda_consistency != 0.0f && a.limb[0] >= 0) {
+        float len[4], dir[4][3];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i0 = a.limb[2 * k], i1 = a.limb[2 * k + 1];
+            float d[3] = { s_xyz[3 * i0] - s_xyz[3 * i1], s_xyz[3 * i0 + 1] - s_xyz[3 * i1 + 1], s_xyz[3 * i0 + 2] - s_xyz[3 * i1 + 2] };
+            len[k] = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+#pragma unroll
+            for (int c = 0; c < 3; c++) dir[k][c] = len[k] > 0.0f ? d[c] / len[k] : 0.0f;
+        }
+        // d|x|/dx = sign(x) (torch.norm of a scalar; 0 at 0)
+        const float sa = (len[0] - len[1]) > 0.0f ? 1.0f : ((len[0] - len[1]) < 0.0f ? -1.0f : 0.0f);
+        const float sl = (len[2] - len[3]) > 0.0f ? 1.0f : ((len[2] - len[3]) < 0.0f ? -1.0f : 0.0f);
+        const float coef[4] = { sa, -sa, sl, -sl };
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float w = a.lambda_consistency * coef[k];
+            if (p == a.limb[2 * k])
+                for (int c = 0; c < 3; c++) gc[c] += w * dir[k][c];
+            if (p == a.limb[2 * k + 1])
+                for (int c = 0; c < 3; c++) gc[c] -= w * dir[k][c];
+        }
+    }
+    if (!live) return;
+    // slots of the views rendered in this group get this group's gradient (others keep what they had: quirk Q8)
+    float gx[3] = { 0, 0, 0 };
+    for (int v = 0; v < V; v++) {
+        float* sl = a.slots + ((size_t)v * P + p) * 3;
+        if ((a.group_mask >> v) & 1ull) {
+            const float* gr = a.grads + ((size_t)v * P + p) * 11;
+#pragma unroll
+            for (int c = 0; c < 3; c++) sl[c] = gr[c] + gc[c];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) gx[c] += sl[c];   // mean over the V slots, view order (train.py:215-217)
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) gx[c] /= (float)V;
+    const float* gl = a.grads + ((size_t)a.last_view * P + p) * 11;
+    const float bc2s = s_hyp[4];
+    const float w1 = (float)(1.0 - a.beta1), b2 = (float)a.beta2, w2 = (float)(1.0 - a.beta2), eps = (float)a.eps;
+    const float ss_xyz = s_hyp[0], ss_s = s_hyp[1], ss_r = s_hyp[2], ss_o = s_hyp[3];
+    float* m = a.m + (size_t)p * 11;
+    float* vv = a.vv + (size_t)p * 11;
+#pragma unroll
+    for (int c = 0; c < 3; c++) adam_update(a.xyz[3 * p + c], gx[c], m[c], vv[c], w1, b2, w2, eps, ss_xyz, bc2s);
+#pragma unroll
+    for (int c = 0; c < 3; c++) adam_update(a.scaling[3 * p + c], gl[3 + c], m[3 + c], vv[3 + c], w1, b2, w2, eps, ss_s, bc2s);
+#pragma unroll
+    for (int c = 0; c < 4; c++) adam_update(a.rotation[4 * p + c], gl[6 + c], m[6 + c], vv[6 + c], w1, b2, w2, eps, ss_r, bc2s);
+    adam_update(a.opacity[p], gl[10], m[10], vv[10], w1, b2, w2, eps, ss_o, bc2s);
+    if (p == 0) { a.counters[0] = it1; a.counters[1] = step; }
+}
+
+
+// host: fills AdamArgs from the C ABI's argument lists; returns nullptr or an error text
+inline const char* fill_adam_args(AdamArgs& a, int V, int P, const float* grads, float* slots, unsigned long long group_mask,
+                                  int last_view, float* xyz, float* scaling, float* rotation, float* opacity, float* exp_avg,
+                                  float* exp_avg_sq, int* counters, int acc_steps, const double* lr_sched, const double* lrs,
+                                  const double* adam, float lambda_consistency, const int* limb)
+{
+    if (!grads || !slots || !xyz || !scaling || !rotation || !opacity || !exp_avg || !exp_avg_sq || !counters || !lr_sched || !lrs || !adam)
+        return "loop_adam: missing pointer";
+    if (last_view < 0 || last_view >= V) return "loop_adam: last_view out of range";
+    a.V = V; a.P = P; a.grads = grads; a.slots = slots; a.group_mask = group_mask; a.last_view = last_view;
+    a.xyz = xyz; a.scaling = scaling; a.rotation = rotation; a.opacity = opacity; a.m = exp_avg; a.vv = exp_avg_sq;
+    a.counters = counters; a.acc_steps = acc_steps;
+    a.lr_init = lr_sched[0]; a.lr_final = lr_sched[1]; a.lr_delay_mult = lr_sched[2];
+    a.log_lr_init = lr_sched[0] > 0.0 ? log(lr_sched[0]) : 0.0;
+    a.log_lr_final = lr_sched[1] > 0.0 ? log(lr_sched[1]) : 0.0;
+    a.lr_delay_steps = (int)lr_sched[3]; a.lr_max_steps = (int)lr_sched[4];
+    a.lr_scaling = lrs[0]; a.lr_rotation = lrs[1]; a.lr_opacity = lrs[2];
+    a.beta1 = adam[0]; a.beta2 = adam[1]; a.eps = adam[2];
+    a.lambda_consistency = lambda_consistency;
+    for (int i = 0; i < 8; i++) a.limb[i] = limb ? limb[i] : -1;
+    if (limb) for (int i = 0; i < 8; i++) if (limb[i] < 0 || limb[i] >= P) return "loop_adam: limb index out of range";
+    a.n_joints = P;
+    return nullptr;
+}
+
+}  // namespace sksloop

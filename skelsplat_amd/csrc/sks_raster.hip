@@ -21,6 +21,7 @@
 
 #include "../../include/skelsplat_hip.h"
 #include "sks_math.h"
+#include "sks_loop_dev.h"
 
 using namespace sks;
 
@@ -185,16 +186,14 @@ inline size_t bin_bytes(int V, int NT, size_t cap)
 // ------------------------------------------------------------------------------------------------------------
 // geometry forward: preprocessCUDA, DGR/cuda_rasterizer/forward.cu:153-273 (+ in_frustum auxiliary.h:151-176)
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_geom_fwd(int P, int W, int H, ViewTan vt, const float* __restrict__ vms,
-                                                   const float* __restrict__ pms, const float* __restrict__ means,
-                                                   const float* __restrict__ opac, const float* __restrict__ scales,
-                                                   const float* __restrict__ rots, const float* __restrict__ cov3Dp,
-                                                   float smod, unsigned flags, Geom g, int* __restrict__ radii)
+// one (view, Gaussian) pair; returns the tile rect (all zero when culled or !live)
+__device__ __forceinline__ uint4 geom_fwd_one(int P, int W, int H, const ViewTan& vt, const float* __restrict__ vms,
+                                              const float* __restrict__ pms, const float* __restrict__ means,
+                                              const float* __restrict__ opac, const float* __restrict__ scales,
+                                              const float* __restrict__ rots, const float* __restrict__ cov3Dp,
+                                              float smod, unsigned flags, const Geom& g, int* __restrict__ radii,
+                                              int v, int idx, bool live)
 {
-    __shared__ uint32_t s_cov[COVER_MAX_WORDS];
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    const int v = blockIdx.y;
-    const bool live = idx < P;
     const size_t o = (size_t)v * P + (live ? idx : 0);
     const float* V = vms + 16 * v;
     const float* PM = pms + 16 * v;
@@ -263,7 +262,22 @@ __global__ __launch_bounds__(256) void k_geom_fwd(int P, int W, int H, ViewTan v
         g.xyd[o] = xyd;
         g.rect[o] = rect;
     }
+    return rect;
+}
+
+__global__ __launch_bounds__(256) void k_geom_fwd(int P, int W, int H, ViewTan vt, const float* __restrict__ vms,
+                                                   const float* __restrict__ pms, const float* __restrict__ means,
+                                                   const float* __restrict__ opac, const float* __restrict__ scales,
+                                                   const float* __restrict__ rots, const float* __restrict__ cov3Dp,
+                                                   float smod, unsigned flags, Geom g, int* __restrict__ radii)
+{
+    __shared__ uint32_t s_cov[COVER_MAX_WORDS];
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int v = blockIdx.y;
+    const bool live = idx < P;
+    const uint4 rect = geom_fwd_one(P, W, H, vt, vms, pms, means, opac, scales, rots, cov3Dp, smod, flags, g, radii, v, idx, live);
     if (g.cover) {  // single block per view (P <= 256): bitmap of covered tiles for the forward's fill blocks
+        const int gy = (H + TILE - 1) / TILE;
         const int cw = cover_cw(W), nw = gy * cw;
         for (int i = threadIdx.x; i < nw; i += 256) s_cov[i] = 0u;
         __syncthreads();
@@ -1321,14 +1335,13 @@ struct GeomBwdArgs {
 
 __device__ __forceinline__ float sq(float x) { return x * x; }
 
-__global__ __launch_bounds__(256) void k_geom_bwd(GeomBwdArgs a, ViewTan vt)
+// part 1 of one (view, Gaussian) pair: the per-split partial sums -> g[0..7], dL/dfeatures, and this Gaussian's share of
+// the fused loss sums (slots 7 / 8)
+__device__ __forceinline__ void geom_bwd_load(const GeomBwdArgs& a, int v, int idx, float (&g)[NACC], double& pS, double& pN)
 {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    const int v = blockIdx.y;
     const size_t o = (size_t)v * a.P + (idx < a.P ? idx : 0);
     const int NVS = NACC + a.C;
     const float* acc = a.accum + o * a.nsplit * NVS;  // layout (value, split)
-    float g[NACC];
     if (a.nsplit == BWD_SPLITS) {
         static_assert(BWD_SPLITS == 16, "4 x float4 per value");
         float4 q[NACC][4];
@@ -1359,26 +1372,21 @@ __global__ __launch_bounds__(256) void k_geom_bwd(GeomBwdArgs a, ViewTan vt)
             a.dfeat[o * a.C + ch] = t;
         }
     }
-    if (a.loss_sums) {  // fused-loss mode (single block per view): image-wide S and N from the owners' partial sums
-        __shared__ double s_l[2][4];
-        double pS = 0.0, pN = 0.0;
-        if (idx < a.P) {
-            for (int sp = 0; sp < a.nsplit; sp++) {
-                pS += (double)acc[7 * a.nsplit + sp];
-                pN += (double)acc[8 * a.nsplit + sp];
-            }
+    pS = 0.0;
+    pN = 0.0;
+    if (a.loss_sums && idx < a.P) {
+        for (int sp = 0; sp < a.nsplit; sp++) {
+            pS += (double)acc[7 * a.nsplit + sp];
+            pN += (double)acc[8 * a.nsplit + sp];
         }
-        pS = wave_sum_d(pS);
-        pN = wave_sum_d(pN);
-        if ((threadIdx.x & 63) == 0) { s_l[0][threadIdx.x >> 6] = pS; s_l[1][threadIdx.x >> 6] = pN; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            a.loss_sums[2 * v] = a.gt_totals[2 * v] + ((s_l[0][0] + s_l[0][1]) + (s_l[0][2] + s_l[0][3]));
-            a.loss_sums[2 * v + 1] = a.gt_totals[2 * v + 1] + ((s_l[1][0] + s_l[1][1]) + (s_l[1][2] + s_l[1][3]));
-        }
-        __syncthreads();   // the packed-gradient epilogue of every thread reads N_v back (same block, same L1)
     }
-    if (idx >= a.P) return;
+}
+
+// part 2: the reference's formulas; n_view = the view's mask count N_v (fused-loss mode, else unused)
+__device__ __forceinline__ void geom_bwd_finish(const GeomBwdArgs& a, const ViewTan& vt, int v, int idx, const float (&g)[NACC],
+                                                double n_view)
+{
+    const size_t o = (size_t)v * a.P + idx;
     float dmean[3] = { 0, 0, 0 }, dcov[6] = { 0, 0, 0, 0, 0, 0 }, dscale[3] = { 0, 0, 0 }, dq[4] = { 0, 0, 0, 0 };
     float sc[3] = { 0, 0, 0 }, q[4] = { 1, 0, 0, 0 }, qnorm = 1.0f;   // activated scale / rotation (raw mode: see activate())
     float dop = g[5];
@@ -1522,9 +1530,9 @@ __global__ __launch_bounds__(256) void k_geom_bwd(GeomBwdArgs a, ViewTan vt)
             dq[3] = 2 * r * (dMt.m[0][1] - dMt.m[1][0]) + 2 * x * (dMt.m[2][0] + dMt.m[0][2]) + 2 * y * (dMt.m[1][2] + dMt.m[2][1]) - 4 * z * (dMt.m[1][1] + dMt.m[0][0]);
         }
     }
-    a.dmeans3D[3 * o] = dmean[0]; a.dmeans3D[3 * o + 1] = dmean[1]; a.dmeans3D[3 * o + 2] = dmean[2];
-    a.dmeans2D[3 * o] = dm2x; a.dmeans2D[3 * o + 1] = dm2y; a.dmeans2D[3 * o + 2] = 0.0f;
-    a.dopacity[o] = dop;
+    if (a.dmeans3D) { a.dmeans3D[3 * o] = dmean[0]; a.dmeans3D[3 * o + 1] = dmean[1]; a.dmeans3D[3 * o + 2] = dmean[2]; }
+    if (a.dmeans2D) { a.dmeans2D[3 * o] = dm2x; a.dmeans2D[3 * o + 1] = dm2y; a.dmeans2D[3 * o + 2] = 0.0f; }
+    if (a.dopacity) a.dopacity[o] = dop;
     if (a.dcov3D) {
 #pragma unroll
         for (int i = 0; i < 6; i++) a.dcov3D[6 * o + i] = dcov[i];
@@ -1535,10 +1543,7 @@ __global__ __launch_bounds__(256) void k_geom_bwd(GeomBwdArgs a, ViewTan vt)
         // raw-parameter gradients [xyz 3 | _scaling 3 | _rotation 4 | _opacity 1] through the activation Jacobians
         // (what autograd does through exp / normalize / sigmoid), times 1/N_v of the fused masked-L2 loss
         float scl = 1.0f;
-        if (a.loss_sums) {
-            const double n = a.loss_sums[2 * v + 1];   // written by thread 0 of this block above
-            scl = (float)(1.0 / (n < 1.0 ? 1.0 : n));
-        }
+        if (a.loss_sums) scl = (float)(1.0 / (n_view < 1.0 ? 1.0 : n_view));
         float* pk = a.packed + o * 11;
         const bool raw = a.flags & SKS_RAW_PARAMS;
         pk[0] = dmean[0] * scl; pk[1] = dmean[1] * scl; pk[2] = dmean[2] * scl;
@@ -1556,6 +1561,66 @@ __global__ __launch_bounds__(256) void k_geom_bwd(GeomBwdArgs a, ViewTan vt)
         }
         pk[10] = dop * oj * scl;
     }
+}
+
+__global__ __launch_bounds__(256) void k_geom_bwd(GeomBwdArgs a, ViewTan vt)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int v = blockIdx.y;
+    float g[NACC];
+    double pS, pN;
+    geom_bwd_load(a, v, idx, g, pS, pN);
+    double n_view = 1.0;
+    if (a.loss_sums) {  // fused-loss mode (single block per view): image-wide S and N from the owners' partial sums
+        __shared__ double s_l[2][4];
+        pS = wave_sum_d(pS);
+        pN = wave_sum_d(pN);
+        if ((threadIdx.x & 63) == 0) { s_l[0][threadIdx.x >> 6] = pS; s_l[1][threadIdx.x >> 6] = pN; }
+        __syncthreads();
+        const double S = a.gt_totals[2 * v] + ((s_l[0][0] + s_l[0][1]) + (s_l[0][2] + s_l[0][3]));
+        n_view = a.gt_totals[2 * v + 1] + ((s_l[1][0] + s_l[1][1]) + (s_l[1][2] + s_l[1][3]));
+        if (threadIdx.x == 0) {
+            a.loss_sums[2 * v] = S;
+            a.loss_sums[2 * v + 1] = n_view;
+        }
+    }
+    if (idx >= a.P) return;
+    geom_bwd_finish(a, vt, v, idx, g, n_view);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Fused tail of one accumulation group of the sparse loop on ONE GPU (sks_loop_fused_step): everything that follows the
+// compositing backward and precedes the next one is tiny (V*P <= a few hundred work items) and used to be three
+// launches (k_geom_bwd, k_loop_adam, k_geom_fwd of the next group) whose fixed cost and the gaps between them were a
+// third of the group.  One 256-thread workgroup runs them back to back:
+//   A  geometry backward of every view: wavefront w takes views w, w+4, ...; lane = Gaussian (P <= 64), so a view's
+//      loss sums are one wave reduction; writes the packed raw-parameter gradients;
+//   B  the optimiser step (slots, mean over views, limb gradient, LR schedule, Adam) -- sks_loop_dev.h;
+//   C  geometry forward of the UPDATED parameters, i.e. the geom / radii the next group's compositor reads.
+// Same arithmetic in the same order as the separate kernels (bit-identical results).
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_step_tail(GeomBwdArgs ga, ViewTan vt, sksloop::AdamArgs aa, int V, Geom g, int* radii)
+{
+    __shared__ float s_xyz[256 * 3];
+    __shared__ float s_hyp[6];
+    __shared__ double s_d[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int v = wv; v < V; v += 4) {
+        float gs[NACC];
+        double pS, pN;
+        geom_bwd_load(ga, v, lane, gs, pS, pN);
+        pS = wave_sum_d(pS);
+        pN = wave_sum_d(pN);
+        const double S = ga.gt_totals[2 * v] + pS, n_view = ga.gt_totals[2 * v + 1] + pN;
+        if (lane == 0) { ga.loss_sums[2 * v] = S; ga.loss_sums[2 * v + 1] = n_view; }
+        if (lane < ga.P) geom_bwd_finish(ga, vt, v, lane, gs, n_view);
+    }
+    __syncthreads();   // every view's packed gradients are written (same workgroup, same L1)
+    sksloop::adam_block_step(aa, s_xyz, s_hyp, s_d);
+    __syncthreads();   // the parameters are updated
+    for (int v = wv; v < V; v += 4)
+        geom_fwd_one(ga.P, ga.W, ga.H, vt, ga.vms, ga.pms, ga.means, ga.opac, ga.scales, ga.rots, ga.cov3Dp, ga.smod, ga.flags, g,
+                     radii, v, lane, lane < ga.P);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -2291,6 +2356,50 @@ int sks_geometry(int V, int P, int C, int W, int H, const float* viewmatrix, con
     hipLaunchKernelGGL(k_geom_fwd, dim3((P + 255) / 256, V), dim3(256), 0, st, P, W, H, vt, viewmatrix, projmatrix,
                        means3D, opacities, scales, rotations, cov3D_precomp, scale_modifier, flags, g, radii);
     STAGE_CHECK("geometry");
+    return 0;
+}
+
+int sks_loop_fused_step(int V, int P, int C, int W, int H, const float* viewmatrix, const float* projmatrix,
+                        const float* tanfovx, const float* tanfovy, const float* features, float scale_modifier,
+                        unsigned flags, int* radii, void* geom, const float* gt, const double* gt_totals, void* accum,
+                        double* loss_sums, float* packed, float* slots, unsigned long long group_mask, int last_view,
+                        float* xyz, float* scaling, float* rotation, float* opacity, float* exp_avg, float* exp_avg_sq,
+                        int* counters, int acc_steps, const double* lr_sched, const double* lrs, const double* adam,
+                        float lambda_consistency, const int* limb, void* stream)
+{
+    if (int rc = check_common(V, P, C, W, H)) return rc;
+    if (P < 1 || P > 64) return fail(-1, "fused step needs 1 <= P <= 64 (got %d)", P);
+    if (!viewmatrix || !projmatrix || !tanfovx || !tanfovy || !features || !radii || !geom || !gt || !gt_totals || !accum ||
+        !loss_sums || !packed)
+        return fail(-2, "missing required pointer");
+    hipStream_t st = (hipStream_t)stream;
+    ViewTan vt;
+    for (int v = 0; v < V; v++) { vt.x[v] = tanfovx[v]; vt.y[v] = tanfovy[v]; }
+    flags |= SKS_RAW_PARAMS | SKS_CLAMP01;
+    sksloop::AdamArgs aa;
+    if (const char* err = sksloop::fill_adam_args(aa, V, P, packed, slots, group_mask, last_view, xyz, scaling, rotation, opacity,
+                                                  exp_avg, exp_avg_sq, counters, acc_steps, lr_sched, lrs, adam,
+                                                  lambda_consistency, limb))
+        return fail(-2, "%s", err);
+    Geom g = geom_from(geom, V, P, W, H);
+    g.cover = nullptr;   // no forward render on this path
+    BwdArgs a{ P, C, W, H, flags, g, features, nullptr, gt, nullptr, (float*)accum, nullptr, nullptr };
+    dim3 grid(BWD_SPLITS, P, V);
+    {
+        ProfScope prof(1, st);
+        switch (pick_cg(C)) {
+            case 4: hipLaunchKernelGGL((k_render_bwd_wave<4, false, true>), grid, dim3(256), 0, st, a); break;
+            case 16: hipLaunchKernelGGL((k_render_bwd_wave<16, false, true>), grid, dim3(256), 0, st, a); break;
+            case 20: hipLaunchKernelGGL((k_render_bwd_wave<20, false, true>), grid, dim3(256), 0, st, a); break;
+            default: hipLaunchKernelGGL((k_render_bwd_wave<32, false, true>), grid, dim3(256), 0, st, a); break;
+        }
+    }
+    STAGE_CHECK("render-backward(fused loss)");
+    GeomBwdArgs ga{ P, C, W, H, flags, viewmatrix, projmatrix, xyz, opacity, scaling, rotation, nullptr, scale_modifier, radii,
+                    (const float*)accum, BWD_SPLITS, gt_totals, loss_sums, packed, nullptr, nullptr, nullptr, nullptr, nullptr,
+                    nullptr, nullptr };
+    hipLaunchKernelGGL(k_step_tail, dim3(1), dim3(256), 0, st, ga, vt, aa, V, g, radii);
+    STAGE_CHECK("step tail");
     return 0;
 }
 

@@ -71,7 +71,7 @@ class MultiViewLoop:
 
     def __init__(self, gaussians, cameras, heatmaps, dataset="h36m", accumulation_steps=4, lambda_consistency=1e-5,
                  bg=None, antialiasing=False, loss_grad=None, group=None, view_grad_fn=None, device_tail=None,
-                 use_graph=False, sparse=None):
+                 use_graph=False, sparse=None, fused_tail=None):
         self.gm = gaussians
         self.dataset = dataset
         self.V = len(cameras)
@@ -145,6 +145,19 @@ class MultiViewLoop:
             self.exp_avg = torch.zeros((P, 11), device=dev)
             self.exp_avg_sq = torch.zeros((P, 11), device=dev)
             self.counters = torch.zeros(2, dtype=torch.int32, device=dev)
+        # one GPU, one image size, sparse step: the whole group is two launches (sks_loop_fused_step); the geometry of
+        # the current parameters lives in a persistent state that every step leaves up to date for the next one
+        self.fused_tail = (self.sparse and self.world == 1 and len(self.size_groups) == 1 and bg is None
+                           and fused_tail is not False)
+        self._fstate = None          # persistent ForwardState (geom + radii) of the fused tail
+        self._geom_valid = False     # does it describe the current parameters?
+        if self.fused_tail:          # persistent buffers are allocated here, never inside a graph capture
+            slots, vb, gt, stats = self.size_groups[0]
+            with torch.no_grad():
+                self._fstate = R.geometry_views(vb, gaussians._xyz.detach(), gaussians.get_features.reshape(P, -1).shape[1],
+                                                gaussians._opacity, gaussians._scaling, gaussians._rotation, None,
+                                                antialiasing=self.antialiasing, raw_params=True)
+            self._fbuf = (torch.empty((self.V, P, 11), device=dev), torch.empty((self.V, 2), dtype=torch.float64, device=dev))
 
     # -- scene streaming ---------------------------------------------------------------------------------------
     def new_scene(self, points, poses_2d=None, heatmaps=None):
@@ -178,6 +191,7 @@ class MultiViewLoop:
                     raise ValueError("new_scene needs poses_2d or heatmaps")
                 if stats is not None:
                     R.gt_tile_stats(gt, out=stats)
+        self._geom_valid = False
         self.iteration = 0    # (last_losses keeps pointing at the buffers the captured graphs write)
         return self
 
@@ -220,6 +234,19 @@ class MultiViewLoop:
         gm, P, dev = self.gm, self.P, self.device
         stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.no_grad():
+            if self.fused_tail:
+                slots, vb, gt, stats = self.size_groups[0]
+                feats = gm.get_features.reshape(P, -1)
+                if not self._geom_valid:
+                    self._fstate = R.geometry_views(vb, gm._xyz.detach(), feats.shape[1], gm._opacity, gm._scaling, gm._rotation,
+                                                    None, antialiasing=self.antialiasing, raw_params=True, out=self._fstate)
+                    self._geom_valid = True
+                packed, sums = self._fbuf
+                R.loop_fused_step(self._fstate, stats, feats, packed, sums, self.accumulated_grads, group_mask, last_view,
+                                  gm._xyz, gm._scaling, gm._rotation, gm._opacity, self.exp_avg, self.exp_avg_sq, self.counters,
+                                  n_iters, self._sched, self._lrs, self._adam, float(self.lambda_consistency), self._limb)
+                self.last_losses = (sums[:, 0], sums[:, 1])
+                return
             if self.local_ids:
                 means = gm._xyz.detach()
                 feats = gm.get_features.reshape(P, -1)
@@ -300,10 +327,12 @@ class MultiViewLoop:
                     # warm up on a side stream, then capture one group; replays advance the device counters themselves
                     graph = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(graph):
+                        self._geom_valid = False    # (see run(): a replay never assumes who ran before it)
                         self._device_group(*key)
                     self._graph = (key, graph)      # the capture itself does not execute: replay below
                 self._graph[1].replay()
             else:
+                self._geom_valid = False    # eager steps never assume the parameters were left untouched since the last one
                 self._device_group(*key)
             self.iteration = it1
             return it1
@@ -364,6 +393,7 @@ class MultiViewLoop:
                     remaining -= 1
                     graph = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(graph):
+                        self._geom_valid = False    # every replay starts by refreshing the geometry (new_scene, eager steps)
                         for _ in range(G):
                             self._device_group(*key)
                     self._multi = ((key, G), graph)

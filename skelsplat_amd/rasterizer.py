@@ -436,7 +436,7 @@ def gt_tile_stats(gt, out=None, tiles=False):
 
 
 def geometry_views(views: ViewBatch, means3D, C, opacities, scales, rotations, cov3D_precomp, scale_modifier=1.0,
-                   antialiasing=False, raw_params=False):
+                   antialiasing=False, raw_params=False, out=None):
     """Geometry stage only (no image): returns a ForwardState usable by backward_fused_loss.  raw_params: the three
     tensors are the leaf parameters (_opacity, _scaling, _rotation); activations run in-kernel (SKS_RAW_PARAMS)."""
     lib = _lib.load()
@@ -448,8 +448,11 @@ def geometry_views(views: ViewBatch, means3D, C, opacities, scales, rotations, c
     V, W, H = views.V, views.W, views.H
     flags = (_lib.SKS_ANTIALIASING if antialiasing else 0) | (_lib.SKS_RAW_PARAMS if raw_params else 0)
     gbytes, _, _ = _lib.scratch_bytes(V, max(P, 1), C, W, H, 0)
-    radii = torch.empty((V, P), dtype=torch.int32, device=dev)
-    geom = torch.empty(gbytes, dtype=torch.uint8, device=dev)
+    if out is not None and out.P == P and out.C == C and out.views is views and out.flags == flags:
+        radii, geom = out.radii, out.geom       # refill in place (persistent state of the fused loop step)
+    else:
+        radii = torch.empty((V, P), dtype=torch.int32, device=dev)
+        geom = torch.empty(gbytes, dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         rc = lib.sks_geometry(V, P, C, W, H, views.viewmatrix.data_ptr(), views.projmatrix.data_ptr(), views.tanfovx,
                               views.tanfovy, _lib.ptr(means3D), _lib.ptr(opacities), _lib.ptr(scales), _lib.ptr(rotations),
@@ -460,6 +463,31 @@ def geometry_views(views: ViewBatch, means3D, C, opacities, scales, rotations, c
     st.views, st.P, st.C, st.flags, st.scale_modifier = views, P, C, flags, float(scale_modifier)
     st.geom, st.binning, st.bin_capacity, st.radii, st.num_rendered_dev = geom, None, 0, radii, None
     return st
+
+
+def loop_fused_step(st: ForwardState, stats: GtStats, features, packed, sums, slots, group_mask, last_view, xyz, scaling,
+                    rotation, opacity, exp_avg, exp_avg_sq, counters, acc_steps, lr_sched, lrs, adam, lambda_consistency, limb):
+    """sks_loop_fused_step: fused-loss compositing backward + (geometry backward, Adam step, geometry forward of the
+    updated parameters) for one accumulation group; `st` must describe the current parameters and is left describing the
+    updated ones.  lr_sched / lrs / adam / limb: ctypes arrays as for sks_loop_adam_step."""
+    lib = _lib.load()
+    dev = xyz.device
+    V, P, C = st.views.V, st.P, st.C
+    W, H = st.views.W, st.views.H
+    if tuple(stats.gt.shape) != (V, C, H, W):
+        raise RuntimeError(f"heat-maps {tuple(stats.gt.shape)} do not match the views {(V, C, H, W)}")
+    feat2 = _f32c(features, "features").reshape(P, -1)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    accum = _accum(dev, stream, V, P, C)
+    with torch.cuda.device(dev):
+        rc = lib.sks_loop_fused_step(V, P, C, W, H, st.views.viewmatrix.data_ptr(), st.views.projmatrix.data_ptr(),
+                                     st.views.tanfovx, st.views.tanfovy, feat2.data_ptr(), st.scale_modifier, st.flags,
+                                     st.radii.data_ptr(), st.geom.data_ptr(), stats.gt.data_ptr(), stats.totals.data_ptr(),
+                                     accum.data_ptr(), sums.data_ptr(), packed.data_ptr(), slots.data_ptr(), group_mask,
+                                     last_view, xyz.data_ptr(), scaling.data_ptr(), rotation.data_ptr(), opacity.data_ptr(),
+                                     exp_avg.data_ptr(), exp_avg_sq.data_ptr(), counters.data_ptr(), acc_steps, lr_sched, lrs,
+                                     adam, float(lambda_consistency), limb, stream)
+    _lib.check(rc, "sks_loop_fused_step")
 
 
 def backward_fused_loss(st: ForwardState, stats: GtStats, means3D, features, opacities, scales, rotations, cov3D_precomp,
