@@ -70,7 +70,10 @@ __global__ __launch_bounds__(256) void k_loop_adam(AdamArgs a)
     __shared__ float s_xyz[256 * 3];
     __shared__ float s_hyp[6];
     __shared__ double s_d[4];
-    sksloop::adam_block_step(a, s_xyz, s_hyp, s_d);
+    __shared__ int s_it[2];
+    sksloop::adam_block_begin(a, s_xyz, s_d, s_it);
+    __syncthreads();
+    sksloop::adam_block_finish(a, s_xyz, s_hyp, s_d, s_it);
 }
 
 }  // namespace

@@ -37,23 +37,35 @@ __device__ __forceinline__ void adam_update(float& param, float g, float& m, flo
     param = param - step_size * (m / denom);
 }
 
-// One optimiser step by one 256-thread workgroup (thread p < P owns Gaussian p).  Every thread of the workgroup must
-// call it (it synchronises).  s_xyz: 768 floats, s_hyp: 6 floats, s_d: 4 doubles of LDS.
-__device__ __forceinline__ void adam_block_step(const AdamArgs& a, float* s_xyz, float* s_hyp, double* s_d)
+// LDS mirror of the updated parameters (k_step_tail hands them to the next geometry pass without a trip to memory)
+struct AdamLdsParams {
+    float* xyz;       // 3 * P
+    float* scaling;   // 3 * P
+    float* rotation;  // 4 * P
+    float* opacity;   // P
+};
+
+// One optimiser step by one 256-thread workgroup (thread p < P owns Gaussian p), in two parts that every thread of the
+// workgroup must call, with a __syncthreads() between them:
+//   adam_block_begin : reads the step counters and the current xyz, starts the LR-schedule / bias-correction
+//                      transcendentals (needs nothing from the gradients, so a caller can overlap it with other work);
+//   adam_block_finish: slots, mean over views, limb gradient, Adam update, counters.
+// s_xyz: 768 floats, s_hyp: 6 floats, s_d: 4 doubles, s_it: 2 ints of LDS.
+__device__ __forceinline__ void adam_block_begin(const AdamArgs& a, float* s_xyz, double* s_d, int* s_it)
 {
     const int p = threadIdx.x;
-    const int P = a.P, V = a.V;
+    const int P = a.P;
     const bool live = p < P;
     const int it1 = a.counters[0] + a.acc_steps;   // iteration at which the optimiser steps (train.py:182)
-    const int step = a.counters[1] + 1;            // (read before the barrier; thread 0 advances them at the end)
+    const int step = a.counters[1] + 1;
+    if (p == 0) { s_it[0] = it1; s_it[1] = step; }
     if (live) {
         s_xyz[3 * p] = a.xyz[3 * p]; s_xyz[3 * p + 1] = a.xyz[3 * p + 1]; s_xyz[3 * p + 2] = a.xyz[3 * p + 2];
     }
     // LR schedule + bias corrections, in double like the host code (train.py:134, quirk Q9).  The four double
     // transcendentals are a few hundred dependent instructions each; one lane of each of the four wavefronts takes
     // one of them so that they run side by side (different lanes of ONE wavefront would serialise).
-    // s_hyp: step sizes xyz / scaling / rotation / opacity, sqrt(bias_correction2), spare
-    // s_d:   delay factor, exp(interpolated log lr), beta1^step, beta2^step
+    // s_d: delay factor, exp(interpolated log lr), beta1^step, beta2^step
     if ((p & 63) == 0) {
         const int w = p >> 6;
         const bool sched = !(a.lr_init == 0.0 && a.lr_final == 0.0);
@@ -73,7 +85,16 @@ __device__ __forceinline__ void adam_block_step(const AdamArgs& a, float* s_xyz,
             s_d[3] = pow(a.beta2, (double)step);
         }
     }
-    __syncthreads();
+}
+
+__device__ __forceinline__ void adam_block_finish(const AdamArgs& a, float* s_xyz, float* s_hyp, double* s_d, int* s_it,
+                                                  const AdamLdsParams* mirror = nullptr)
+{
+    const int p = threadIdx.x;
+    const int P = a.P, V = a.V;
+    const bool live = p < P;
+    const int it1 = s_it[0], step = s_it[1];
+    // s_hyp: step sizes xyz / scaling / rotation / opacity, sqrt(bias_correction2), spare
     if (p == 0) {
         const double lr_xyz = s_d[0] * s_d[1];
         const double bc1 = 1.0 - s_d[2];
@@ -131,13 +152,23 @@ __device__ __forceinline__ void adam_block_step(const AdamArgs& a, float* s_xyz,
     const float ss_xyz = s_hyp[0], ss_s = s_hyp[1], ss_r = s_hyp[2], ss_o = s_hyp[3];
     float* m = a.m + (size_t)p * 11;
     float* vv = a.vv + (size_t)p * 11;
+    float np[11];
 #pragma unroll
-    for (int c = 0; c < 3; c++) adam_update(a.xyz[3 * p + c], gx[c], m[c], vv[c], w1, b2, w2, eps, ss_xyz, bc2s);
+    for (int c = 0; c < 3; c++) { np[c] = a.xyz[3 * p + c]; adam_update(np[c], gx[c], m[c], vv[c], w1, b2, w2, eps, ss_xyz, bc2s); a.xyz[3 * p + c] = np[c]; }
 #pragma unroll
-    for (int c = 0; c < 3; c++) adam_update(a.scaling[3 * p + c], gl[3 + c], m[3 + c], vv[3 + c], w1, b2, w2, eps, ss_s, bc2s);
+    for (int c = 0; c < 3; c++) { np[3 + c] = a.scaling[3 * p + c]; adam_update(np[3 + c], gl[3 + c], m[3 + c], vv[3 + c], w1, b2, w2, eps, ss_s, bc2s); a.scaling[3 * p + c] = np[3 + c]; }
 #pragma unroll
-    for (int c = 0; c < 4; c++) adam_update(a.rotation[4 * p + c], gl[6 + c], m[6 + c], vv[6 + c], w1, b2, w2, eps, ss_r, bc2s);
-    adam_update(a.opacity[p], gl[10], m[10], vv[10], w1, b2, w2, eps, ss_o, bc2s);
+    for (int c = 0; c < 4; c++) { np[6 + c] = a.rotation[4 * p + c]; adam_update(np[6 + c], gl[6 + c], m[6 + c], vv[6 + c], w1, b2, w2, eps, ss_r, bc2s); a.rotation[4 * p + c] = np[6 + c]; }
+    np[10] = a.opacity[p];
+    adam_update(np[10], gl[10], m[10], vv[10], w1, b2, w2, eps, ss_o, bc2s);
+    a.opacity[p] = np[10];
+    if (mirror) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) { mirror->xyz[3 * p + c] = np[c]; mirror->scaling[3 * p + c] = np[3 + c]; }
+#pragma unroll
+        for (int c = 0; c < 4; c++) mirror->rotation[4 * p + c] = np[6 + c];
+        mirror->opacity[p] = np[10];
+    }
     if (p == 0) { a.counters[0] = it1; a.counters[1] = step; }
 }
 

@@ -1604,7 +1604,12 @@ __global__ __launch_bounds__(256) void k_step_tail(GeomBwdArgs ga, ViewTan vt, s
     __shared__ float s_xyz[256 * 3];
     __shared__ float s_hyp[6];
     __shared__ double s_d[4];
+    __shared__ int s_it[2];
+    __shared__ float s_np[64 * 11];   // the updated parameters, handed to phase C through LDS (P <= 64)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // the optimiser's scalar work (LR schedule, bias corrections: double transcendentals) needs no gradient: started
+    // first, it is finished long before phase A's loads are back
+    sksloop::adam_block_begin(aa, s_xyz, s_d, s_it);
     for (int v = wv; v < V; v += 4) {
         float gs[NACC];
         double pS, pN;
@@ -1616,11 +1621,13 @@ __global__ __launch_bounds__(256) void k_step_tail(GeomBwdArgs ga, ViewTan vt, s
         if (lane < ga.P) geom_bwd_finish(ga, vt, v, lane, gs, n_view);
     }
     __syncthreads();   // every view's packed gradients are written (same workgroup, same L1)
-    sksloop::adam_block_step(aa, s_xyz, s_hyp, s_d);
+    const int P = ga.P;
+    const sksloop::AdamLdsParams mirror{ s_np, s_np + 3 * P, s_np + 6 * P, s_np + 10 * P };
+    sksloop::adam_block_finish(aa, s_xyz, s_hyp, s_d, s_it, &mirror);
     __syncthreads();   // the parameters are updated
     for (int v = wv; v < V; v += 4)
-        geom_fwd_one(ga.P, ga.W, ga.H, vt, ga.vms, ga.pms, ga.means, ga.opac, ga.scales, ga.rots, ga.cov3Dp, ga.smod, ga.flags, g,
-                     radii, v, lane, lane < ga.P);
+        geom_fwd_one(P, ga.W, ga.H, vt, ga.vms, ga.pms, mirror.xyz, mirror.opacity, mirror.scaling, mirror.rotation, nullptr,
+                     ga.smod, ga.flags, g, radii, v, lane, lane < P);
 }
 
 // ------------------------------------------------------------------------------------------------------------

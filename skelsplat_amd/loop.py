@@ -147,8 +147,10 @@ class MultiViewLoop:
             self.counters = torch.zeros(2, dtype=torch.int32, device=dev)
         # one GPU, one image size, sparse step: the whole group is two launches (sks_loop_fused_step); the geometry of
         # the current parameters lives in a persistent state that every step leaves up to date for the next one
+        # (the single-workgroup tail walks the views four at a time: a win for a handful of views -- H36M's 4 --, a loss
+        # for Panoptic's 31, where the one-block-per-view kernels stay)
         self.fused_tail = (self.sparse and self.world == 1 and len(self.size_groups) == 1 and bg is None
-                           and fused_tail is not False)
+                           and (fused_tail is True or (fused_tail is None and self.V <= 8)))
         self._fstate = None          # persistent ForwardState (geom + radii) of the fused tail
         self._geom_valid = False     # does it describe the current parameters?
         if self.fused_tail:          # persistent buffers are allocated here, never inside a graph capture
