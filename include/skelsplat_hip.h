@@ -48,6 +48,8 @@ extern "C" {
 #define SKS_RAW_PARAMS   32u   /* opacities / scales / rotations are the LEAF parameters (_opacity logits, _scaling
                                  log-scales, raw _rotation); sigmoid / exp / normalize (scene/gaussian_model.py:39-47)
                                  run inside the kernels (sks_geometry, sks_forward, sks_backward*) */
+#define SKS_FILL_LINEAR (1u << 21)  /* tuning/tests: forward fill blocks always in linear (pass-major) mode */
+#define SKS_FILL_ROWS (1u << 22)    /* tuning/tests: row-aligned fill blocks whenever W % 4 == 0 */
 #define SKS_BWD_LDS_LIST (1u << 20) /* tests: use the LDS-list backward even when P <= 64 (default: wave-resident) */
 
 const char* sks_last_error(void);

@@ -6,6 +6,7 @@ plus the batched multi-view entry points the MI355X loop uses.
 """
 from typing import NamedTuple, Optional
 
+import os
 import weakref
 
 import torch
@@ -134,7 +135,7 @@ def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotati
     scales, rotations, cov3D_precomp = _f32c(scales, "scales"), _f32c(rotations, "rotations"), _f32c(cov3D_precomp, "cov3D_precomp")
     V, W, H = views.V, views.W, views.H
     flags = (_lib.SKS_ANTIALIASING if antialiasing else 0) | (_lib.SKS_CLAMP01 if clamp01 else 0) | \
-            (_lib.SKS_DEBUG_SYNC if debug else 0) | (_lib.SKS_FORCE_BINNED if force_binned else 0) | int(tune_flags)
+            (_lib.SKS_DEBUG_SYNC if debug else 0) | (_lib.SKS_FORCE_BINNED if force_binned else 0) | int(tune_flags) | _ENV_TUNE
     binned = force_binned or P > _lib.SKS_SMALL_P
     if binned and bin_capacity is None:
         bin_capacity = max(4096, 16 * P)
@@ -173,6 +174,7 @@ def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotati
 
 
 _BG_CACHE = {}
+_ENV_TUNE = int(os.environ.get("SKS_FWD_TUNE", "0"), 0)   # tuning experiments: extra forward flag bits (include/skelsplat_hip.h)
 
 
 def _bg_channels(bg, C, dev):

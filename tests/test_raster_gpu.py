@@ -59,6 +59,31 @@ def test_forward_bit_exact(device, kw, binned):
             assert np.array_equal(pl[v, :Rn].cpu().numpy().astype(np.uint32), o["point_list"])
 
 
+@pytest.mark.parametrize("W,H", [(1000, 40), (2048, 33), (960, 24), (1100, 20)], ids=lambda v: str(v))
+@pytest.mark.parametrize("binned", [False, True], ids=["small", "binned"])
+def test_forward_wide_images_row_aligned_fill(device, W, H, binned):
+    """Wide images whose rows are whole 128-byte lines (1920, 2048 ...) take the row-aligned fill blocks by default; both
+    fill modes are forced here at every width: bit-exact against the oracle, identical to each other, debug planes too."""
+    c = util.make_case(seed=51, W=W, H=H, n_views=2, scale_log=4.3, fxmul=0.2 * 1000.0 / W, ring=2500.0)
+    outs = []
+    for tune in (0, 1 << 21, 1 << 22):   # default / forced linear / forced row-aligned
+        color, inv, radii, st, final_T, n_contrib = run_forward(c, device, force_binned=binned, tune_flags=tune)
+        outs.append((color, inv, final_T, n_contrib))
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert torch.equal(a, b)
+    color, inv, final_T, n_contrib = outs[0]
+    covered = 0
+    for v in range(len(c.cams)):
+        o = util.oracle_forward(c, v)
+        covered += int((o["n_contrib"] > 0).sum())
+        assert np.array_equal(color[v].cpu().numpy(), o["color"])
+        assert np.array_equal(inv[v].cpu().numpy(), o["invdepth"])
+        assert np.array_equal(final_T[v].cpu().numpy(), o["final_T"])
+        assert np.array_equal(n_contrib[v].cpu().numpy().astype(np.uint32), o["n_contrib"])
+    assert covered > 200, "the splats should land inside the strip"
+
+
 @pytest.mark.parametrize("kw", CASES, ids=lambda k: f"seed{k['seed']}")
 @pytest.mark.parametrize("binned", [False, True], ids=["small", "binned"])
 @pytest.mark.parametrize("aa", [False, True], ids=["noaa", "aa"])

@@ -1,0 +1,9 @@
+import sys, os
+sys.path.insert(0, os.getcwd())
+from tools.tune_fwd import setup, run
+for dataset, V in (("h36m", 4), ("panoptic", 31)):
+    scene, views, params, dL = setup(dataset, V)
+    for rep in range(4):
+        for name, tune in (("default", 0), ("rows", 1 << 22), ("linear", 1 << 21)):
+            f, b, tot = run(views, params, dL, tune, iters=60 if V == 4 else 15)
+            print(f"{dataset} rep{rep} {name}: fwd {f:.1f} us bwd {b:.1f} us step {tot:.1f} us", flush=True)

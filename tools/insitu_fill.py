@@ -26,7 +26,7 @@ from skelsplat_amd import _lib
 # the forward and backward kernels in the same interleaving (hipEvent pairs around the kernel, like bench.py).
 # Experiments that switched pieces of the forward off (no cover look-up / no composite blocks / passes per block /
 # composite slots) were run from this script with temporary kernel flags; their numbers are in DESIGN.md section 5.
-for name, tune in (("sks fwd", 0), ("sks fwd, 3 passes per fill block", 3 << 8)):
+for name, tune in (("sks fwd (row-aligned fill)", 0), ("sks fwd, linear fill", 1 << 21), ("sks fwd, row-aligned, 1 row per block", 1 << 8), ("sks fwd, row-aligned, 4 rows per block", 4 << 8)):
     _lib.prof_enable(True); _lib.prof_read(0)
     for it in range(40):
         c, i, r, st2 = R.forward_views(views, *params, tune_flags=tune)
