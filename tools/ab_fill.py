@@ -1,5 +1,6 @@
+"""Interleaved A/B of the forward fill-block shapes on one box (row-aligned vs linear passes), as quoted in DESIGN.md."""
 import sys, os
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tools.tune_fwd import setup, run
 for dataset, V in (("h36m", 4), ("panoptic", 31)):
     scene, views, params, dL = setup(dataset, V)
