@@ -349,6 +349,30 @@ def test_scene_streaming_reuses_graphs(device, sparse):
         assert torch.equal(a.detach(), b.detach())
 
 
+def test_fused_step_tail_many_views(device):
+    """The single-workgroup tail walks the views four at a time: 7 views of a 19-joint skeleton (two rounds, the second
+    one partial) still equal the separate kernels bit for bit."""
+    from skelsplat_amd.loop import MultiViewLoop
+    from skelsplat_amd.heatmaps import generate_heatmaps
+    from skelsplat_amd.scene import SyntheticScene, GaussianModel
+    sc = SyntheticScene("panoptic", n_views=7, seed=23, W=192, H=112, ring=2500.0, fx=1400.0 * 0.1 * 1.5, device=device)
+    res = []
+    for fused in (True, False):
+        gm = GaussianModel().create_from_points(sc.pose_3d_init, sc.spatial_lr_scale, sc.n_joints, scaling=3.9,
+                                                scene_type="panoptic", device=device)
+        gm.training_setup()
+        hm = generate_heatmaps(gm._xyz.detach(), gm.get_scaling.detach(), gm._rotation.detach(),
+                               torch.tensor(sc.poses_2d, device=device), sc.cameras)
+        loop = MultiViewLoop(gm, sc.cameras, hm, dataset="panoptic", accumulation_steps=7, sparse=True, use_graph=True,
+                             fused_tail=fused)
+        assert loop.fused_tail == fused and loop.P == 19
+        loop.run(70, groups_per_graph=4)
+        res.append([t.detach().clone() for t in (gm._xyz, gm._scaling, gm._rotation, gm._opacity, loop.last_losses[1])])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    assert (res[0][0].cpu() - torch.tensor(sc.pose_3d_init).float()).norm(dim=1).mean() > 0.5
+
+
 @pytest.mark.parametrize("use_graph", [False, True], ids=["eager", "hipgraph"])
 def test_fused_step_tail_equals_separate_kernels(device, use_graph):
     """sks_loop_fused_step (compositing backward + one single-workgroup tail: geometry backward, Adam, geometry of the
