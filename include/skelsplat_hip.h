@@ -142,6 +142,10 @@ int sks_fused_ssim_bwd(int B, int CH, int H, int W, float C1, float C2, const fl
 /* Replaces distCUDA2 (submodules/simple-knn/spatial.cu:15-26 -> SimpleKNN::knn simple_knn.cu:186-222):
  * points (P,3) -> mean squared distance to the 3 nearest neighbours (P). */
 int sks_knn3_meandist2(int P, const float* points, float* mean_dist2, void* stream);
+/* The same result (identical floats) for large clouds: exact uniform-grid search, O(P) for well-spread points
+ * instead of the all-pairs sweep.  scratch: sks_knn3_scratch_bytes(P) bytes of device memory. */
+size_t sks_knn3_scratch_bytes(int P);
+int sks_knn3_meandist2_grid(int P, const float* points, float* mean_dist2, void* scratch, size_t scratch_bytes, void* stream);
 
 /* Sparse fused training step (no dense image, no dense gradient).  In the loop the render is only ever compared with the
  * constant pseudo-GT heat-maps (train.py:148-152), and it is exactly zero outside the tiles some Gaussian rect covers,

@@ -37,6 +37,8 @@ SIGNATURES = {
     "sks_fused_ssim_fwd": (_i, [_i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sks_fused_ssim_bwd": (_i, [_i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sks_knn3_meandist2": (_i, [_i, _vp, _vp, _vp]),
+    "sks_knn3_scratch_bytes": (_sz, [_i]),
+    "sks_knn3_meandist2_grid": (_i, [_i, _vp, _vp, _vp, _sz, _vp]),
     "sks_heatmaps": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sks_gt_tile_stats": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "sks_geometry": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _u, _vp, _vp, _vp]),

@@ -5,6 +5,7 @@
 // All HBM-bound elementwise / stencil work: 16-byte coalesced accesses, LDS-staged tiles, no MFMA.
 #include <hip/hip_runtime.h>
 #include <float.h>
+#include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
 
@@ -361,6 +362,182 @@ __global__ __launch_bounds__(256) void k_knn3(int P, const float* __restrict__ p
     if (i < P) out[i] = (best[0] + best[1] + best[2]) / 3.0f;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// 3-NN mean squared distance for LARGE clouds: exact search over a uniform grid (the reference sorts by Morton code and
+// prunes 1024-point boxes, simple_knn.cu:150-222; both are conservative, i.e. exact).  Points are bucketed into
+// ~2-per-cell cells (count -> scan -> scatter), then every point walks the cell shells around its own cell, keeping
+// the 3 best squared distances with the reference's updateKBest insertion, until the 3rd best cannot be beaten by
+// anything outside the shells already visited.  Distances are evaluated exactly like the all-pairs kernel, so the
+// two paths return identical floats.
+// ------------------------------------------------------------------------------------------------------------
+struct KnnGrid {
+    int n;             // cells per axis
+    float* part;       // [256][6] partial bounding boxes
+    uint32_t* start;   // n^3 + 1 exclusive cell offsets
+    uint32_t* cursor;  // n^3
+    float4* sorted;    // P points in cell order, .w = original index (bits)
+};
+inline int knn_cells_per_axis(int P)
+{
+    int n = (int)ceil(cbrt((double)P / 2.0));   // ~2 points per cell on average: dense regions of a non-uniform cloud
+    return n < 1 ? 1 : (n > 160 ? 160 : n);      // stay cheap, at the price of walking more (empty) cells elsewhere
+}
+inline size_t knn_scratch(int P, KnnGrid* g, void* base)
+{
+    const int n = knn_cells_per_axis(P);
+    const size_t nc = (size_t)n * n * n;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_part = take(256 * 6 * 4), o_start = take((nc + 1) * 4), o_cur = take(nc * 4), o_sorted = take((size_t)P * 16);
+    if (g) {
+        g->n = n;
+        g->part = (float*)((char*)base + o_part);
+        g->start = (uint32_t*)((char*)base + o_start);
+        g->cursor = (uint32_t*)((char*)base + o_cur);
+        g->sorted = (float4*)((char*)base + o_sorted);
+    }
+    return off;
+}
+
+__global__ __launch_bounds__(256) void k_knn_bbox(int P, const float* __restrict__ pts, float* __restrict__ part)
+{
+    __shared__ float s[6][256];
+    float lo[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, hi[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < P; i += gridDim.x * 256)
+        for (int k = 0; k < 3; k++) { const float v = pts[3 * i + k]; lo[k] = fminf(lo[k], v); hi[k] = fmaxf(hi[k], v); }
+    for (int k = 0; k < 3; k++) { s[k][threadIdx.x] = lo[k]; s[3 + k][threadIdx.x] = hi[k]; }
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o)
+            for (int k = 0; k < 3; k++) {
+                s[k][threadIdx.x] = fminf(s[k][threadIdx.x], s[k][threadIdx.x + o]);
+                s[3 + k][threadIdx.x] = fmaxf(s[3 + k][threadIdx.x], s[3 + k][threadIdx.x + o]);
+            }
+        __syncthreads();
+    }
+    if (threadIdx.x < 6) part[blockIdx.x * 6 + threadIdx.x] = s[threadIdx.x][0];
+}
+
+struct KnnBox { float lo[3], inv[3], h; };   // inv = cells per unit length, h = smallest cell edge
+
+// every block folds the <= 256 partial boxes itself (cheaper than another launch)
+__device__ __forceinline__ KnnBox knn_box(const float* __restrict__ part, int nparts, int n, float* s6)
+{
+    if (threadIdx.x < 6) {
+        float v = part[threadIdx.x];
+        for (int b = 1; b < nparts; b++) v = threadIdx.x < 3 ? fminf(v, part[b * 6 + threadIdx.x]) : fmaxf(v, part[b * 6 + threadIdx.x]);
+        s6[threadIdx.x] = v;
+    }
+    __syncthreads();
+    KnnBox bx;
+    bx.h = FLT_MAX;
+    for (int k = 0; k < 3; k++) {
+        bx.lo[k] = s6[k];
+        const float ext = fmaxf(s6[3 + k] - s6[k], 1e-30f);
+        bx.inv[k] = (float)n / ext;
+        bx.h = fminf(bx.h, ext / (float)n);
+    }
+    return bx;
+}
+__device__ __forceinline__ void knn_cell(const KnnBox& bx, int n, float x, float y, float z, int (&c)[3])
+{
+    const float p[3] = { x, y, z };
+    for (int k = 0; k < 3; k++) c[k] = min(n - 1, max(0, (int)((p[k] - bx.lo[k]) * bx.inv[k])));
+}
+
+__global__ __launch_bounds__(256) void k_knn_count(int P, const float* __restrict__ pts, KnnGrid g, int nparts)
+{
+    __shared__ float s6[6];
+    const KnnBox bx = knn_box(g.part, nparts, g.n, s6);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    int c[3];
+    knn_cell(bx, g.n, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], c);
+    atomicAdd(&g.cursor[(c[2] * g.n + c[1]) * g.n + c[0]], 1u);
+}
+
+__global__ __launch_bounds__(1024) void k_knn_scan(int ncell, KnnGrid g)
+{
+    __shared__ uint32_t s_part[1024];
+    const int tid = threadIdx.x;
+    const int per = (ncell + 1023) / 1024;
+    const int b = min(ncell, tid * per), e = min(ncell, b + per);
+    uint32_t sum = 0;
+    for (int i = b; i < e; i++) sum += g.cursor[i];
+    s_part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const uint32_t t = tid >= off ? s_part[tid - off] : 0;
+        __syncthreads();
+        s_part[tid] += t;
+        __syncthreads();
+    }
+    uint32_t run = tid ? s_part[tid - 1] : 0;
+    for (int i = b; i < e; i++) {
+        const uint32_t c = g.cursor[i];
+        g.start[i] = run;
+        g.cursor[i] = run;    // scatter cursor
+        run += c;
+    }
+    if (tid == 1023) g.start[ncell] = s_part[1023];
+}
+
+__global__ __launch_bounds__(256) void k_knn_scatter(int P, const float* __restrict__ pts, KnnGrid g, int nparts)
+{
+    __shared__ float s6[6];
+    const KnnBox bx = knn_box(g.part, nparts, g.n, s6);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+    int c[3];
+    knn_cell(bx, g.n, x, y, z, c);
+    const uint32_t pos = atomicAdd(&g.cursor[(c[2] * g.n + c[1]) * g.n + c[0]], 1u);
+    g.sorted[pos] = make_float4(x, y, z, __uint_as_float((uint32_t)i));
+}
+
+__global__ __launch_bounds__(256) void k_knn_search(int P, KnnGrid g, int nparts, float* __restrict__ out)
+{
+    __shared__ float s6[6];
+    const KnnBox bx = knn_box(g.part, nparts, g.n, s6);
+    const int si = blockIdx.x * 256 + threadIdx.x;   // position in cell order: neighbouring threads share cells
+    if (si >= P) return;
+    const float4 me = g.sorted[si];
+    const int n = g.n;
+    int c[3];
+    knn_cell(bx, n, me.x, me.y, me.z, c);
+    float best[3] = { FLT_MAX, FLT_MAX, FLT_MAX };
+    for (int r = 0; r < n; r++) {
+        // shell r: cells at Chebyshev distance exactly r from (c0, c1, c2)
+        const int z0 = max(0, c[2] - r), z1 = min(n - 1, c[2] + r);
+        const int y0 = max(0, c[1] - r), y1 = min(n - 1, c[1] + r);
+        const int x0 = max(0, c[0] - r), x1 = min(n - 1, c[0] + r);
+        for (int zz = z0; zz <= z1; zz++)
+            for (int yy = y0; yy <= y1; yy++) {
+                const bool face = abs(zz - c[2]) == r || abs(yy - c[1]) == r;
+                for (int xx = x0; xx <= x1; xx += (face || r == 0) ? 1 : max(1, x1 - x0)) {
+                    if (!face && abs(xx - c[0]) != r) continue;   // interior of the cube was visited by earlier shells
+                    const int cell = (zz * n + yy) * n + xx;
+                    const uint32_t s0 = g.start[cell], s1 = g.start[cell + 1];
+                    for (uint32_t j = s0; j < s1; j++) {
+                        if ((int)j == si) continue;
+                        const float4 q = g.sorted[j];
+                        const float dx = q.x - me.x, dy = q.y - me.y, dz = q.z - me.z;
+                        float dist = dx * dx + dy * dy + dz * dz;
+#pragma unroll
+                        for (int k = 0; k < 3; k++) {
+                            if (best[k] > dist) { const float t = best[k]; best[k] = dist; dist = t; }
+                        }
+                    }
+                }
+            }
+        // everything not visited yet is at least (r - slack) * h away (slack covers the rounding of the cell index)
+        const float reach = ((float)r - 1e-3f) * bx.h;
+        if (reach > 0.0f && best[2] <= reach * reach) break;
+    }
+    out[__float_as_uint(me.w)] = (best[0] + best[1] + best[2]) / 3.0f;
+}
+
 }  // namespace
 
 namespace {
@@ -466,6 +643,31 @@ int sks_knn3_meandist2(int P, const float* points, float* mean_dist2, void* stre
     if (P == 0) return 0;
     if (!points || !mean_dist2) return fail2(-2, "knn: missing pointer");
     hipLaunchKernelGGL(k_knn3, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, points, mean_dist2);
+    HIP_TRY2(hipGetLastError());
+    return 0;
+}
+
+size_t sks_knn3_scratch_bytes(int P)
+{
+    return P > 0 ? knn_scratch(P, nullptr, nullptr) : 0;
+}
+
+int sks_knn3_meandist2_grid(int P, const float* points, float* mean_dist2, void* scratch, size_t scratch_bytes, void* stream)
+{
+    if (P < 0) return fail2(-1, "knn: P negative");
+    if (P == 0) return 0;
+    if (!points || !mean_dist2 || !scratch) return fail2(-2, "knn: missing pointer");
+    KnnGrid g;
+    if (knn_scratch(P, &g, scratch) > scratch_bytes) return fail2(-1, "knn: scratch too small (see sks_knn3_scratch_bytes)");
+    hipStream_t st = (hipStream_t)stream;
+    const int ncell = g.n * g.n * g.n;
+    const int nb = (P + 255) / 256, nparts = nb < 256 ? nb : 256;
+    HIP_TRY2(hipMemsetAsync(g.cursor, 0, (size_t)ncell * 4, st));
+    hipLaunchKernelGGL(k_knn_bbox, dim3(nparts), dim3(256), 0, st, P, points, g.part);
+    hipLaunchKernelGGL(k_knn_count, dim3(nb), dim3(256), 0, st, P, points, g, nparts);
+    hipLaunchKernelGGL(k_knn_scan, dim3(1), dim3(1024), 0, st, ncell, g);
+    hipLaunchKernelGGL(k_knn_scatter, dim3(nb), dim3(256), 0, st, P, points, g, nparts);
+    hipLaunchKernelGGL(k_knn_search, dim3(nb), dim3(256), 0, st, P, g, nparts, mean_dist2);
     HIP_TRY2(hipGetLastError());
     return 0;
 }

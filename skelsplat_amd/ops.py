@@ -94,16 +94,28 @@ def fused_ssim(img1, img2, padding="same", train=True):
     return FusedSSIMMap.apply(C1, C2, img1, img2, padding, train).mean()
 
 
-def distCUDA2(points):
-    """submodules/simple-knn/spatial.cu:15-26: mean squared distance to the 3 nearest neighbours, (P,)."""
+KNN_GRID_MIN_POINTS = 2048   # above this the uniform-grid search beats the all-pairs sweep
+
+
+def distCUDA2(points, method=None):
+    """submodules/simple-knn/spatial.cu:15-26: mean squared distance to the 3 nearest neighbours, (P,).
+    method: None (automatic), "allpairs" or "grid" -- both are exact and return identical floats."""
     pts = _chk(points, "points")
     if pts.dim() != 2 or pts.shape[1] != 3:
         raise RuntimeError("points must have dimensions (num_points, 3)")
     P = pts.shape[0]
     out = torch.zeros(P, dtype=torch.float32, device=pts.device)
     if P:
+        lib = _lib.load()
+        stream = torch.cuda.current_stream(pts.device).cuda_stream
+        grid = method == "grid" or (method is None and P > KNN_GRID_MIN_POINTS)
         with torch.cuda.device(pts.device):
-            rc = _lib.load().sks_knn3_meandist2(P, pts.data_ptr(), out.data_ptr(),
-                                                torch.cuda.current_stream(pts.device).cuda_stream)
-        _lib.check(rc, "sks_knn3_meandist2")
+            if grid:
+                nbytes = int(lib.sks_knn3_scratch_bytes(P))
+                scratch = torch.empty(nbytes, dtype=torch.uint8, device=pts.device)
+                rc = lib.sks_knn3_meandist2_grid(P, pts.data_ptr(), out.data_ptr(), scratch.data_ptr(), nbytes, stream)
+                _lib.check(rc, "sks_knn3_meandist2_grid")
+            else:
+                rc = lib.sks_knn3_meandist2(P, pts.data_ptr(), out.data_ptr(), stream)
+                _lib.check(rc, "sks_knn3_meandist2")
     return out

@@ -400,3 +400,29 @@ def test_fused_step_tail_equals_separate_kernels(device, use_graph):
         else:
             assert torch.equal(a, b), k
     assert (res[0][0].cpu() - torch.tensor(sc.pose_3d_init).float()).norm(dim=1).mean() > 1.0
+
+
+@pytest.mark.parametrize("kind", ["uniform", "clustered", "duplicates", "line"])
+@pytest.mark.parametrize("P", [1, 3, 5, 17, 300, 5000, 40000])
+def test_knn_grid_equals_allpairs(device, P, kind):
+    """The uniform-grid search used for large clouds returns exactly the floats of the all-pairs sweep (both are exact
+    3-NN searches evaluating each squared distance the same way), whatever the distribution."""
+    from skelsplat_amd.ops import distCUDA2
+    g = torch.Generator().manual_seed(P + len(kind))
+    if kind == "uniform":
+        pts = torch.rand(P, 3, generator=g) * 1000
+    elif kind == "clustered":   # a few tight blobs far apart: most grid cells are empty, the search needs many shells
+        centres = torch.rand(5, 3, generator=g) * 1e4
+        pts = centres[torch.randint(0, 5, (P,), generator=g)] + torch.randn(P, 3, generator=g)
+    elif kind == "duplicates":
+        base = torch.rand(max(1, P // 4), 3, generator=g) * 100
+        pts = base[torch.randint(0, base.shape[0], (P,), generator=g)]
+    else:                        # degenerate extent in two axes
+        pts = torch.zeros(P, 3)
+        pts[:, 0] = torch.rand(P, generator=g) * 50
+    pts = pts.to(device)
+    a = distCUDA2(pts, method="allpairs")
+    b = distCUDA2(pts, method="grid")
+    assert torch.equal(a, b)
+    if P > 2048:
+        assert torch.equal(distCUDA2(pts), b)

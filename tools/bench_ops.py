@@ -36,9 +36,10 @@ for shape in ((5, 5, 1080, 1920), (1, 17, 1000, 1000), (5, 1, 1500, 1500)):
     print(f"fused_ssim {shape}: inference {ti:.3f} ms ({3*n/ti/1e6:.0f} GB/s alg: 2 reads + 1 write) vs torch conv2d {tti:.3f} ms ({tti/ti:.1f}x); "
           f"train fwd+bwd {tt:.3f} ms ({12*n/tt/1e6:.0f} GB/s alg) vs torch {ttt:.3f} ms ({ttt/tt:.1f}x)")
 
-for P in (17, 4352, 100000):
+for P in (17, 4352, 100000, 1000000):
     pts = torch.randn(P, 3, device=dev) * 100
     t = timeit(lambda: ops.distCUDA2(pts))
+    ta = timeit(lambda: ops.distCUDA2(pts, method="allpairs"), iters=3) if 2048 < P <= 200000 else (t if P <= 2048 else float("nan"))
     def brute():
         if P > 20000:
             return None
@@ -46,7 +47,7 @@ for P in (17, 4352, 100000):
         d.fill_diagonal_(float("inf"))
         return d.topk(3, largest=False).values.mean(1)
     tb = timeit(brute) if P <= 20000 else float("nan")
-    print(f"distCUDA2 P={P}: {t:.3f} ms vs torch cdist+topk {tb:.3f} ms")
+    print(f"distCUDA2 P={P}: {t:.3f} ms (all-pairs sweep {ta:.3f} ms) vs torch cdist+topk {tb:.3f} ms")
 
 r = torch.rand((4, 17, 1000, 1000), device=dev) * (torch.rand((4, 17, 1000, 1000), device=dev) > 0.9)
 g = torch.rand((4, 17, 1000, 1000), device=dev) * (torch.rand((4, 17, 1000, 1000), device=dev) > 0.9)
