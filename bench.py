@@ -131,7 +131,9 @@ def main():
     torch.cuda.synchronize()
     prof = not args.no_prof
     if prof:
-        _lib.prof_enable(True)
+        # the kernels of every 8th step are bracketed with hipEvents on the launch stream: >= 25 samples of the timed
+        # region at the default 200 steps, without the ~12 us per step that four event records per step would add
+        _lib.prof_enable(True, every=max(1, min(8, args.steps // 8)))
         _lib.prof_read(0), _lib.prof_read(1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -250,7 +252,8 @@ def main():
             res["roofline"] = {"bound": "hbm", "kernel": "k_render_fwd_sparse (forward fill + sparse compositor)",
                                "achieved": alg_bytes / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": alg_bytes / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-                               "avg_launch_us": avg_s * 1e6, "launches": fwd_n, "algorithmic_bytes_per_launch": alg_bytes}
+                               "avg_launch_us": avg_s * 1e6, "launches_timed": fwd_n, "launches": args.steps,
+                               "algorithmic_bytes_per_launch": alg_bytes}
             if bwd_n:
                 res["bwd_kernel_avg_us"] = bwd_ms * 1e3 / bwd_n
         res.update(extras)

@@ -101,8 +101,9 @@ def farray(vals):
     return (C.c_float * len(vals))(*[float(v) for v in vals])
 
 
-def prof_enable(on):
-    check(load().sks_prof_enable(1 if on else 0), "sks_prof_enable")
+def prof_enable(on, every=1):
+    """Bracket the forward / backward compositor launches with hipEvents (every `every`-th launch of each kind)."""
+    check(load().sks_prof_enable(max(1, int(every)) if on else 0), "sks_prof_enable")
 
 
 def prof_read(kind):

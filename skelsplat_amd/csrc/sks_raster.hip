@@ -404,6 +404,8 @@ int sks_loop_fused_step(int V, int P, int C, int W, int H, const float* viewmatr
 int sks_prof_enable(int on)
 {
     g_prof_on = on != 0;
+    g_prof_every = on > 1 ? on : 1;
+    g_prof_seen[0] = g_prof_seen[1] = 0;
     return 0;
 }
 
