@@ -276,6 +276,14 @@ class GaussianModel:
             self._opacity.copy_(self._initial[2])
         return self
 
+    def get_covariance(self, scaling_modifier=1.0):
+        """scene/gaussian_model.py:33-37,131-134 (build_covariance_from_scaling_rotation + strip_symmetric,
+        utils/general_utils.py:61-119): the 6 upper-triangle entries (xx, xy, xz, yy, yz, zz) of R S S^T R^T, what the
+        renderer passes as cov3D_precomp when pipe.compute_cov3D_python is set (gaussian_renderer/__init__.py:80-86)."""
+        from .heatmaps import covariance_from_scaling_rotation
+        cov = covariance_from_scaling_rotation(self.get_scaling, self._rotation, scaling_modifier)
+        return torch.stack([cov[:, 0, 0], cov[:, 0, 1], cov[:, 0, 2], cov[:, 1, 1], cov[:, 1, 2], cov[:, 2, 2]], dim=1)
+
     get_xyz = property(lambda self: self._xyz)
     get_scaling = property(lambda self: torch.exp(self._scaling))
     get_rotation = property(lambda self: torch.nn.functional.normalize(self._rotation))

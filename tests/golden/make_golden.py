@@ -4,7 +4,8 @@ input/output vectors are committed.  Run:  python tests/golden/make_golden.py
 
 Pins: camera matrices (utils/graphics_utils.py), LR schedule (utils/general_utils.py:38-71),
 masked-L2 loss value+gradient (utils/loss_utils.py:86-100), limb-symmetry loss value+gradient (:226-250),
-SSIM value+gradient (:253-300 -- the same function fused-ssim's own test uses as oracle).
+SSIM value+gradient (:253-300 -- the same function fused-ssim's own test uses as oracle),
+3D covariance from scaling + rotation (utils/general_utils.py:61-119, the Python twin of computeCov3D).
 """
 import os
 import sys
@@ -84,6 +85,28 @@ def main():
     s = loss_utils.ssim(a, b)
     s.backward()
     out.update(ssim_img1=a.detach().numpy(), ssim_img2=b.numpy(), ssim_value=np.float64(s.item()), ssim_grad=a.grad.numpy())
+
+    # 3D covariance of the Gaussians, the Python twin of computeCov3D (scene/gaussian_model.py:33-37:
+    # strip_symmetric(L @ L^T) with L = build_scaling_rotation(modifier * scaling, rotation), general_utils.py:61-119).
+    # Those helpers hard-code device="cuda" in their torch.zeros calls; torch.zeros is wrapped for the duration of the
+    # call so that the reference's own code runs on the CPU of the build container.
+    cs = torch.exp(torch.randn((12, 3), generator=g) * 0.4 + 3.0)
+    cq = torch.randn((12, 4), generator=g)
+    real_zeros = torch.zeros
+
+    def zeros_cpu(*a, **k):
+        k.pop("device", None)
+        return real_zeros(*a, **k)
+
+    torch.zeros = zeros_cpu
+    try:
+        for tag, mod in (("", 1.0), ("_mod", 0.7)):
+            L = general_utils.build_scaling_rotation(mod * cs, cq)
+            out["cov_six" + tag] = general_utils.strip_symmetric(L @ L.transpose(1, 2)).numpy()
+        out["cov_R"] = general_utils.build_rotation(cq).numpy()
+    finally:
+        torch.zeros = real_zeros
+    out.update(cov_scaling=cs.numpy(), cov_rotation=cq.numpy())
 
     np.savez_compressed(os.path.join(HERE, "reference_python.npz"), **out)
     print("wrote", os.path.join(HERE, "reference_python.npz"), {k: np.asarray(v).shape for k, v in out.items()})

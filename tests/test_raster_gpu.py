@@ -161,6 +161,34 @@ def test_bg_cache_identity(device):
     assert got is not None and got.shape == (17,) and float(got[1]) == 0.25 and float(got[5]) == 0.0
 
 
+@pytest.mark.parametrize("binned", [False, True], ids=["small", "binned"])
+def test_cov3d_precomp_path(device, binned):
+    """pipe.compute_cov3D_python (gaussian_renderer/__init__.py:80-86): the covariance comes precomputed from
+    GaussianModel.get_covariance instead of scales + rotations.  Bit-exact forward against the oracle on the same six
+    numbers, gradients with respect to them, and agreement with the scales/rotations rendering of the same Gaussians."""
+    from skelsplat_amd.heatmaps import covariance_from_scaling_rotation
+    c = util.make_case(seed=9, W=176, H=128, scale_log=4.1)
+    dev = device
+    cov = covariance_from_scaling_rotation(torch.tensor(c.scales), torch.tensor(c.quats), 1.0)
+    six = torch.stack([cov[:, 0, 0], cov[:, 0, 1], cov[:, 0, 2], cov[:, 1, 1], cov[:, 1, 2], cov[:, 2, 2]], 1).contiguous()
+    views = R.ViewBatch.from_cameras([cam.to(dev) for cam in c.cams])
+    args = (t(c.means, dev), t(c.feat, dev), t(c.opac, dev), None, None, six.to(dev))
+    color, inv, radii, st = R.forward_views(views, *args, force_binned=binned)
+    g = R.backward_views(st, *args, t(c.dL_color, dev), t(c.dL_inv, dev))
+    assert g["scales"] is None and g["rotations"] is None
+    ref_color, _, ref_radii, _ = R.forward_views(views, t(c.means, dev), t(c.feat, dev), t(c.opac, dev), t(c.scales, dev),
+                                                 t(c.quats, dev), None, force_binned=binned)
+    assert torch.equal(radii, ref_radii)
+    util.assert_close("vs scales+rotations", color.cpu(), ref_color.cpu(), rtol=2e-3, atol_scale=2e-4)
+    for v in range(len(c.cams)):
+        o = orc.forward(c.means, c.feat, c.opac, None, None, six.numpy(), c.ocams[v])
+        assert np.array_equal(color[v].cpu().numpy(), o["color"]) and np.array_equal(radii[v].cpu().numpy(), o["radii"])
+        b = orc.backward(o, c.means, c.feat, c.opac, None, None, six.numpy(), c.ocams[v], c.dL_color[v], c.dL_inv[v])
+        util.assert_close("dL_dcov3D", g["cov3D"][v].cpu(), b["dL_dcov3D"])
+        util.assert_close("dL_dmeans3D", g["means3D"][v].cpu(), b["dL_dmeans3D"])
+        util.assert_close("dL_dopacity", g["opacities"][v].cpu(), b["dL_dopacity"])
+
+
 def test_autograd_single_view_api(device):
     """The reference's call shape: GaussianRasterizer(settings)(means3D=..., shs=(P,1,C), ...) -> (color, radii, invdepth)."""
     import math
