@@ -4,8 +4,9 @@ The reference writes a single 255 impulse at (floor(y), floor(x)) of each joint 
 cupyx.scipy.ndimage.gaussian_filter(sigma=[sqrt(lambda1), sqrt(lambda2)]) over the full-resolution plane, V*J times
 per scene, then min-max normalises each channel.  Filtering an impulse is closed form: the result is
 255 * outer(k_rows, k_cols) with k the (truncate = 4 sigma, sum-normalised, 'reflect'-extended) 1-D kernels, so all
-V*J planes are produced by a handful of small tensor ops.  lambda1/lambda2 come from the same EWA projection the
-rasterizer uses (axis-aligned: the reference ignores the eigen-directions, :252-265, 287-289).
+V*J planes are produced by a handful of small tensor ops.  lambda1/lambda2 come from the reference's own transcription
+of the EWA projection (see ewa_lambdas_views: not the rasterizer's footprint) and are used axis-aligned: the reference
+ignores the eigen-directions (:252-265, 287-289).
 """
 import math
 
@@ -13,52 +14,40 @@ import torch
 
 
 def ewa_lambdas(means, cov3D, cam, W, H):
-    """(lambda1, lambda2) of every Gaussian in one camera: general_utils.py:201-265 (same math as
-    DGR/cuda_rasterizer/forward.cu:74-109, 219-243, including the +0.3 px^2 low-pass and the max(0.1, .) guard)."""
-    dt = torch.float32
-    means = means.to(dt)
-    P = means.shape[0]
-    Vt = cam.world_view_transform.to(device=means.device, dtype=dt)     # transposed view matrix
-    tanx, tany = math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5)
-    fx, fy = W / (2.0 * tanx), H / (2.0 * tany)
-    ph = torch.cat([means, torch.ones(P, 1, dtype=dt, device=means.device)], 1)
-    t = ph @ Vt[:, :3]
-    tz = t[:, 2]
-    tx = torch.clamp(t[:, 0] / tz, -1.3 * tanx, 1.3 * tanx) * tz
-    ty = torch.clamp(t[:, 1] / tz, -1.3 * tany, 1.3 * tany) * tz
-    z = torch.zeros_like(tz)
-    J = torch.stack([fx / tz, z, -(fx * tx) / (tz * tz), z, fy / tz, -(fy * ty) / (tz * tz), z, z, z], 1).reshape(P, 3, 3)
-    Wm = Vt[:3, :3].T
-    JW = J @ Wm
-    cov = JW @ cov3D.to(dt) @ JW.transpose(1, 2)
-    cx, cy, cz = cov[:, 0, 0] + 0.3, cov[:, 0, 1], cov[:, 1, 1] + 0.3
-    det = cx * cz - cy * cy
-    mid = 0.5 * (cx + cz)
-    root = torch.sqrt(torch.clamp_min(mid * mid - det, 0.1))
-    return mid + root, mid - root
+    """(lambda1, lambda2) of every Gaussian in one camera: general_utils.py:189-265; see ewa_lambdas_views."""
+    l1, l2 = ewa_lambdas_views(means, cov3D, [cam], W, H)
+    return l1[0], l2[0]
 
 
 def ewa_lambdas_views(means, cov3D, cameras, W, H):
-    """ewa_lambdas for all cameras at once: (V, P) tensors (same arithmetic, batched over the view axis)."""
+    """(lambda1, lambda2), each (V, P): utils/general_utils.py:189-265, restated LITERALLY.
+
+    The reference transcribes the rasterizer's glm expressions (forward.cu:74-109: T = W * J,
+    cov = transpose(T) * transpose(Vrk) * T) into torch calls with the same operand order, but torch matrices are
+    row-major where glm's constructors fill columns: with J the Jacobian (rows = d(screen)/d(camera)) and R the
+    camera rotation, the rasterizer's 2D covariance is (J R) Sigma (J R)^T while this one is (R J)^T Sigma^T (R J).
+    They differ whenever R is not the identity, so the pseudo-GT blobs are NOT the projected Gaussians' footprints --
+    a quirk of the reference that a drop-in has to keep (pinned by tests/golden/reference_heatmaps.npz, produced by
+    the reference's own function).  +0.3 px^2 low-pass and max(0.1, .) guard as in the rasterizer."""
     dt = torch.float32
     dev = means.device
     means = means.to(dt)
     P = means.shape[0]
-    Vt = torch.stack([cam.world_view_transform.to(device=dev, dtype=dt) for cam in cameras], 0)          # (V,4,4)
+    view_matrix = torch.stack([cam.world_view_transform.to(device=dev, dtype=dt).T for cam in cameras], 0)   # (V,4,4)
     tanx = torch.tensor([math.tan(cam.FoVx * 0.5) for cam in cameras], dtype=dt, device=dev)[:, None]
     tany = torch.tensor([math.tan(cam.FoVy * 0.5) for cam in cameras], dtype=dt, device=dev)[:, None]
-    fx = torch.tensor([W / (2.0 * math.tan(cam.FoVx * 0.5)) for cam in cameras], dtype=dt, device=dev)[:, None]
-    fy = torch.tensor([H / (2.0 * math.tan(cam.FoVy * 0.5)) for cam in cameras], dtype=dt, device=dev)[:, None]
-    ph = torch.cat([means, torch.ones(P, 1, dtype=dt, device=dev)], 1)
-    t = ph[None] @ Vt[:, :, :3]                                          # (V,P,3)
+    fx = W / (2.0 * tanx)
+    fy = H / (2.0 * tany)
+    hom = torch.cat([means, torch.ones(P, 1, dtype=dt, device=dev)], 1)
+    t = torch.matmul(view_matrix, hom.T).transpose(1, 2)[:, :, :3]                     # (V,P,3) camera-space means
     tz = t[..., 2]
     tx = torch.minimum(torch.maximum(t[..., 0] / tz, -1.3 * tanx), 1.3 * tanx) * tz
     ty = torch.minimum(torch.maximum(t[..., 1] / tz, -1.3 * tany), 1.3 * tany) * tz
     z = torch.zeros_like(tz)
-    J = torch.stack([fx / tz, z, -(fx * tx) / (tz * tz), z, fy / tz, -(fy * ty) / (tz * tz), z, z, z], -1).reshape(-1, P, 3, 3)
-    Wm = Vt[:, :3, :3].transpose(1, 2)[:, None]                          # (V,1,3,3)
-    JW = J @ Wm
-    cov = JW @ cov3D.to(dt)[None] @ JW.transpose(-1, -2)
+    J = torch.stack([fx / tz, z, -(fx * tx) / tz ** 2, z, fy / tz, -(fy * ty) / tz ** 2, z, z, z], -1).reshape(-1, P, 3, 3)
+    Wm = view_matrix[:, :3, :3].unsqueeze(1)                                             # (V,1,3,3)
+    T = Wm @ J
+    cov = T.permute(0, 1, 3, 2) @ cov3D.to(dt).permute(0, 2, 1)[None] @ T
     cx, cy, cz = cov[..., 0, 0] + 0.3, cov[..., 0, 1], cov[..., 1, 1] + 0.3
     det = cx * cz - cy * cy
     mid = 0.5 * (cx + cz)

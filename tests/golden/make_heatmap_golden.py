@@ -1,0 +1,78 @@
+"""Generates tests/golden/reference_heatmaps.npz by running the REFERENCE's own generate_heatmaps
+(utils/general_utils.py:175-304, imported from /root/reference) on the CPU of the build container.
+Run:  python tests/golden/make_heatmap_golden.py
+
+What is adapted so that the unmodified reference function runs without a GPU, for the duration of the call only:
+  * torch.zeros / torch.ones / torch.tensor drop their hard-coded device="cuda" keyword;
+  * cupy.asarray -> numpy.asarray and cupyx.scipy.ndimage.gaussian_filter -> scipy.ndimage.gaussian_filter (cupy's
+    ndimage mirrors scipy's API and defaults: mode="reflect", truncate=4.0; cupy itself is not installed here);
+  * tensordict.TensorDict -> dict (only item assignment / lookup are used).
+Inputs (a synthetic 17-joint skeleton, 2 cameras, 96x72 images) and the function's outputs are stored; the reference
+itself does not travel.  This fixture is what caught that the reference's 2D covariance is NOT the rasterizer's
+(torch row-major transcription of glm column-major code, see skelsplat_amd/heatmaps.py:ewa_lambdas_views).
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import scipy.ndimage
+import torch
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+
+
+def main():
+    for n in ("tensordict", "cupy", "cupyx", "cupyx.scipy", "cupyx.scipy.ndimage", "plyfile", "cv2"):
+        sys.modules[n] = types.ModuleType(n)
+    sys.modules["tensordict"].TensorDict = dict
+    sys.modules["cupyx.scipy.ndimage"].gaussian_filter = scipy.ndimage.gaussian_filter
+    sys.modules["cupy"].asarray = lambda t: np.asarray(t)
+    sys.modules["plyfile"].PlyData = sys.modules["plyfile"].PlyElement = None
+    sys.path.insert(0, REF)
+    from utils import general_utils
+    sys.path.insert(0, ROOT)
+    from skelsplat_amd.scene import SyntheticScene, GaussianModel
+
+    W, H = 96, 72
+    sc = SyntheticScene("h36m", n_views=2, seed=3, W=W, H=H, ring=2500.0, fx=1145.0 * 0.096 * 1.5)
+    gm = GaussianModel().create_from_points(sc.pose_3d_init, sc.spatial_lr_scale, sc.n_joints, scaling=3.9)
+    with torch.no_grad():   # anisotropic, rotated Gaussians: every convention matters
+        gm._rotation.add_(0.4 * torch.randn(gm._rotation.shape, generator=torch.Generator().manual_seed(1)))
+        gm._scaling.add_(0.4 * torch.randn(gm._scaling.shape, generator=torch.Generator().manual_seed(2)))
+    p2d = torch.tensor(sc.poses_2d)
+
+    real = {k: getattr(torch, k) for k in ("zeros", "ones", "tensor")}
+
+    def strip(fn):
+        def wrapped(*a, **k):
+            k.pop("device", None)
+            return fn(*a, **k)
+        return wrapped
+
+    for k, f in real.items():
+        setattr(torch, k, strip(f))
+    try:
+        # train.py:91-92: covariance_3d = unpack_covariance(gaussians.get_covariance()) with the reference's own helpers
+        L = general_utils.build_scaling_rotation(torch.exp(gm._scaling.detach()), gm._rotation.detach())
+        six = general_utils.strip_symmetric(L @ L.transpose(1, 2))
+        cov3 = general_utils.unpack_covariance(six)
+        g = types.SimpleNamespace(get_xyz=gm._xyz.detach())
+        ref = general_utils.generate_heatmaps(g, p2d, sc.cameras, cov3, False, "data/h36m", 2)
+    finally:
+        for k, f in real.items():
+            setattr(torch, k, f)
+    out = dict(xyz=gm._xyz.detach().numpy(), scaling_raw=gm._scaling.detach().numpy(), rotation_raw=gm._rotation.detach().numpy(),
+               poses_2d=p2d.numpy(), W=np.int32(W), H=np.int32(H),
+               world_view_transform=np.stack([c.world_view_transform.numpy() for c in sc.cameras]),
+               fov=np.array([[c.FoVx, c.FoVy] for c in sc.cameras], dtype=np.float64),
+               heatmaps=np.stack([ref[str(v)].numpy() for v in range(2)]).astype(np.float32))
+    path = os.path.join(HERE, "reference_heatmaps.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes", {k: np.asarray(v).shape for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    main()

@@ -393,3 +393,21 @@ def test_cov3d_against_reference_python_golden():
         cov = covariance_from_scaling_rotation(torch.tensor(s), torch.tensor(q), mod)
         six = torch.stack([cov[:, 0, 0], cov[:, 0, 1], cov[:, 0, 2], cov[:, 1, 1], cov[:, 1, 2], cov[:, 2, 2]], 1).numpy()
         util.assert_close("host covariance" + tag, six, want, rtol=2e-5, atol_scale=1e-6)
+
+
+def test_heatmaps_against_reference_generate_heatmaps_golden():
+    """tests/golden/reference_heatmaps.npz: output of the REFERENCE's own generate_heatmaps + normalize_heatmaps
+    (utils/general_utils.py:175-304) run in the build container (tests/golden/make_heatmap_golden.py).  The closed-form
+    generator must reproduce it, including the reference's own 2D covariance (which is not the rasterizer's)."""
+    import types
+    from skelsplat_amd.heatmaps import generate_heatmaps
+    g = np.load(os.path.join(ROOT, "tests", "golden", "reference_heatmaps.npz"))
+    W, H = int(g["W"]), int(g["H"])
+    cams = [types.SimpleNamespace(image_width=W, image_height=H, world_view_transform=torch.tensor(g["world_view_transform"][v]),
+                                  FoVx=float(g["fov"][v, 0]), FoVy=float(g["fov"][v, 1])) for v in range(2)]
+    hm = generate_heatmaps(torch.tensor(g["xyz"]), torch.exp(torch.tensor(g["scaling_raw"])), torch.tensor(g["rotation_raw"]),
+                           torch.tensor(g["poses_2d"]), cams)
+    want = torch.tensor(g["heatmaps"])
+    assert hm.shape == want.shape == (2, 17, H, W)
+    assert float(want.max()) == 1.0 and float((want > 0.5).float().mean()) > 1e-4
+    torch.testing.assert_close(hm, want, rtol=0, atol=2e-6)
