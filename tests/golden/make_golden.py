@@ -5,7 +5,8 @@ input/output vectors are committed.  Run:  python tests/golden/make_golden.py
 Pins: camera matrices (utils/graphics_utils.py), LR schedule (utils/general_utils.py:38-71),
 masked-L2 loss value+gradient (utils/loss_utils.py:86-100), limb-symmetry loss value+gradient (:226-250),
 SSIM value+gradient (:253-300 -- the same function fused-ssim's own test uses as oracle),
-3D covariance from scaling + rotation (utils/general_utils.py:61-119, the Python twin of computeCov3D).
+3D covariance from scaling + rotation (utils/general_utils.py:61-119, the Python twin of computeCov3D),
+scene.cameras.Camera matrices and scene.gaussian_model.GaussianModel initialisation / optimiser groups.
 """
 import os
 import sys
@@ -107,6 +108,64 @@ def main():
     finally:
         torch.zeros = real_zeros
     out.update(cov_scaling=cs.numpy(), cov_rotation=cq.numpy())
+
+    # scene.cameras.Camera and scene.gaussian_model.GaussianModel are hard-wired to device "cuda" (.cuda() calls and
+    # device="cuda" keywords).  For the duration of the calls Tensor.cuda is the identity and the factory functions drop
+    # the keyword, so that the reference's own constructors run on the CPU of the build container.
+    real = {k: getattr(torch, k) for k in ("zeros", "ones", "tensor", "eye")}
+    real_cuda = torch.Tensor.cuda
+
+    def strip(fn):
+        def wrapped(*a, **k):
+            k.pop("device", None)
+            return fn(*a, **k)
+        return wrapped
+
+    for k, fn in real.items():
+        setattr(torch, k, strip(fn))
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        from scene.cameras import Camera
+        from scene.gaussian_model import GaussianModel
+        from utils.graphics_utils import BasicPointCloud
+        wv, pj, fp, cc = [], [], [], []
+        for i in range(6):
+            W, H = int(out["cam_fov"][i, 2]), int(out["cam_fov"][i, 3])
+            cam = Camera((W, H), i, out["cam_R"][i], out["cam_T"][i], out["cam_fov"][i, 0], out["cam_fov"][i, 1], out["cam_K"][i],
+                         None, None, None, f"cam{i}", i, data_device="cpu")
+            wv.append(cam.world_view_transform.numpy()); pj.append(cam.projection_matrix.numpy())
+            fp.append(cam.full_proj_transform.numpy()); cc.append(cam.camera_center.numpy())
+        out.update(camobj_world_view=np.stack(wv), camobj_projection=np.stack(pj), camobj_full_proj=np.stack(fp),
+                   camobj_center=np.stack(cc))
+
+        targs = types.SimpleNamespace(percent_dense=0.01, position_lr_init=0.0005, position_lr_final=0.000005,
+                                      position_lr_delay_mult=0.0, position_lr_max_steps=4000, feature_lr=0.0, opacity_lr=0.0,
+                                      scaling_lr=0.005, rotation_lr=0.001, exposure_lr_init=0.01, exposure_lr_final=0.001,
+                                      exposure_lr_delay_steps=0, exposure_lr_delay_mult=0.0, iterations=500)
+        for key, J in (("h36m", 17), ("panoptic", 19), ("occlusion-person", 15)):
+            pts = rng.normal(scale=400.0, size=(J, 3))
+            pcd = BasicPointCloud(points=pts, colors=np.zeros((J, 3)), normals=np.zeros((J, 3)))
+            gmod = GaussianModel(1)
+            gmod.create_from_pcd(pcd, [types.SimpleNamespace(image_name="a")], 5500.0, True, 3.0, J, 1.5, key)
+            gmod.training_setup(targs)
+            pre = f"gm_{key}_"
+            out[pre + "points"] = pts
+            out[pre + "xyz"] = gmod._xyz.detach().numpy()
+            out[pre + "features_dc"] = gmod._features_dc.detach().numpy()
+            out[pre + "scaling"] = gmod._scaling.detach().numpy()
+            out[pre + "rotation"] = gmod._rotation.detach().numpy()
+            out[pre + "opacity"] = gmod._opacity.detach().numpy()
+            out[pre + "get_scaling"] = gmod.get_scaling.detach().numpy()
+            out[pre + "get_opacity"] = gmod.get_opacity.detach().numpy()
+            out[pre + "get_rotation"] = gmod.get_rotation.detach().numpy()
+            out[pre + "group_names"] = np.array([g_["name"] for g_ in gmod.optimizer.param_groups])
+            out[pre + "group_lrs"] = np.array([g_["lr"] for g_ in gmod.optimizer.param_groups], dtype=np.float64)
+            out[pre + "adam_eps_betas"] = np.array([gmod.optimizer.defaults["eps"], *gmod.optimizer.defaults["betas"]], dtype=np.float64)
+            out[pre + "xyz_lr_at"] = np.array([gmod.update_learning_rate(it) for it in (1, 4, 100, 500)], dtype=np.float64)
+    finally:
+        for k, fn in real.items():
+            setattr(torch, k, fn)
+        torch.Tensor.cuda = real_cuda
 
     np.savez_compressed(os.path.join(HERE, "reference_python.npz"), **out)
     print("wrote", os.path.join(HERE, "reference_python.npz"), {k: np.asarray(v).shape for k, v in out.items()})

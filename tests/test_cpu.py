@@ -411,3 +411,41 @@ def test_heatmaps_against_reference_generate_heatmaps_golden():
     assert hm.shape == want.shape == (2, 17, H, W)
     assert float(want.max()) == 1.0 and float((want > 0.5).float().mean()) > 1e-4
     torch.testing.assert_close(hm, want, rtol=0, atol=2e-6)
+
+
+def test_camera_and_model_against_reference_classes_golden():
+    """tests/golden/reference_python.npz also holds what the REFERENCE's own scene.cameras.Camera and
+    scene.gaussian_model.GaussianModel (create_from_pcd + training_setup + update_learning_rate) produce when run on the
+    CPU of the build container: the attribute-compatible classes of skelsplat_amd/scene.py must build the same
+    matrices, the same initial parameters and the same optimiser configuration."""
+    from skelsplat_amd.scene import Camera, GaussianModel
+    g = np.load(os.path.join(ROOT, "tests", "golden", "reference_python.npz"))
+    for i in range(6):
+        W, H = int(g["cam_fov"][i, 2]), int(g["cam_fov"][i, 3])
+        cam = Camera(i, g["cam_R"][i], g["cam_T"][i], g["cam_K"][i], W, H)
+        assert abs(cam.FoVx - g["cam_fov"][i, 0]) < 1e-12 and abs(cam.FoVy - g["cam_fov"][i, 1]) < 1e-12
+        assert np.array_equal(cam.world_view_transform.numpy(), g["camobj_world_view"][i])
+        assert np.array_equal(cam.projection_matrix.numpy(), g["camobj_projection"][i])
+        np.testing.assert_allclose(cam.full_proj_transform.numpy(), g["camobj_full_proj"][i], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(cam.camera_center.numpy(), g["camobj_center"][i], rtol=1e-5, atol=1e-3)
+    for key in ("h36m", "panoptic", "occlusion-person"):
+        pre = f"gm_{key}_"
+        J = g[pre + "points"].shape[0]
+        gm = GaussianModel(1).create_from_points(g[pre + "points"], 5500.0, J, opacity_on=True, scaling=3.0, scaling_modifier=1.5,
+                                                 scene_type=key)
+        gm.training_setup()
+        assert np.array_equal(gm._xyz.detach().numpy(), g[pre + "xyz"])
+        assert np.array_equal(gm._features_dc.detach().numpy(), g[pre + "features_dc"])      # (J, 1, J) one-hot
+        assert np.array_equal(gm._scaling.detach().numpy(), g[pre + "scaling"])              # limb ends x modifier
+        assert np.array_equal(gm._rotation.detach().numpy(), g[pre + "rotation"])
+        assert np.array_equal(gm._opacity.detach().numpy(), g[pre + "opacity"])              # inverse_sigmoid(1) = +inf
+        assert np.array_equal(gm.get_scaling.detach().numpy(), g[pre + "get_scaling"])
+        assert np.array_equal(gm.get_opacity.detach().numpy(), g[pre + "get_opacity"])
+        assert np.array_equal(gm.get_rotation.detach().numpy(), g[pre + "get_rotation"])
+        assert [grp["name"] for grp in gm.optimizer.param_groups] == list(g[pre + "group_names"])
+        assert np.array_equal(np.array([grp["lr"] for grp in gm.optimizer.param_groups]), g[pre + "group_lrs"])
+        d = gm.optimizer.defaults
+        assert np.array_equal(np.array([d["eps"], *d["betas"]]), g[pre + "adam_eps_betas"])
+        assert np.array_equal(np.array([gm.update_learning_rate(it) for it in (1, 4, 100, 500)]), g[pre + "xyz_lr_at"])
+        c = gm.opt_cfg   # what the device-side optimiser step receives
+        assert (c["lr_scaling"], c["lr_rotation"], c["lr_opacity"], c["eps"], tuple(c["betas"])) == (0.005, 0.001, 0.0, 1e-15, (0.9, 0.999))
