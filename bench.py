@@ -144,9 +144,10 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     fwd_ms = fwd_n = bwd_ms = bwd_n = 0
+    fwd_q = bwd_q = (0.0, 0.0, 0.0)
     if prof:
-        fwd_ms, fwd_n = _lib.prof_read(0)
-        bwd_ms, bwd_n = _lib.prof_read(1)
+        fwd_ms, fwd_n, fwd_q = _lib.prof_read_quantiles(0)
+        bwd_ms, bwd_n, bwd_q = _lib.prof_read_quantiles(1)
         _lib.prof_enable(False)
     if use_dist:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -252,10 +253,12 @@ def main():
             res["roofline"] = {"bound": "hbm", "kernel": "k_render_fwd_sparse (forward fill + sparse compositor)",
                                "achieved": alg_bytes / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": alg_bytes / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-                               "avg_launch_us": avg_s * 1e6, "launches_timed": fwd_n, "launches": args.steps,
+                               "avg_launch_us": avg_s * 1e6, "launch_us_p10_p50_p90": [round(1e3 * x, 2) for x in fwd_q],
+                               "launches_timed": fwd_n, "launches": args.steps,
                                "algorithmic_bytes_per_launch": alg_bytes}
             if bwd_n:
                 res["bwd_kernel_avg_us"] = bwd_ms * 1e3 / bwd_n
+                res["bwd_kernel_us_p10_p50_p90"] = [round(1e3 * x, 2) for x in bwd_q]
         res.update(extras)
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(ref_scene, params, n_views=2)

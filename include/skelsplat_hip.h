@@ -219,6 +219,8 @@ int sks_loop_fused_step(int V, int P, int C, int W, int H, const float* viewmatr
  * the summed kernel time in milliseconds and the number of BRACKETED launches since the last read, and resets them. */
 int sks_prof_enable(int on);
 int sks_prof_read(int kind, double* total_ms, long long* launches);
+/* Same, plus the 10th / 50th / 90th percentile of the bracketed launch durations (milliseconds). */
+int sks_prof_read_quantiles(int kind, double* q_ms /* 3 */, double* total_ms, long long* launches);
 
 #ifdef __cplusplus
 }

@@ -51,6 +51,7 @@ SIGNATURES = {
                                  _vp, C.c_ulonglong, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _f, _vp, _vp]),
     "sks_prof_enable": (_i, [_i]),
     "sks_prof_read": (_i, [_i, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
+    "sks_prof_read_quantiles": (_i, [_i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
 }
 
 
@@ -104,6 +105,14 @@ def farray(vals):
 def prof_enable(on, every=1):
     """Bracket the forward / backward compositor launches with hipEvents (every `every`-th launch of each kind)."""
     check(load().sks_prof_enable(max(1, int(every)) if on else 0), "sks_prof_enable")
+
+
+def prof_read_quantiles(kind):
+    """(total_ms, launches, (p10_ms, p50_ms, p90_ms)) of the bracketed launches of one kind since the last read."""
+    q = (C.c_double * 3)()
+    ms, n = C.c_double(0), C.c_longlong(0)
+    check(load().sks_prof_read_quantiles(kind, q, C.byref(ms), C.byref(n)), "sks_prof_read_quantiles")
+    return ms.value, n.value, (q[0], q[1], q[2])
 
 
 def prof_read(kind):

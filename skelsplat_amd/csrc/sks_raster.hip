@@ -426,6 +426,33 @@ int sks_prof_read(int kind, double* total_ms, long long* launches)
     return 0;
 }
 
+int sks_prof_read_quantiles(int kind, double* q_ms /* 3: p10, p50, p90 */, double* total_ms, long long* launches)
+{
+    if (kind < 0 || kind > 1 || !q_ms || !total_ms || !launches) return fail(-2, "bad profile query");
+    ProfKind& p = g_prof[kind];
+    static thread_local float t[PROF_MAX];
+    double tot = 0;
+    for (int i = 0; i < p.n; i++) {
+        HIP_TRY(hipEventSynchronize(p.e[i]));
+        HIP_TRY(hipEventElapsedTime(&t[i], p.b[i], p.e[i]));
+        tot += t[i];
+    }
+    const int n = p.n;
+    for (int i = 1; i < n; i++) {   // insertion sort: n is a few dozen samples
+        const float v = t[i];
+        int j = i - 1;
+        for (; j >= 0 && t[j] > v; j--) t[j + 1] = t[j];
+        t[j + 1] = v;
+    }
+    q_ms[0] = n ? t[(int)(0.1 * (n - 1) + 0.5)] : 0.0;
+    q_ms[1] = n ? t[(n - 1) / 2] : 0.0;
+    q_ms[2] = n ? t[(int)(0.9 * (n - 1) + 0.5)] : 0.0;
+    *total_ms = tot;
+    *launches = n;
+    p.n = 0;
+    return 0;
+}
+
 int sks_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,
                      void* stream)
 {
