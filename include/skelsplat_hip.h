@@ -50,6 +50,7 @@ extern "C" {
                                  run inside the kernels (sks_geometry, sks_forward, sks_backward*) */
 #define SKS_FILL_LINEAR (1u << 21)  /* tuning/tests: forward fill blocks always in linear (pass-major) mode */
 #define SKS_FILL_ROWS (1u << 22)    /* tuning/tests: row-aligned fill blocks whenever W % 4 == 0 */
+/* bits 26..29: tuning, composite blocks per (view, Gaussian) of the small-path forward (0 = default 4) */
 #define SKS_BWD_LDS_LIST (1u << 20) /* tests: use the LDS-list backward even when P <= 64 (default: wave-resident) */
 
 const char* sks_last_error(void);

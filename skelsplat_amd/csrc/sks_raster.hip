@@ -82,13 +82,14 @@ inline void fill_geometry(const FwdArgs& a, bool have_cover, int& fsplit, int& p
     }
     pb = tune;
     if (pb <= 0) pb = passes / 8 > 2 ? (passes + 4) / 8 : 2;          // ~8 fill blocks per (plane, band) row measured best
+    if (pb > 32) pb = 32;                                             // (one skip bit per pass)
     fsplit = (passes + pb - 1) / pb;                                  // fill blocks per (plane, band) row
 }
 
 template <int CG>
 void launch_fwd_small(const FwdArgs& a, int V, int gy, hipStream_t st)
 {
-    const int ncomp = T_SLOTS * a.P * V;
+    const int ncomp = a.tslots * a.P * V;
     int fsplit, pb;
     fill_geometry(a, a.g.cover != nullptr, fsplit, pb);
     const int rows_zy = (a.C + 1) * V * gy;
@@ -192,7 +193,7 @@ int sks_forward(int V, int P, int C, int W, int H, const float* viewmatrix, cons
                        means3D, opacities, scales, rotations, cov3D_precomp, scale_modifier, flags, g, radii);
     STAGE_CHECK("geometry");
 
-    FwdArgs a{ P, C, W, H, flags, g, features, out_color, out_invdepth, final_T, n_contrib };
+    FwdArgs a{ P, C, W, H, flags, g, features, out_color, out_invdepth, final_T, n_contrib, composite_slots(flags, V, P) };
     const int cg = pick_cg(C);
     const bool small = P <= SKS_SMALL_P && !(flags & SKS_FORCE_BINNED);
     if (small) {
