@@ -70,7 +70,7 @@ def load(build_if_missing=True):
                 raise ImportError(f"libskelsplat_hip.so is missing and could not be built: {e}") from e
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} not found; run `python -m skelsplat_amd.build`")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(os.environ.get("SKS_LIB_OVERRIDE") or LIB_PATH)   # override: A/B of build variants (tools/ab_libs.sh)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError = ABI drift, fail loudly
         fn.restype = res

@@ -193,7 +193,8 @@ int sks_forward(int V, int P, int C, int W, int H, const float* viewmatrix, cons
                        means3D, opacities, scales, rotations, cov3D_precomp, scale_modifier, flags, g, radii);
     STAGE_CHECK("geometry");
 
-    FwdArgs a{ P, C, W, H, flags, g, features, out_color, out_invdepth, final_T, n_contrib, composite_slots(flags, V, P) };
+    FwdArgs a{ P, C, W, H, flags, g, features, out_color, out_invdepth, final_T, n_contrib, composite_slots(flags, V, P),
+               ((1u << 20) + (unsigned)C) / (unsigned)(C + 1) };
     const int cg = pick_cg(C);
     const bool small = P <= SKS_SMALL_P && !(flags & SKS_FORCE_BINNED);
     if (small) {
