@@ -14,7 +14,11 @@ SOURCES = ["sks_raster.hip", "sks_ops.hip", "sks_loop.hip"]
 # -ffp-contract=off is part of the numeric contract (DESIGN.md "Numerics"): tile lists, n_contrib and the forward
 # image must not depend on the compiler's FMA-contraction choices.
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-         "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function"]
+         "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function",
+         # keep kernel-argument loads in the entry block: sunk into the branch that uses them they become extra
+         # dependent scalar round trips in front of the first store of the forward's fill blocks, whose whole life is
+         # ~2 us (interleaved A/B of the two builds, tools/ab_libs.sh: forward 53.8 -> 51.9 us, everything else neutral)
+         "-mllvm", "-disable-machine-sink"]
 
 
 def hipcc():
