@@ -87,9 +87,11 @@ inline void fill_geometry(const FwdArgs& a, bool have_cover, int& fsplit, int& p
 }
 
 template <int CG>
-void launch_fwd_small(const FwdArgs& a, int V, int gy, hipStream_t st)
+void launch_fwd_small(const FwdArgs& a_in, int V, int gy, hipStream_t st)
 {
+    FwdArgs a = a_in;
     const int ncomp = a.tslots * a.P * V;
+    a.ncomp = ncomp;
     int fsplit, pb;
     fill_geometry(a, a.g.cover != nullptr, fsplit, pb);
     const int rows_zy = (a.C + 1) * V * gy;
@@ -99,10 +101,10 @@ void launch_fwd_small(const FwdArgs& a, int V, int gy, hipStream_t st)
     dim3 grid(fsplit + xc, gy, (a.C + 1) * V);
     const bool nt = !(a.flags & SKS_NO_NT_STORES);
     if (a.W % 4 == 0) {
-        if (nt) hipLaunchKernelGGL((k_render_fwd_sparse<CG, 4, true>), grid, dim3(256), lds, st, a, ncomp, gy, fsplit, pb, (const uint32_t*)a.g.cover);
-        else hipLaunchKernelGGL((k_render_fwd_sparse<CG, 4, false>), grid, dim3(256), lds, st, a, ncomp, gy, fsplit, pb, (const uint32_t*)a.g.cover);
+        if (nt) hipLaunchKernelGGL((k_render_fwd_sparse<CG, 4, true>), grid, dim3(256), lds, st, a, a.cp1_magic, gy, fsplit, pb, (const uint32_t*)a.g.cover);
+        else hipLaunchKernelGGL((k_render_fwd_sparse<CG, 4, false>), grid, dim3(256), lds, st, a, a.cp1_magic, gy, fsplit, pb, (const uint32_t*)a.g.cover);
     } else {
-        hipLaunchKernelGGL((k_render_fwd_sparse<CG, 1, false>), grid, dim3(256), lds, st, a, ncomp, gy, fsplit, pb, (const uint32_t*)a.g.cover);
+        hipLaunchKernelGGL((k_render_fwd_sparse<CG, 1, false>), grid, dim3(256), lds, st, a, a.cp1_magic, gy, fsplit, pb, (const uint32_t*)a.g.cover);
     }
 }
 
@@ -194,7 +196,7 @@ int sks_forward(int V, int P, int C, int W, int H, const float* viewmatrix, cons
     STAGE_CHECK("geometry");
 
     FwdArgs a{ P, C, W, H, flags, g, features, out_color, out_invdepth, final_T, n_contrib, composite_slots(flags, V, P),
-               ((1u << 20) + (unsigned)C) / (unsigned)(C + 1) };
+               ((1u << 20) + (unsigned)C) / (unsigned)(C + 1), 0 };
     const int cg = pick_cg(C);
     const bool small = P <= SKS_SMALL_P && !(flags & SKS_FORCE_BINNED);
     if (small) {
