@@ -61,7 +61,7 @@ int check_common(int V, int P, int C, int W, int H)
 // `pb` is returned NEGATIVE = -(rows per block).  Otherwise linear mode, pb passes of 4 KB per block: every pass is
 // 32 whole lines whatever the width (at W = 1000 a row is 31.25 lines and the row-aligned mode loses 7% to the
 // partial lines at both ends of every row).
-inline void fill_geometry(const FwdArgs& a, bool have_cover, int& fsplit, int& pb)
+inline void fill_geometry(const FwdArgs& a, bool have_cover, bool binned, int& fsplit, int& pb)
 {
     const int ppt = a.W % 4 == 0 ? 4 : 1;
     const int passes = (TILE * a.W + 256 * ppt - 1) / (256 * ppt);
@@ -71,10 +71,9 @@ inline void fill_geometry(const FwdArgs& a, bool have_cover, int& fsplit, int& p
                           (ppt == 4 && have_cover && (a.flags & SKS_FILL_ROWS))) && !(a.flags & SKS_FILL_LINEAR);
     if (rowmode) {
         int pbr = tune;
-        if (pbr <= 0) {
-            const int rblocks = chunks >= 8 ? 1 : 8 / chunks;
-            pbr = (TILE + rblocks - 1) / rblocks;
-        }
+        // rows per block, interleaved A/B on one box: 1920 wide small path 2 rows 860 us / 3: 898 / 4: 907 / 6: 915;
+        // 2048 wide binned path (8 composite-role blocks per row) 2 rows 0.632 ms / 3: 0.579 / 4: 0.637 / 6: 0.571
+        if (pbr <= 0) pbr = binned ? 3 : 2;
         if (pbr > TILE) pbr = TILE;
         fsplit = chunks * ((TILE + pbr - 1) / pbr);
         pb = -pbr;
@@ -93,7 +92,7 @@ void launch_fwd_small(const FwdArgs& a_in, int V, int gy, hipStream_t st)
     const int ncomp = a.tslots * a.P * V;
     a.ncomp = ncomp;
     int fsplit, pb;
-    fill_geometry(a, a.g.cover != nullptr, fsplit, pb);
+    fill_geometry(a, a.g.cover != nullptr, false, fsplit, pb);
     const int rows_zy = (a.C + 1) * V * gy;
     const int xc = (ncomp + rows_zy - 1) / rows_zy;                   // composite blocks appended to every row
     const int cap = (a.P + 15) & ~15;
@@ -112,7 +111,7 @@ template <int CG>
 void launch_fwd_binned(const FwdArgs& a, const BinView& bv, int V, int gx, int gy, const uint32_t* cover, hipStream_t st)
 {
     int fsplit, pb;
-    fill_geometry(a, true, fsplit, pb);
+    fill_geometry(a, true, true, fsplit, pb);
     const int xc = (gx + a.C) / (a.C + 1);                            // (view, tile) composite blocks spread over the rows
     dim3 grid(fsplit + xc, gy, (a.C + 1) * V);
     const bool nt = !(a.flags & SKS_NO_NT_STORES);
