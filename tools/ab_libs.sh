@@ -10,7 +10,7 @@ sys.path.insert(0, os.getcwd())
 from tools.tune_fwd import setup, run
 scene, views, params, dL = setup(sys.argv[2], int(sys.argv[3]))
 f, b, tot = run(views, params, dL, 0, iters=100 if int(sys.argv[3]) <= 8 else 20)
-print(sys.argv[1], os.path.basename(os.environ["SKS_LIB_OVERRIDE"]), f"fwd {f:.1f} us bwd {b:.1f} us step {tot:.1f} us", flush=True)
+print(sys.argv[1], os.path.basename(os.environ["SKS_LIB_OVERRIDE"]), sys.argv[2], f"fwd {f:.1f} us bwd {b:.1f} us step {tot:.1f} us", flush=True)
 PY
   done
 done
