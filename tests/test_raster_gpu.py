@@ -326,6 +326,59 @@ def test_many_gaussians_small_path(device):
     util.assert_close("dL_dfeatures", g["features"][0].cpu(), b["dL_dcolors"])
 
 
+@pytest.mark.parametrize("P", [64, 65, 256, 257])
+def test_kernel_selection_boundaries(device, P):
+    """P = 64 is the last size of the wave-resident backward (one Gaussian per lane), 65 the first of the LDS gather
+    variant, 256 the last of the small path, 257 the first binned one: forward bit-exact and backward within tolerance
+    on both sides of each switch."""
+    rng = np.random.default_rng(P)
+    c = util.make_case(seed=61, W=144, H=112, scale_log=3.3, n_skeletons=16, pitch=200.0, n_views=2)   # 272 Gaussians
+    keep = np.sort(rng.choice(c.P, size=P, replace=False))
+    for name in ("means", "feat", "opac", "scales", "quats"):
+        setattr(c, name, np.ascontiguousarray(getattr(c, name)[keep]))
+    c.P = P
+    dev = device
+    views = R.ViewBatch.from_cameras([cam.to(dev) for cam in c.cams])
+    args = (t(c.means, dev), t(c.feat, dev), t(c.opac, dev), t(c.scales, dev), t(c.quats, dev), None)
+    color, inv, radii, st = R.forward_views(views, *args)
+    assert (st.binning is not None) == (P > 256)
+    g = R.backward_views(st, *args, t(c.dL_color, dev), t(c.dL_inv, dev))
+    for v in range(2):
+        o = util.oracle_forward(c, v)
+        assert np.array_equal(radii[v].cpu().numpy(), o["radii"]) and np.array_equal(color[v].cpu().numpy(), o["color"])
+        b = util.oracle_backward(c, v, o)
+        util.assert_close("dL_dmeans3D", g["means3D"][v].cpu(), b["dL_dmeans3D"])
+        util.assert_close("dL_dscales", g["scales"][v].cpu(), b["dL_dscales"])
+        util.assert_close("dL_dopacity", g["opacities"][v].cpu(), b["dL_dopacity"])
+
+
+def test_maximum_view_count(device):
+    """SKS_MAX_VIEWS = 64 views in one call (the per-view tan(fov) arrays travel by value in the kernel arguments); one more
+    is refused with a message."""
+    from skelsplat_amd.scene import SyntheticScene
+    dev = device
+    sc = SyntheticScene("h36m", n_views=64, seed=4, W=64, H=48, ring=2500.0, fx=1145.0 * 0.064 * 1.5, device=dev)
+    c = util.make_case(seed=4, W=64, H=48, scale_log=3.6, n_views=1)
+    views = R.ViewBatch.from_cameras(sc.cameras)
+    args = (t(c.means, dev), t(c.feat, dev), t(c.opac, dev), t(c.scales, dev), t(c.quats, dev), None)
+    color, inv, radii, st = R.forward_views(views, *args)
+    assert color.shape == (64, 17, 48, 64)
+    dL = torch.randn(color.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(0))
+    g = R.backward_views(st, *args, dL)
+    import math
+    for v in (0, 31, 63):
+        cam = sc.cameras[v]
+        ocam = orc.Cam(64, 48, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), cam.world_view_transform.cpu().numpy(),
+                       cam.full_proj_transform.cpu().numpy())
+        o = orc.forward(c.means, c.feat, c.opac, c.scales, c.quats, None, ocam)
+        assert np.array_equal(color[v].cpu().numpy(), o["color"])
+        b = orc.backward(o, c.means, c.feat, c.opac, c.scales, c.quats, None, ocam, dL[v].cpu().numpy(), None)
+        util.assert_close("dL_dmeans3D", g["means3D"][v].cpu(), b["dL_dmeans3D"])
+    sc65 = SyntheticScene("h36m", n_views=65, seed=4, W=64, H=48, ring=2500.0, fx=1145.0 * 0.064 * 1.5, device=dev)
+    with pytest.raises(RuntimeError, match="at most 64 views"):
+        R.forward_views(R.ViewBatch.from_cameras(sc65.cameras), *args)
+
+
 def test_stress_config_binned_path(device):
     """BASELINE config 5 shape: 256 skeletons (P = 4352, C = 17), 2048x2048, binned path.  The oracle is too slow at this
     size, so: oracle parity on a cropped-resolution twin (same P, 512x512) + size-independent properties at full size."""
