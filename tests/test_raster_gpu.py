@@ -379,6 +379,50 @@ def test_maximum_view_count(device):
         R.forward_views(R.ViewBatch.from_cameras(sc65.cameras), *args)
 
 
+@pytest.mark.parametrize("binned", [False, True], ids=["small", "binned"])
+def test_debug_flag_synchronises_and_changes_nothing(device, binned):
+    """debug=True (the reference's CHECK_CUDA(..., debug), auxiliary.h:178-185) adds a stream sync + error check after
+    every stage; results are identical to the asynchronous path."""
+    c = util.make_case(seed=13, W=160, H=128, scale_log=4.0)
+    dev = device
+    views = R.ViewBatch.from_cameras([cam.to(dev) for cam in c.cams])
+    args = (t(c.means, dev), t(c.feat, dev), t(c.opac, dev), t(c.scales, dev), t(c.quats, dev), None)
+    outs = []
+    for dbg in (False, True):
+        color, inv, radii, st = R.forward_views(views, *args, debug=dbg, force_binned=binned)
+        g = R.backward_views(st, *args, t(c.dL_color, dev), t(c.dL_inv, dev))
+        outs.append((color, inv, radii, g["means3D"], g["scales"]))
+    for a, b in zip(*outs):
+        if binned and a.dtype == torch.float32 and a.dim() == 3 and a.shape[-1] in (3,):
+            util.assert_close("binned grads (atomics)", a.cpu(), b.cpu(), rtol=1e-4, atol_scale=1e-6)
+        else:
+            assert torch.equal(a, b)
+
+
+def test_antialiasing_in_the_sparse_loop(device):
+    """pipe.antialiasing = True through the sparse fused training step (geometry kernels carry the opacity scaling and
+    its gradient): the sparse and the dense loop agree."""
+    from skelsplat_amd.loop import MultiViewLoop
+    from skelsplat_amd.heatmaps import generate_heatmaps
+    from skelsplat_amd.scene import SyntheticScene, GaussianModel
+    sc = SyntheticScene("h36m", n_views=4, seed=15, W=160, H=128, ring=2500.0, fx=1145.0 * 0.16 * 1.5, device=device)
+    outs = []
+    for sparse in (True, False):
+        gm = GaussianModel().create_from_points(sc.pose_3d_init, sc.spatial_lr_scale, sc.n_joints, scaling=1.2, device=device)
+        gm.training_setup()
+        with torch.no_grad():
+            gm._opacity.fill_(1.0)    # finite opacity: its gradient (through the antialiasing factor too) matters
+        hm = generate_heatmaps(gm._xyz.detach(), gm.get_scaling.detach(), gm._rotation.detach(),
+                               torch.tensor(sc.poses_2d, device=device), sc.cameras)
+        loop = MultiViewLoop(gm, sc.cameras, hm, dataset="h36m", sparse=sparse, antialiasing=True)
+        loop.run(24)
+        outs.append([p.detach().cpu().clone() for p in (gm._xyz, gm._scaling, gm._opacity)])
+    moved = (outs[0][0] - torch.tensor(sc.pose_3d_init).float()).norm(dim=1).mean().item()
+    assert moved > 0.1
+    assert (outs[0][0] - outs[1][0]).norm(dim=1).max().item() < 5e-3 * max(moved, 1.0)
+    util.assert_close("scaling", outs[0][1], outs[1][1], rtol=1e-3, atol_scale=1e-3)
+
+
 def test_stress_config_binned_path(device):
     """BASELINE config 5 shape: 256 skeletons (P = 4352, C = 17), 2048x2048, binned path.  The oracle is too slow at this
     size, so: oracle parity on a cropped-resolution twin (same P, 512x512) + size-independent properties at full size."""
