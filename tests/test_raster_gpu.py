@@ -326,6 +326,44 @@ def test_many_gaussians_small_path(device):
     util.assert_close("dL_dfeatures", g["features"][0].cpu(), b["dL_dcolors"])
 
 
+def test_render_pipe_switches(device):
+    """The two pipeline switches of gaussian_renderer/__init__.py that change what reaches the rasterizer:
+    compute_cov3D_python (cov3D_precomp = pc.get_covariance(), :80-86) and override_color (colors_precomp instead of the
+    shs, :96-98); gradients reach the override colours (the true dL/dcolour)."""
+    from gaussian_renderer import render_functions
+    from skelsplat_amd.scene import SyntheticScene, GaussianModel
+    sc = SyntheticScene("h36m", n_views=2, seed=8, W=160, H=128, ring=2500.0, fx=1145.0 * 0.16 * 1.5, device=device)
+    gm = GaussianModel().create_from_points(sc.pose_3d_init, sc.spatial_lr_scale, sc.n_joints, scaling=3.9, device=device)
+    with torch.no_grad():
+        gm._opacity.fill_(1.0)
+        gm._rotation.add_(0.3 * torch.randn(gm._rotation.shape, generator=torch.Generator().manual_seed(0)).to(device))
+        gm._scaling.add_(0.3 * torch.randn(gm._scaling.shape, generator=torch.Generator().manual_seed(1)).to(device))
+    render = render_functions["diff-gaussian-rasterization-h36m"]
+    bg = torch.zeros(3, device=device)
+    cam = sc.cameras[0]
+    base = render(cam, gm, _Pipe, bg)
+
+    class PipeCov(_Pipe):
+        compute_cov3D_python = True
+    alt = render(cam, gm, PipeCov, bg)
+    assert torch.equal(alt["radii"], base["radii"])
+    util.assert_close("cov3D_python render", alt["render"].detach().cpu(), base["render"].detach().cpu(), rtol=2e-3, atol_scale=2e-4)
+    (alt["render"] * torch.rand_like(alt["render"])).sum().backward()
+    assert gm._scaling.grad is not None and gm._rotation.grad is not None and torch.isfinite(gm._scaling.grad).all()
+    assert float(gm._scaling.grad.abs().max()) > 0 and float(gm._rotation.grad.abs().max()) > 0
+    oc = (0.2 + 0.6 * torch.rand((sc.n_points, sc.n_joints), generator=torch.Generator().manual_seed(3))).to(device).requires_grad_(True)
+    ov = render(cam, gm, _Pipe, bg, override_color=oc)
+    w = torch.rand(ov["render"].shape, generator=torch.Generator().manual_seed(4)).to(device)
+    (ov["render"] * w).sum().backward()
+    assert oc.grad is not None and oc.grad.shape == oc.shape and float(oc.grad.abs().max()) > 0
+    # linear in the colours wherever the clamp does not bite: doubling a colour column doubles its plane
+    with torch.no_grad():
+        oc2 = oc.detach().clone() * 0.5
+    half = render(cam, gm, _Pipe, bg, override_color=oc2)["render"]
+    inside = ov["render"].detach() < 0.999
+    util.assert_close("colour linearity", (2.0 * half.detach())[inside].cpu(), ov["render"].detach()[inside].cpu(), rtol=1e-4, atol_scale=1e-5)
+
+
 @pytest.mark.parametrize("P", [64, 65, 256, 257])
 def test_kernel_selection_boundaries(device, P):
     """P = 64 is the last size of the wave-resident backward (one Gaussian per lane), 65 the first of the LDS gather
