@@ -94,7 +94,9 @@ __device__ __forceinline__ void adam_block_finish(const AdamArgs& a, float* s_xy
     const int P = a.P, V = a.V;
     const bool live = p < P;
     const int it1 = s_it[0], step = s_it[1];
-    // s_hyp: step sizes xyz / scaling / rotation / opacity, sqrt(bias_correction2), spare
+    // s_hyp: step sizes xyz / scaling / rotation / opacity, sqrt(bias_correction2), spare.  Thread 0 forms them (a few
+    // double divisions and a square root) while everybody else already gathers gradients, slots, moments and parameters:
+    // the barrier that publishes s_hyp comes only right before the update, so those loads and the scalar work overlap.
     if (p == 0) {
         const double lr_xyz = s_d[0] * s_d[1];
         const double bc1 = 1.0 - s_d[2];
@@ -104,7 +106,6 @@ __device__ __forceinline__ void adam_block_finish(const AdamArgs& a, float* s_xy
         s_hyp[3] = (float)(a.lr_opacity / bc1);
         s_hyp[4] = (float)sqrt(1.0 - s_d[3]);
     }
-    __syncthreads();
     // limb-symmetry loss gradient: L = lambda * (| |la| - |ra| | + | |ll| - |rl| |)  (loss_utils.py:226-250);
     // every view's loss contains it, so every slot carries it (train.py:150-152,175)
     float gc[3] = { 0, 0, 0 };
@@ -131,36 +132,52 @@ __device__ __forceinline__ void adam_block_finish(const AdamArgs& a, float* s_xy
                 for (int c = 0; c < 3; c++) gc[c] -= w * dir[k][c];
         }
     }
-    if (!live) return;
     // slots of the views rendered in this group get this group's gradient (others keep what they had: quirk Q8)
-    float gx[3] = { 0, 0, 0 };
-    for (int v = 0; v < V; v++) {
-        float* sl = a.slots + ((size_t)v * P + p) * 3;
-        if ((a.group_mask >> v) & 1ull) {
-            const float* gr = a.grads + ((size_t)v * P + p) * 11;
+    float g11[11], m[11], vv[11], np[11];
 #pragma unroll
-            for (int c = 0; c < 3; c++) sl[c] = gr[c] + gc[c];
+    for (int c = 0; c < 11; c++) { g11[c] = 0.0f; m[c] = 0.0f; vv[c] = 0.0f; np[c] = 0.0f; }
+    const int pl = live ? p : 0;
+    float* mp = a.m + (size_t)pl * 11;
+    float* vp = a.vv + (size_t)pl * 11;
+    if (live) {
+        for (int v = 0; v < V; v++) {
+            float* sl = a.slots + ((size_t)v * P + p) * 3;
+            if ((a.group_mask >> v) & 1ull) {
+                const float* gr = a.grads + ((size_t)v * P + p) * 11;
+#pragma unroll
+                for (int c = 0; c < 3; c++) sl[c] = gr[c] + gc[c];
+            }
+#pragma unroll
+            for (int c = 0; c < 3; c++) g11[c] += sl[c];   // mean over the V slots, view order (train.py:215-217)
         }
 #pragma unroll
-        for (int c = 0; c < 3; c++) gx[c] += sl[c];   // mean over the V slots, view order (train.py:215-217)
-    }
+        for (int c = 0; c < 3; c++) g11[c] /= (float)V;
+        const float* gl = a.grads + ((size_t)a.last_view * P + p) * 11;
 #pragma unroll
-    for (int c = 0; c < 3; c++) gx[c] /= (float)V;
-    const float* gl = a.grads + ((size_t)a.last_view * P + p) * 11;
+        for (int c = 3; c < 11; c++) g11[c] = gl[c];
+#pragma unroll
+        for (int c = 0; c < 11; c++) { m[c] = mp[c]; vv[c] = vp[c]; }
+#pragma unroll
+        for (int c = 0; c < 3; c++) { np[c] = a.xyz[3 * p + c]; np[3 + c] = a.scaling[3 * p + c]; }
+#pragma unroll
+        for (int c = 0; c < 4; c++) np[6 + c] = a.rotation[4 * p + c];
+        np[10] = a.opacity[p];
+    }
+    __syncthreads();   // s_hyp is published
+    if (!live) return;
     const float bc2s = s_hyp[4];
     const float w1 = (float)(1.0 - a.beta1), b2 = (float)a.beta2, w2 = (float)(1.0 - a.beta2), eps = (float)a.eps;
-    const float ss_xyz = s_hyp[0], ss_s = s_hyp[1], ss_r = s_hyp[2], ss_o = s_hyp[3];
-    float* m = a.m + (size_t)p * 11;
-    float* vv = a.vv + (size_t)p * 11;
-    float np[11];
+    const float ss[11] = { s_hyp[0], s_hyp[0], s_hyp[0], s_hyp[1], s_hyp[1], s_hyp[1], s_hyp[2], s_hyp[2], s_hyp[2], s_hyp[2], s_hyp[3] };
 #pragma unroll
-    for (int c = 0; c < 3; c++) { np[c] = a.xyz[3 * p + c]; adam_update(np[c], gx[c], m[c], vv[c], w1, b2, w2, eps, ss_xyz, bc2s); a.xyz[3 * p + c] = np[c]; }
+    for (int c = 0; c < 11; c++) {
+        adam_update(np[c], g11[c], m[c], vv[c], w1, b2, w2, eps, ss[c], bc2s);
+        mp[c] = m[c];
+        vp[c] = vv[c];
+    }
 #pragma unroll
-    for (int c = 0; c < 3; c++) { np[3 + c] = a.scaling[3 * p + c]; adam_update(np[3 + c], gl[3 + c], m[3 + c], vv[3 + c], w1, b2, w2, eps, ss_s, bc2s); a.scaling[3 * p + c] = np[3 + c]; }
+    for (int c = 0; c < 3; c++) { a.xyz[3 * p + c] = np[c]; a.scaling[3 * p + c] = np[3 + c]; }
 #pragma unroll
-    for (int c = 0; c < 4; c++) { np[6 + c] = a.rotation[4 * p + c]; adam_update(np[6 + c], gl[6 + c], m[6 + c], vv[6 + c], w1, b2, w2, eps, ss_r, bc2s); a.rotation[4 * p + c] = np[6 + c]; }
-    np[10] = a.opacity[p];
-    adam_update(np[10], gl[10], m[10], vv[10], w1, b2, w2, eps, ss_o, bc2s);
+    for (int c = 0; c < 4; c++) a.rotation[4 * p + c] = np[6 + c];
     a.opacity[p] = np[10];
     if (mirror) {
 #pragma unroll
