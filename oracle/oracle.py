@@ -19,7 +19,7 @@ _LIB = None
 
 def build(force=False):
     so = os.path.join(_HERE, "libsks_oracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("sks_oracle.c", "sks_oracle_aux.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("sks_oracle.c",)]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return so
