@@ -36,6 +36,8 @@ SIGNATURES = {
     "sks_masked_l2": (_i, [_i, _sz, _vp, _vp, _vp, _vp, _vp]),
     "sks_fused_ssim_fwd": (_i, [_i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sks_fused_ssim_bwd": (_i, [_i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sks_fused_ssim_bwd_uniform": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "sks_fused_ssim_sum": (_i, [_i, _i, _i, _i, _f, _f, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "sks_knn3_meandist2": (_i, [_i, _vp, _vp, _vp]),
     "sks_knn3_scratch_bytes": (_sz, [_i]),
     "sks_knn3_meandist2_grid": (_i, [_i, _vp, _vp, _vp, _sz, _vp]),

@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libskelsplat_hip.so")
-SOURCES = ["sks_raster.hip", "sks_ops.hip", "sks_loop.hip"]
+SOURCES = ["sks_raster.hip", "sks_ops.hip", "sks_ssim.hip", "sks_loop.hip"]
 # -ffp-contract=off is part of the numeric contract (DESIGN.md "Numerics"): tile lists, n_contrib and the forward
 # image must not depend on the compiler's FMA-contraction choices.
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",

@@ -1,39 +1,18 @@
 // sks_ops.hip -- the smaller ops of the hot path for MI355X (gfx950):
 //   * fused masked-L2 heat-map loss + gradient          (reference: utils/loss_utils.py:86-100, train.py:150-161)
-//   * fused SSIM forward / backward                      (reference: submodules/fused-ssim/ssim.cu:187-444)
 //   * mean squared distance to the 3 nearest neighbours  (reference: submodules/simple-knn/simple_knn.cu:132-222)
+//   * pseudo-GT heat-map planes                          (reference: utils/general_utils.py:175-304)
+// (fused SSIM: sks_ssim.hip)
 // All HBM-bound elementwise / stencil work: 16-byte coalesced accesses, LDS-staged tiles, no MFMA.
 #include <hip/hip_runtime.h>
 #include <float.h>
 #include <math.h>
-#include <stdarg.h>
-#include <stdio.h>
 
 #include "../../include/skelsplat_hip.h"
+#include "sks_err.h"
 #include "sks_math.h"
 
-// the error text lives in sks_raster.hip's thread-local buffer (sks_last_error); this TU reports through it
-extern "C" void sks_set_error_(const char* msg);
-
 namespace {
-
-thread_local char g_err2[512] = "";
-
-int fail2(int code, const char* fmt, ...)
-{
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(g_err2, sizeof(g_err2), fmt, ap);
-    va_end(ap);
-    sks_set_error_(g_err2);
-    return code;
-}
-
-#define HIP_TRY2(expr)                                                                        \
-    do {                                                                                      \
-        hipError_t e_ = (expr);                                                               \
-        if (e_ != hipSuccess) return fail2((int)e_, "%s: %s", #expr, hipGetErrorString(e_));  \
-    } while (0)
 
 using sks::wave_sum_d;
 
@@ -80,251 +59,6 @@ __global__ __launch_bounds__(256) void k_masked_l2(size_t n, const float* __rest
     if (tid == 0) {
         atomicAdd(&sums[2 * v], (s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3]));
         atomicAdd(&sums[2 * v + 1], (s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3]));
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// fused SSIM.  32x32 output tile per 256-thread workgroup (4 rows per thread), 11-tap separable Gaussian,
-// zero ("same") padding like get_pix_value (ssim.cu:36-42).  Tap order and the sigma = E[x^2] - mu^2 form follow
-// ssim.cu:100-185, 218-283.  grid (ceil(W/32), ceil(H/32), B*CH).
-// ------------------------------------------------------------------------------------------------------------
-__constant__ float c_gauss[11] = { 0.001028380123898387f, 0.0075987582094967365f, 0.036000773310661316f,
-                                   0.10936068743467331f,  0.21300552785396576f,  0.26601171493530273f,
-                                   0.21300552785396576f,  0.10936068743467331f,  0.036000773310661316f,
-                                   0.0075987582094967365f, 0.001028380123898387f };  // ssim.cu:9-19
-constexpr int ST = 32, SH = ST + 10;   // 32x32 outputs per block, 42x42 inputs with the 5-pixel halo
-constexpr int SP = 44;                  // LDS row pitch of the input tiles (floats): 16-byte aligned rows
-
-__device__ __forceinline__ float pix_or_zero(const float* __restrict__ img, int y, int x, int H, int W)
-{
-    return (x >= 0 && y >= 0 && x < W && y < H) ? img[(size_t)y * W + x] : 0.0f;
-}
-
-// Register-blocked separable convolution: the horizontal pass produces 4 adjacent outputs per work item from 14
-// inputs read as four 16-byte LDS loads; the vertical pass produces 4 vertically adjacent outputs per thread from
-// 14 rows.  ~4x fewer LDS instructions than one-output-per-read; tap order per output is still the reference's
-// left-to-right / top-to-bottom accumulation (ssim.cu:100-185).
-template <int NQ>
-__device__ __forceinline__ void conv_y4(const float (*hx)[SH][ST], int ly0, int lx, float (&out)[4][NQ])
-{
-#pragma unroll
-    for (int q = 0; q < NQ; q++) {
-        float col[14];
-#pragma unroll
-        for (int r = 0; r < 14; r++) col[r] = hx[q][ly0 + r][lx];
-#pragma unroll
-        for (int o = 0; o < 4; o++) {
-            float val = 0.0f;
-#pragma unroll
-            for (int t = 0; t < 11; t++) val += c_gauss[t] * col[o + t];
-            out[o][q] = val;
-        }
-    }
-}
-
-__device__ __forceinline__ void load14(const float* row, float (&v)[16])
-{
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const float4 t = reinterpret_cast<const float4*>(row)[i];
-        v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w;
-    }
-}
-
-// A block runs a sequence of jobs = (channel, x-tile) for its (tile row, batch); the next job's halo tile is
-// prefetched into registers while the current one is convolved, so the global-load latency overlaps the LDS/VALU work
-// (with one job per block the kernel ran at the speed of its load latency: 3 blocks per CU, ~2.3 us each).
-constexpr int NLD = (SH * SP + 255) / 256;   // halo elements per thread (8)
-
-struct SsimJob {
-    int c, tx;
-};
-__device__ __forceinline__ SsimJob ssim_job(int j, int txb, int tiles_x)
-{
-    SsimJob jb;
-    jb.c = j / txb;
-    jb.tx = blockIdx.x * txb + (j - jb.c * txb);
-    if (jb.tx >= tiles_x) jb.tx = -1;
-    return jb;
-}
-
-__global__ __launch_bounds__(256) void k_ssim_fwd(int H, int W, int CH, int txb, float C1, float C2,
-                                                   const float* __restrict__ img1, const float* __restrict__ img2,
-                                                   float* __restrict__ ssim_map, float* __restrict__ dm_dmu1,
-                                                   float* __restrict__ dm_dsigma1_sq, float* __restrict__ dm_dsigma12)
-{
-    __shared__ __attribute__((aligned(16))) float p1[SH][SP], p2[SH][SP];
-    __shared__ __attribute__((aligned(16))) float hx[5][SH][ST];
-    const int tid = threadIdx.x;
-    const int tiles_x = (W + ST - 1) / ST;
-    const int y0 = blockIdx.y * ST;
-    const int njobs = CH * txb;
-    float r1[NLD], r2[NLD];
-    auto fetch = [&](int j) {
-        const SsimJob jb = ssim_job(j, txb, tiles_x);
-        const size_t plane = ((size_t)blockIdx.z * CH + jb.c) * H * W;
-#pragma unroll
-        for (int k = 0; k < NLD; k++) {
-            const int i = tid + k * 256;
-            const int ly = i / SP, lx = i - ly * SP;
-            const bool in = jb.tx >= 0 && i < SH * SP && lx < SH;
-            r1[k] = in ? pix_or_zero(img1 + plane, y0 + ly - 5, jb.tx * ST + lx - 5, H, W) : 0.0f;
-            r2[k] = in ? pix_or_zero(img2 + plane, y0 + ly - 5, jb.tx * ST + lx - 5, H, W) : 0.0f;
-        }
-    };
-    fetch(0);
-    for (int j = 0; j < njobs; j++) {
-        const SsimJob jb = ssim_job(j, txb, tiles_x);
-#pragma unroll
-        for (int k = 0; k < NLD; k++) {
-            const int i = tid + k * 256;
-            if (i < SH * SP) { (&p1[0][0])[i] = r1[k]; (&p2[0][0])[i] = r2[k]; }
-        }
-        __syncthreads();
-        if (j + 1 < njobs) fetch(j + 1);   // in flight during the two passes below
-        if (jb.tx >= 0) {
-            for (int i = tid; i < SH * (ST / 4); i += 256) {  // horizontal pass (ssim.cu:100-164), 4 outputs per item
-                const int ly = i / (ST / 4), g4 = (i - ly * (ST / 4)) * 4;
-                float u[16], w[16];
-                load14(&p1[ly][g4], u);
-                load14(&p2[ly][g4], w);
-                float4 o[5];
-                float* of = reinterpret_cast<float*>(o);
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    float m1 = 0.0f, m2 = 0.0f, s11 = 0.0f, s22 = 0.0f, s12 = 0.0f;
-#pragma unroll
-                    for (int t = 0; t < 11; t++) {
-                        const float uu = u[k + t], ww = w[k + t], gk = c_gauss[t];
-                        m1 += gk * uu;
-                        m2 += gk * ww;
-                        s11 += gk * (uu * uu);
-                        s22 += gk * (ww * ww);
-                        s12 += gk * (uu * ww);
-                    }
-                    of[0 * 4 + k] = m1; of[1 * 4 + k] = m2; of[2 * 4 + k] = s11; of[3 * 4 + k] = s22; of[4 * 4 + k] = s12;
-                }
-#pragma unroll
-                for (int q = 0; q < 5; q++) *reinterpret_cast<float4*>(&hx[q][ly][g4]) = o[q];
-            }
-        }
-        __syncthreads();
-        if (jb.tx >= 0) {
-            const size_t plane = ((size_t)blockIdx.z * CH + jb.c) * H * W;
-            const int x0 = jb.tx * ST;
-            const int lx = tid & 31, ly0 = (tid >> 5) * 4;
-            float q4[4][5];
-            conv_y4<5>(hx, ly0, lx, q4);
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int x = x0 + lx, y = y0 + ly0 + r;
-                const float mu1 = q4[r][0], mu2 = q4[r][1];
-                const float sigma1_sq = q4[r][2] - mu1 * mu1;
-                const float sigma2_sq = q4[r][3] - mu2 * mu2;
-                const float sigma12 = q4[r][4] - mu1 * mu2;
-                // ssim.cu:262-283
-                const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu1_mu2 = mu1 * mu2;
-                const float Cc = (2.0f * mu1_mu2 + C1);
-                const float D = (2.0f * sigma12 + C2);
-                const float A = (mu1_sq + mu2_sq + C1);
-                const float B = (sigma1_sq + sigma2_sq + C2);
-                const float m = (Cc * D) / (A * B);
-                if (x < W && y < H) {
-                    const size_t gi = plane + (size_t)y * W + x;
-                    ssim_map[gi] = m;
-                    if (dm_dmu1) {
-                        dm_dmu1[gi] = ((mu2 * 2.0f * D) / (A * B) - (mu2 * 2.0f * Cc) / (A * B) - (mu1 * 2.0f * Cc * D) / (A * A * B) +
-                                       (mu1 * 2.0f * Cc * D) / (A * B * B));
-                        dm_dsigma1_sq[gi] = ((-Cc * D) / (A * B * B));
-                        dm_dsigma12[gi] = ((2 * Cc) / (A * B));
-                    }
-                }
-            }
-        }
-        // the next iteration's LDS writes are ordered behind this barrier-free region by the barrier at its top...
-        __syncthreads();
-    }
-}
-
-// backward (ssim.cu:288-366): dL/dimg1 = G*(dL_dmap dm_dmu1) + 2 img1 G*(dL_dmap dm_dsigma1_sq) + img2 G*(dL_dmap dm_dsigma12)
-__global__ __launch_bounds__(256) void k_ssim_bwd(int H, int W, int CH, int txb, const float* __restrict__ img1,
-                                                   const float* __restrict__ img2, const float* __restrict__ dL_dmap,
-                                                   const float* __restrict__ dm_dmu1, const float* __restrict__ dm_dsigma1_sq,
-                                                   const float* __restrict__ dm_dsigma12, float* __restrict__ dL_dimg1)
-{
-    __shared__ __attribute__((aligned(16))) float pq[3][SH][SP];
-    __shared__ __attribute__((aligned(16))) float hx[3][SH][ST];
-    const int tid = threadIdx.x;
-    const int tiles_x = (W + ST - 1) / ST;
-    const int y0 = blockIdx.y * ST;
-    const int njobs = CH * txb;
-    float r0[NLD], r1[NLD], r2[NLD];
-    auto fetch = [&](int j) {
-        const SsimJob jb = ssim_job(j, txb, tiles_x);
-        const size_t plane = ((size_t)blockIdx.z * CH + jb.c) * H * W;
-#pragma unroll
-        for (int k = 0; k < NLD; k++) {
-            const int i = tid + k * 256;
-            const int ly = i / SP, lx = i - ly * SP;
-            const bool in = jb.tx >= 0 && i < SH * SP && lx < SH;
-            const int y = y0 + ly - 5, x = jb.tx * ST + lx - 5;
-            const float d = in ? pix_or_zero(dL_dmap + plane, y, x, H, W) : 0.0f;
-            r0[k] = in ? pix_or_zero(dm_dmu1 + plane, y, x, H, W) * d : 0.0f;
-            r1[k] = in ? pix_or_zero(dm_dsigma1_sq + plane, y, x, H, W) * d : 0.0f;
-            r2[k] = in ? pix_or_zero(dm_dsigma12 + plane, y, x, H, W) * d : 0.0f;
-        }
-    };
-    fetch(0);
-    for (int j = 0; j < njobs; j++) {
-        const SsimJob jb = ssim_job(j, txb, tiles_x);
-#pragma unroll
-        for (int k = 0; k < NLD; k++) {
-            const int i = tid + k * 256;
-            if (i < SH * SP) { (&pq[0][0][0])[i] = r0[k]; (&pq[1][0][0])[i] = r1[k]; (&pq[2][0][0])[i] = r2[k]; }
-        }
-        __syncthreads();
-        if (j + 1 < njobs) fetch(j + 1);
-        if (jb.tx >= 0) {
-            for (int i = tid; i < SH * (ST / 4); i += 256) {
-                const int ly = i / (ST / 4), g4 = (i - ly * (ST / 4)) * 4;
-#pragma unroll
-                for (int q = 0; q < 3; q++) {
-                    float u[16];
-                    load14(&pq[q][ly][g4], u);
-                    float4 o;
-                    float* of = reinterpret_cast<float*>(&o);
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        float val = 0.0f;
-#pragma unroll
-                        for (int t = 0; t < 11; t++) val += c_gauss[t] * u[k + t];
-                        of[k] = val;
-                    }
-                    *reinterpret_cast<float4*>(&hx[q][ly][g4]) = o;
-                }
-            }
-        }
-        __syncthreads();
-        if (jb.tx >= 0) {
-            const size_t plane = ((size_t)blockIdx.z * CH + jb.c) * H * W;
-            const int x0 = jb.tx * ST;
-            const int lx = tid & 31, ly0 = (tid >> 5) * 4;
-            float q4[4][3];
-            conv_y4<3>(hx, ly0, lx, q4);
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int x = x0 + lx, y = y0 + ly0 + r;
-                if (x < W && y < H) {
-                    const size_t gi = plane + (size_t)y * W + x;
-                    float dL_dpix = 0.0f;
-                    dL_dpix += q4[r][0];
-                    dL_dpix += img1[gi] * 2.0f * q4[r][1];
-                    dL_dpix += img2[gi] * q4[r][2];
-                    dL_dimg1[gi] = dL_dpix;
-                }
-            }
-        }
-        __syncthreads();
     }
 }
 
@@ -541,14 +275,6 @@ __global__ __launch_bounds__(256) void k_knn_search(int P, KnnGrid g, int nparts
 }  // namespace
 
 namespace {
-// x-tiles per block: every block runs CH * txb pipelined jobs; keep >= ~3000 blocks on the chip when the image allows
-int ssim_tiles_per_block(int tiles_x, int tiles_y, int B, int CH)
-{
-    int txb = 1;
-    while (txb < 8 && CH * txb < 4 && (long long)((tiles_x + 2 * txb - 1) / (2 * txb)) * tiles_y * B >= 3000) txb *= 2;
-    return txb;
-}
-
 // ------------------------------------------------------------------------------------------------------------
 // heat-map planes: out[y][x] = (row[y] * col[x] - cmin) / den, one streaming write.  grid (x chunks of 1024 px,
 // 16-row bands, V*J); a thread keeps its 4 column weights in registers and walks the band's rows (the row weight is
@@ -598,41 +324,6 @@ int sks_masked_l2(int V, size_t n_per_view, const float* render, const float* gt
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_masked_l2, dim3((unsigned)blocks, V), dim3(256), 0, st, n_per_view, render, gt, dL_unscaled, sums);
-    HIP_TRY2(hipGetLastError());
-    return 0;
-}
-
-int sks_fused_ssim_fwd(int B, int CH, int H, int W, float C1, float C2, const float* img1, const float* img2,
-                       float* ssim_map, float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12, void* stream)
-{
-    if (B < 0 || CH < 0 || H < 1 || W < 1) return fail2(-1, "ssim: bad shape");
-    if (B * CH == 0) return 0;
-    if (!img1 || !img2 || !ssim_map) return fail2(-2, "ssim: missing pointer");
-    if ((dm_dmu1 != nullptr) != (dm_dsigma1_sq != nullptr) || (dm_dmu1 != nullptr) != (dm_dsigma12 != nullptr))
-        return fail2(-2, "ssim: provide all three partial-derivative maps or none");
-    const int tiles_x = (W + ST - 1) / ST, tiles_y = (H + ST - 1) / ST;
-    const int txb = ssim_tiles_per_block(tiles_x, tiles_y, B, CH);
-    dim3 grid((tiles_x + txb - 1) / txb, tiles_y, B);
-    hipLaunchKernelGGL(k_ssim_fwd, grid, dim3(256), 0, (hipStream_t)stream, H, W, CH, txb, C1, C2, img1, img2, ssim_map,
-                       dm_dmu1, dm_dsigma1_sq, dm_dsigma12);
-    HIP_TRY2(hipGetLastError());
-    return 0;
-}
-
-int sks_fused_ssim_bwd(int B, int CH, int H, int W, float C1, float C2, const float* img1, const float* img2,
-                       const float* dL_dmap, const float* dm_dmu1, const float* dm_dsigma1_sq, const float* dm_dsigma12,
-                       float* dL_dimg1, void* stream)
-{
-    (void)C1; (void)C2;
-    if (B < 0 || CH < 0 || H < 1 || W < 1) return fail2(-1, "ssim: bad shape");
-    if (B * CH == 0) return 0;
-    if (!img1 || !img2 || !dL_dmap || !dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12 || !dL_dimg1)
-        return fail2(-2, "ssim backward: missing pointer");
-    const int tiles_x = (W + ST - 1) / ST, tiles_y = (H + ST - 1) / ST;
-    const int txb = ssim_tiles_per_block(tiles_x, tiles_y, B, CH);
-    dim3 grid((tiles_x + txb - 1) / txb, tiles_y, B);
-    hipLaunchKernelGGL(k_ssim_bwd, grid, dim3(256), 0, (hipStream_t)stream, H, W, CH, txb, img1, img2, dL_dmap, dm_dmu1,
-                       dm_dsigma1_sq, dm_dsigma12, dL_dimg1);
     HIP_TRY2(hipGetLastError());
     return 0;
 }

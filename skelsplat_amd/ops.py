@@ -1,4 +1,4 @@
-"""Python surface of the smaller hot-path ops (C ABI: sks_masked_l2, sks_fused_ssim_fwd/bwd, sks_knn3_meandist2)."""
+"""Python surface of the smaller hot-path ops (C ABI: sks_masked_l2, sks_fused_ssim_*, sks_knn3_meandist2*)."""
 import torch
 
 from . import _lib
@@ -83,15 +83,59 @@ class FusedSSIMMap(torch.autograd.Function):
         return None, None, grad, None, None, None
 
 
+class FusedSSIMMean(torch.autograd.Function):
+    """`FusedSSIMMap.apply(...).mean()` in one pass each way: the forward accumulates the (cropped) mean while it
+    writes the three partial-derivative maps and never writes the SSIM map; the backward takes the scalar upstream
+    gradient, so no (B,CH,H,W) gradient image is materialised, padded or read."""
+
+    @staticmethod
+    def forward(ctx, C1, C2, img1, img2, padding="same", train=True):
+        img1c, img2c = _chk(img1, "img1"), _chk(img2, "img2")
+        if img1c.dim() != 4 or img1c.shape != img2c.shape:
+            raise RuntimeError("fused_ssim expects two (B,CH,H,W) tensors of equal shape")
+        B, CH, H, W = img1c.shape
+        dev = img1c.device
+        crop = 5 if padding == "valid" else 0
+        count = B * CH * max(H - 2 * crop, 0) * max(W - 2 * crop, 0)
+        parts = [torch.empty_like(img1c) for _ in range(3)] if train else [None, None, None]
+        total = torch.empty((), dtype=torch.float64, device=dev)
+        with torch.cuda.device(dev):
+            rc = _lib.load().sks_fused_ssim_sum(B, CH, H, W, float(C1), float(C2), img1c.data_ptr(), img2c.data_ptr(), crop,
+                                                _lib.ptr(parts[0]), _lib.ptr(parts[1]), _lib.ptr(parts[2]),
+                                                total.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(rc, "sks_fused_ssim_sum")
+        emp = torch.empty(0, device=dev)
+        ctx.save_for_backward(img1c.detach(), img2c, *(p if p is not None else emp for p in parts))
+        ctx.crop, ctx.count, ctx.train = crop, count, train
+        return (total / count).to(torch.float32)   # count == 0 -> nan, like the mean of an empty map
+
+    @staticmethod
+    def backward(ctx, g):
+        img1, img2, dm_dmu1, dm_dsigma1_sq, dm_dsigma12 = ctx.saved_tensors
+        if not ctx.train:
+            raise RuntimeError("fused_ssim was called with train=False: no backward state was kept")
+        B, CH, H, W = img1.shape
+        dev = img1.device
+        grad = torch.empty_like(img1)
+        dval = (g.to(torch.float32) / ctx.count).contiguous()   # d mean / d map, one device scalar
+        with torch.cuda.device(dev):
+            rc = _lib.load().sks_fused_ssim_bwd_uniform(B, CH, H, W, img1.data_ptr(), img2.data_ptr(), dval.data_ptr(),
+                                                        ctx.crop, dm_dmu1.data_ptr(), dm_dsigma1_sq.data_ptr(),
+                                                        dm_dsigma12.data_ptr(), grad.data_ptr(),
+                                                        torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(rc, "sks_fused_ssim_bwd_uniform")
+        return None, None, grad, None, None, None
+
+
 allowed_padding = ["same", "valid"]
 
 
 def fused_ssim(img1, img2, padding="same", train=True):
-    """submodules/fused-ssim/fused_ssim/__init__.py:34-41."""
+    """submodules/fused-ssim/fused_ssim/__init__.py:34-41 (`FusedSSIMMap.apply(...).mean()`, fused)."""
     C1 = 0.01 ** 2
     C2 = 0.03 ** 2
     assert padding in allowed_padding
-    return FusedSSIMMap.apply(C1, C2, img1, img2, padding, train).mean()
+    return FusedSSIMMean.apply(C1, C2, img1, img2, padding, train)
 
 
 KNN_GRID_MIN_POINTS = 2048   # above this the uniform-grid search beats the all-pairs sweep

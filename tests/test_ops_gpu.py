@@ -26,7 +26,38 @@ def ssim_torch(img1, img2):
     return ((2 * mu1 * mu2 + C1) * (2 * s12 + C2)) / ((mu1.pow(2) + mu2.pow(2) + C1) * (s1 + s2 + C2))
 
 
-@pytest.mark.parametrize("shape", [(2, 3, 67, 45), (1, 17, 128, 160), (5, 5, 270, 480)])
+SSIM_SHAPES = [(2, 3, 67, 45), (1, 17, 128, 160), (5, 5, 270, 480), (1, 2, 33, 200), (1, 1, 12, 16), (2, 1, 97, 131)]
+
+
+@pytest.mark.parametrize("shape", SSIM_SHAPES)
+@pytest.mark.parametrize("padding", ["same", "valid"])
+def test_fused_ssim_map_matches_conv2d_ssim(device, shape, padding):
+    """The map-returning autograd function (fused_ssim/__init__.py:8-32) under an arbitrary upstream gradient."""
+    from fused_ssim import FusedSSIMMap
+    g = torch.Generator().manual_seed(1)
+    img1 = torch.rand(shape, generator=g).to(device).requires_grad_(True)
+    img2 = torch.rand(shape, generator=g).to(device)
+    m = FusedSSIMMap.apply(0.01 ** 2, 0.03 ** 2, img1, img2, padding, True)
+    wgt = torch.rand(m.shape, generator=g)
+    (m * wgt.to(device)).sum().backward()
+    ref1 = img1.detach().double().cpu().requires_grad_(True)
+    mr = ssim_torch(ref1, img2.double().cpu())
+    if padding == "valid":
+        mr = mr[:, :, 5:-5, 5:-5]
+    (mr * wgt.double()).sum().backward()
+    util.assert_close("ssim_map", m.detach().cpu(), mr.detach(), rtol=2e-5, atol_scale=5e-6)
+    util.assert_close("dL_dimg1", img1.grad.cpu(), ref1.grad, rtol=1e-3, atol_scale=1e-4)
+    # a contiguous tensor at a 4-byte offset takes the scalar-load path and gives the same map
+    n = int(np.prod(shape))
+    f1, f2 = torch.rand(n + 1, generator=g).to(device), torch.rand(n + 1, generator=g).to(device)
+    a, b = f1[1:].view(shape), f2[1:].view(shape)
+    assert a.is_contiguous() and a.data_ptr() % 16 != 0
+    m1 = FusedSSIMMap.apply(0.01 ** 2, 0.03 ** 2, a, b, "same", False)
+    m2 = FusedSSIMMap.apply(0.01 ** 2, 0.03 ** 2, a.clone(), b.clone(), "same", False)
+    assert torch.equal(m1, m2)
+
+
+@pytest.mark.parametrize("shape", SSIM_SHAPES)
 @pytest.mark.parametrize("padding", ["same", "valid"])
 def test_fused_ssim_matches_conv2d_ssim(device, shape, padding):
     from fused_ssim import fused_ssim
