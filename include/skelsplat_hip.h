@@ -139,17 +139,22 @@ int sks_fused_ssim_fwd(int B, int CH, int H, int W, float C1, float C2, const fl
 int sks_fused_ssim_bwd(int B, int CH, int H, int W, float C1, float C2, const float* img1, const float* img2,
                        const float* dL_dmap, const float* dm_dmu1, const float* dm_dsigma1_sq, const float* dm_dsigma12,
                        float* dL_dimg1, void* stream);
-/* The same backward when dL_dmap is what `.mean()` of the map hands back (fused_ssim/__init__.py:41): one value
- * (*dL_value, device memory) on the image shrunk by `crop` pixels per side (5 for padding == "valid",
+/* The same backward when dL_dmap is what `.mean()` of the map hands back (fused_ssim/__init__.py:41): one value,
+ * *dL_value (device memory) * dL_scale, on the image shrunk by `crop` pixels per side (5 for padding == "valid",
  * fused_ssim/__init__.py:13-14,24-26; 0 for "same") and zero outside.  No gradient image is materialised or read. */
 int sks_fused_ssim_bwd_uniform(int B, int CH, int H, int W, const float* img1, const float* img2, const float* dL_value,
-                               int crop, const float* dm_dmu1, const float* dm_dsigma1_sq, const float* dm_dsigma12,
-                               float* dL_dimg1, void* stream);
-/* fused_ssim()'s `map.mean()` without the map (fused_ssim/__init__.py:34-41): *total (device, fp64) = sum of the SSIM
- * map over the image shrunk by `crop` pixels per side; the caller divides by B*CH*(H-2crop)*(W-2crop).  The three
- * partial-derivative maps are written when given (train == true), the map itself never. */
-int sks_fused_ssim_sum(int B, int CH, int H, int W, float C1, float C2, const float* img1, const float* img2, int crop,
-                       float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12, double* total, void* stream);
+                               float dL_scale, int crop, const float* dm_dmu1, const float* dm_dsigma1_sq,
+                               const float* dm_dsigma12, float* dL_dimg1, void* stream);
+/* fused_ssim()'s `map.mean()` without the map (fused_ssim/__init__.py:34-41): *mean_out (device, fp32) = mean of the
+ * SSIM map over the image shrunk by `crop` pixels per side (accumulated in fp64).  The three partial-derivative maps
+ * are written when given (train == true), the map itself never.  scratch: SKS_SSIM_SCRATCH_BYTES of device memory that
+ * is ZERO on entry and is left zero on exit (workgroups add to different slots, a one-wave kernel reduces and clears
+ * them), so one buffer zeroed once serves every call on a stream. */
+#define SKS_SSIM_SUM_SLOTS 64
+#define SKS_SSIM_SCRATCH_BYTES (SKS_SSIM_SUM_SLOTS * 8)
+int sks_fused_ssim_mean(int B, int CH, int H, int W, float C1, float C2, const float* img1, const float* img2, int crop,
+                        float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12, double* scratch, float* mean_out,
+                        void* stream);
 
 /* Replaces distCUDA2 (submodules/simple-knn/spatial.cu:15-26 -> SimpleKNN::knn simple_knn.cu:186-222):
  * points (P,3) -> mean squared distance to the 3 nearest neighbours (P). */

@@ -6,14 +6,17 @@ import os
 import shutil
 import subprocess
 import sys
+import tempfile
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libskelsplat_hip.so")
-SOURCES = ["sks_raster.hip", "sks_ops.hip", "sks_ssim.hip", "sks_loop.hip"]
+# source -> extra flags.  sks_ssim.hip: see its header (the SLP vectoriser's packing costs more moves than it saves)
+SOURCES = {"sks_raster.hip": [], "sks_ops.hip": [], "sks_ssim.hip": ["-fno-slp-vectorize"], "sks_loop.hip": []}
 # -ffp-contract=off is part of the numeric contract (DESIGN.md "Numerics"): tile lists, n_contrib and the forward
 # image must not depend on the compiler's FMA-contraction choices.
-FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function",
          # keep kernel-argument loads in the entry block: sunk into the branch that uses them they become extra
          # dependent scalar round trips in front of the first store of the forward's fill blocks, whose whole life is
@@ -39,11 +42,23 @@ def _stale():
 def build(force=False, verbose=False):
     if not force and not _stale():
         return LIB
-    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    cmd = [hipcc()] + FLAGS + ["-o", LIB + ".tmp"] + srcs
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
+    cc = hipcc()
+    with tempfile.TemporaryDirectory(prefix="sks_build_") as tmp:
+        def compile_one(item):
+            src, extra = item
+            obj = os.path.join(tmp, src + ".o")
+            cmd = [cc] + FLAGS + extra + ["-c", "-o", obj, os.path.join(CSRC, src)]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.check_call(cmd)
+            return obj
+
+        with ThreadPoolExecutor(max_workers=4) as pool:   # one translation unit per source, compiled side by side
+            objs = list(pool.map(compile_one, SOURCES.items()))
+        cmd = [cc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB + ".tmp"] + objs
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
     os.replace(LIB + ".tmp", LIB)
     return LIB
 

@@ -83,6 +83,18 @@ class FusedSSIMMap(torch.autograd.Function):
         return None, None, grad, None, None, None
 
 
+_SSIM_SCRATCH = {}
+
+
+def _ssim_scratch(dev, stream):
+    """The self-clearing reduction scratch of sks_fused_ssim_mean, one per (device, stream), zeroed once."""
+    key = (dev.index, stream)
+    buf = _SSIM_SCRATCH.get(key)
+    if buf is None:
+        buf = _SSIM_SCRATCH[key] = torch.zeros(_lib.SKS_SSIM_SCRATCH_BYTES // 8, dtype=torch.float64, device=dev)
+    return buf
+
+
 class FusedSSIMMean(torch.autograd.Function):
     """`FusedSSIMMap.apply(...).mean()` in one pass each way: the forward accumulates the (cropped) mean while it
     writes the three partial-derivative maps and never writes the SSIM map; the backward takes the scalar upstream
@@ -98,16 +110,17 @@ class FusedSSIMMean(torch.autograd.Function):
         crop = 5 if padding == "valid" else 0
         count = B * CH * max(H - 2 * crop, 0) * max(W - 2 * crop, 0)
         parts = [torch.empty_like(img1c) for _ in range(3)] if train else [None, None, None]
-        total = torch.empty((), dtype=torch.float64, device=dev)
+        mean = torch.empty((), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            rc = _lib.load().sks_fused_ssim_sum(B, CH, H, W, float(C1), float(C2), img1c.data_ptr(), img2c.data_ptr(), crop,
-                                                _lib.ptr(parts[0]), _lib.ptr(parts[1]), _lib.ptr(parts[2]),
-                                                total.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
-        _lib.check(rc, "sks_fused_ssim_sum")
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            rc = _lib.load().sks_fused_ssim_mean(B, CH, H, W, float(C1), float(C2), img1c.data_ptr(), img2c.data_ptr(), crop,
+                                                 _lib.ptr(parts[0]), _lib.ptr(parts[1]), _lib.ptr(parts[2]),
+                                                 _ssim_scratch(dev, stream).data_ptr(), mean.data_ptr(), stream)
+        _lib.check(rc, "sks_fused_ssim_mean")
         emp = torch.empty(0, device=dev)
         ctx.save_for_backward(img1c.detach(), img2c, *(p if p is not None else emp for p in parts))
         ctx.crop, ctx.count, ctx.train = crop, count, train
-        return (total / count).to(torch.float32)   # count == 0 -> nan, like the mean of an empty map
+        return mean
 
     @staticmethod
     def backward(ctx, g):
@@ -117,11 +130,11 @@ class FusedSSIMMean(torch.autograd.Function):
         B, CH, H, W = img1.shape
         dev = img1.device
         grad = torch.empty_like(img1)
-        dval = (g.to(torch.float32) / ctx.count).contiguous()   # d mean / d map, one device scalar
+        g = g.to(torch.float32).contiguous()   # d loss / d mean, one device scalar; d mean / d map = 1 / count
         with torch.cuda.device(dev):
-            rc = _lib.load().sks_fused_ssim_bwd_uniform(B, CH, H, W, img1.data_ptr(), img2.data_ptr(), dval.data_ptr(),
-                                                        ctx.crop, dm_dmu1.data_ptr(), dm_dsigma1_sq.data_ptr(),
-                                                        dm_dsigma12.data_ptr(), grad.data_ptr(),
+            rc = _lib.load().sks_fused_ssim_bwd_uniform(B, CH, H, W, img1.data_ptr(), img2.data_ptr(), g.data_ptr(),
+                                                        1.0 / max(ctx.count, 1), ctx.crop, dm_dmu1.data_ptr(),
+                                                        dm_dsigma1_sq.data_ptr(), dm_dsigma12.data_ptr(), grad.data_ptr(),
                                                         torch.cuda.current_stream(dev).cuda_stream)
         _lib.check(rc, "sks_fused_ssim_bwd_uniform")
         return None, None, grad, None, None, None

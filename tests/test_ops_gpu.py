@@ -76,8 +76,16 @@ def test_fused_ssim_matches_conv2d_ssim(device, shape, padding):
     # against an fp64 reference the fp32 kernel is held to 2e-5 relative on the value, 1e-4*max on the gradient
     assert abs(val.item() - ref.item()) <= 2e-5 * abs(ref.item())
     util.assert_close("dL_dimg1", img1.grad.cpu(), ref1.grad, rtol=1e-3, atol_scale=1e-4)
-    # train=False returns the same value and keeps no state
-    assert abs(fused_ssim(img1.detach(), img2, padding=padding, train=False).item() - val.item()) <= 1e-7
+    # train=False returns the same value and keeps no state; the reduction scratch clears itself between calls
+    for _ in range(3):
+        assert abs(fused_ssim(img1.detach(), img2, padding=padding, train=False).item() - val.item()) <= 1e-7
+
+
+def test_fused_ssim_empty_valid_map_is_nan(device):
+    from fused_ssim import fused_ssim
+    a = torch.rand(1, 2, 9, 40, device=device)
+    assert math.isnan(fused_ssim(a, a.clone(), padding="valid", train=False).item())   # 9 - 10 rows: nothing left
+    assert abs(fused_ssim(a, a.clone(), padding="same", train=False).item() - 1.0) < 1e-6
 
 
 @pytest.mark.parametrize("P", [1, 3, 4, 17, 19, 300, 2000])
