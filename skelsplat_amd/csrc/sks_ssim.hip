@@ -121,9 +121,12 @@ __device__ __forceinline__ void carry_rows(v4f* h, int slots)
 
 // ---- forward ---------------------------------------------------------------------------------------------------
 // horizontal pass (ssim.cu:100-164) over `nrows` staged rows -> filtered rows hoff .. hoff+nrows-1 (hoff even)
-__device__ __forceinline__ void fwd_rows(const v4f* s_in, v4f* s_h01, v4f* s_h23, v4f* s_h4, int nrows, int hoff)
+template <int NROWS>
+__device__ __forceinline__ void fwd_rows(const v4f* s_in, v4f* s_h01, v4f* s_h23, v4f* s_h4, int hoff)
 {
-    for (int i = threadIdx.x; i < nrows * HG; i += NT) {
+#pragma unroll
+    for (int i = threadIdx.x; i < NROWS * HG; i += NT) {   // 2 items per thread per tile: the second one's LDS reads are
+                                                            // in flight under the first one's FMAs
         int row, g, par;
         item_of(i, row, g, par);
         const int base = row * IN_SLOTS + 2 * g + 1;   // chunks 2g+1 .. 2g+8 = tile-local columns 4g-6 .. 4g+9
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(NT) void k_ssim_fwd(int H, int W, int S, float C1, 
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < NLD; k++) fetch(ytop + 2 * HALO, k);   // in flight during the prologue's pass
-    fwd_rows(s_in, s_h01, s_h23, s_h4, 2 * HALO, 0);
+    fwd_rows<2 * HALO>(s_in, s_h01, s_h23, s_h4, 0);
     __syncthreads();
 
     double acc = 0.0;
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(NT) void k_ssim_fwd(int H, int W, int S, float C1, 
 #pragma unroll
             for (int k = 0; k < NLD; k++) fetch(y0 + TH + HALO, k);   // the next tile's rows, in flight during the passes
         }
-        fwd_rows(s_in, s_h01, s_h23, s_h4, TH, 2 * HALO);
+        fwd_rows<TH>(s_in, s_h01, s_h23, s_h4, 2 * HALO);
         __syncthreads();
         {
             // vertical pass (ssim.cu:166-185, 218-260): columns 2cx, 2cx+1; rows 4rg .. 4rg+3
@@ -337,9 +340,11 @@ __global__ __launch_bounds__(64) void k_ssim_mean_finish(double* __restrict__ to
 constexpr int I1_SLOTS = 24;   // chunk pitch of the single-float staged image (20 used): the next row starts 8 chunks
                                // further mod 16, which separates the two rows of a lane group without a swizzle
 
-__device__ __forceinline__ void bwd_rows(const v4f* s_in01, const v4f* s_in2, v4f* s_h01, v4f* s_h2, int nrows, int hoff)
+template <int NROWS>
+__device__ __forceinline__ void bwd_rows(const v4f* s_in01, const v4f* s_in2, v4f* s_h01, v4f* s_h2, int hoff)
 {
-    for (int i = threadIdx.x; i < nrows * HG; i += NT) {   // horizontal pass (ssim.cu:318-340)
+#pragma unroll
+    for (int i = threadIdx.x; i < NROWS * HG; i += NT) {   // horizontal pass (ssim.cu:318-340)
         int row, g, par;
         item_of(i, row, g, par);
         const int base = row * IN_SLOTS + 2 * g + 1;   // tile-local columns 4g-6 .. 4g+9
@@ -438,7 +443,7 @@ __global__ __launch_bounds__(NT) void k_ssim_bwd(int H, int W, int S, const floa
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < NLD; k++) fetch(ytop + 2 * HALO, k);
-    bwd_rows(s_in01, s_in2, s_h01, s_h2, 2 * HALO, 0);
+    bwd_rows<2 * HALO>(s_in01, s_in2, s_h01, s_h2, 0);
     __syncthreads();
 
     for (int j = 0; j < njobs; j++) {
@@ -454,10 +459,27 @@ __global__ __launch_bounds__(NT) void k_ssim_bwd(int H, int W, int S, const floa
 #pragma unroll
             for (int k = 0; k < NLD; k++) fetch(y0 + TH + HALO, k);
         }
-        bwd_rows(s_in01, s_in2, s_h01, s_h2, TH, 2 * HALO);
+        bwd_rows<TH>(s_in01, s_in2, s_h01, s_h2, 2 * HALO);
         __syncthreads();
         {
             const int cx = tid & 31, rg = tid >> 5;   // vertical pass (ssim.cu:342-365)
+            const int x = x0 + 2 * cx;
+            v2f p1[4], p2[4];   // the images at this thread's outputs: requested now, used after the 132 FMAs below
+#pragma unroll
+            for (int o = 0; o < 4; o++) {
+                const int y = y0 + 4 * rg + o;
+                p1[o] = p2[o] = (v2f){ 0.0f, 0.0f };
+                if (y < H && x < W) {
+                    const size_t gi = plane + (size_t)y * W + x;
+                    if (VEC) {
+                        p1[o] = *reinterpret_cast<const v2f*>(img1 + gi);
+                        p2[o] = *reinterpret_cast<const v2f*>(img2 + gi);
+                    } else {
+                        p1[o].x = img1[gi]; p2[o].x = img2[gi];
+                        if (x + 1 < W) { p1[o].y = img1[gi + 1]; p2[o].y = img2[gi + 1]; }
+                    }
+                }
+            }
             v2f A[2][4], Cc[4];
 #pragma unroll
             for (int o = 0; o < 4; o++) A[0][o] = A[1][o] = Cc[o] = (v2f){ 0.0f, 0.0f };
@@ -476,22 +498,19 @@ __global__ __launch_bounds__(NT) void k_ssim_bwd(int H, int W, int S, const floa
                     }
                 }
             }
-            const int x = x0 + 2 * cx;
 #pragma unroll
             for (int o = 0; o < 4; o++) {
                 const int y = y0 + 4 * rg + o;
                 if (y < H && x < W) {
                     const size_t gi = plane + (size_t)y * W + x;
+                    v2f o2;
+                    o2.x = (A[0][o].x + p1[o].x * 2.0f * A[0][o].y) + p2[o].x * Cc[o].x;
+                    o2.y = (A[1][o].x + p1[o].y * 2.0f * A[1][o].y) + p2[o].y * Cc[o].y;
                     if (VEC) {
-                        const v2f p1 = *reinterpret_cast<const v2f*>(img1 + gi);
-                        const v2f p2 = *reinterpret_cast<const v2f*>(img2 + gi);
-                        v2f o2;
-                        o2.x = (A[0][o].x + p1.x * 2.0f * A[0][o].y) + p2.x * Cc[o].x;
-                        o2.y = (A[1][o].x + p1.y * 2.0f * A[1][o].y) + p2.y * Cc[o].y;
                         *reinterpret_cast<v2f*>(dL_dimg1 + gi) = o2;
                     } else {
-                        dL_dimg1[gi] = (A[0][o].x + img1[gi] * 2.0f * A[0][o].y) + img2[gi] * Cc[o].x;
-                        if (x + 1 < W) dL_dimg1[gi + 1] = (A[1][o].x + img1[gi + 1] * 2.0f * A[1][o].y) + img2[gi + 1] * Cc[o].y;
+                        dL_dimg1[gi] = o2.x;
+                        if (x + 1 < W) dL_dimg1[gi + 1] = o2.y;
                     }
                 }
             }
