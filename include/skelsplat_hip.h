@@ -125,9 +125,18 @@ int sks_masked_l2(int V, size_t n_per_view, const float* render, const float* gt
  *   out[y][x] = (row[y] * col[x] - cmin) / den
  * with row = 255 * (1-D impulse response along y), col = the one along x, cmin = min(row) * min(col) and
  * den = max(row) * max(col) - cmin + 1e-8 (all fp32, in this order).  One pass, one write of (V,J,H,W).
- * row (V,J,H), col (V,J,W), cmin (V,J), den (V,J), out (V,J,H,W). */
+ * row (V,J,H), col (V,J,W), cmin (V,J), den (V,J), out (V,J,H,W).  gt_totals (optional, V x 2 fp64): per view the sum of
+ * out^2 and the count of out > 0 over all J planes -- what sks_gt_tile_stats would compute by reading the planes back. */
 int sks_heatmaps(int V, int J, int W, int H, const float* row, const float* col, const float* cmin, const float* den,
-                 float* out, void* stream);
+                 float* out, double* gt_totals, void* stream);
+/* The factors themselves, one launch (general_utils.py:189-289): lambda1/lambda2 of each joint's Gaussian in each view
+ * by the reference's own transcription of the EWA projection, the scipy-'reflect' truncated (4 sigma) 1-D responses of
+ * the 255 impulse at the truncated 2D detection, and the min-max constants.  means3D (J,3), scales (J,3) activated,
+ * rotations (J,4) raw quaternions, poses_2d (V,J,2) pixel (x, y), viewmatrix (V,16) as for sks_forward,
+ * tanfovx/tanfovy HOST arrays of V. */
+int sks_heatmap_factors(int V, int J, int W, int H, const float* means3D, const float* scales, const float* rotations,
+                        float scale_modifier, const float* poses_2d, const float* viewmatrix, const float* tanfovx,
+                        const float* tanfovy, float* row, float* col, float* cmin, float* den, void* stream);
 
 /* Replaces fusedssim (submodules/fused-ssim/ssim.cu:368-404, binding ext.cpp): img1, img2, ssim_map and the three
  * optional partial-derivative maps (train == true) are (B,CH,H,W) fp32; "same" zero padding. */

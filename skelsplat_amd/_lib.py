@@ -42,7 +42,8 @@ SIGNATURES = {
     "sks_knn3_meandist2": (_i, [_i, _vp, _vp, _vp]),
     "sks_knn3_scratch_bytes": (_sz, [_i]),
     "sks_knn3_meandist2_grid": (_i, [_i, _vp, _vp, _vp, _sz, _vp]),
-    "sks_heatmaps": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sks_heatmaps": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sks_heatmap_factors": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sks_gt_tile_stats": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "sks_geometry": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _u, _vp, _vp, _vp]),
     "sks_backward_fused_loss": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _u,

@@ -282,30 +282,177 @@ namespace {
 // ------------------------------------------------------------------------------------------------------------
 typedef float hm_v4f __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void k_heatmaps(int W, int H, const float* __restrict__ row, const float* __restrict__ col,
+// TOTALS: also accumulates, per view, the sum of out^2 and the count of out > 0 (what sks_gt_tile_stats would read back
+// from the planes: the masked-L2 loss of an all-zero render), so a frame's heat-maps are written and never re-read.
+template <bool TOTALS>
+__global__ __launch_bounds__(256) void k_heatmaps(int W, int H, int J, const float* __restrict__ row, const float* __restrict__ col,
                                                    const float* __restrict__ cmin, const float* __restrict__ den,
-                                                   float* __restrict__ out)
+                                                   float* __restrict__ out, double* __restrict__ totals)
 {
+    __shared__ double s_t[2][4];
     const int vj = blockIdx.z, y0 = blockIdx.y * 16, x = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (x >= W) return;
-    const float lo = cmin[vj], d = den[vj];
-    const float* r = row + (size_t)vj * H;
-    const float* c = col + (size_t)vj * W + x;
-    float* o = out + (size_t)vj * H * W + x;
-    const int rows = min(16, H - y0);
-    if ((W & 3) == 0) {
-        const float4 k = *reinterpret_cast<const float4*>(c);
-        for (int i = 0; i < rows; i++) {
-            const float a = r[y0 + i];
-            hm_v4f v = { (a * k.x - lo) / d, (a * k.y - lo) / d, (a * k.z - lo) / d, (a * k.w - lo) / d };
-            __builtin_nontemporal_store(v, reinterpret_cast<hm_v4f*>(o + (size_t)(y0 + i) * W));
+    float S = 0.0f, N = 0.0f;
+    if (x < W) {
+        const float lo = cmin[vj], d = den[vj];
+        const float* r = row + (size_t)vj * H;
+        const float* c = col + (size_t)vj * W + x;
+        float* o = out + (size_t)vj * H * W + x;
+        const int rows = min(16, H - y0);
+        if ((W & 3) == 0) {
+            const float4 k = *reinterpret_cast<const float4*>(c);
+            for (int i = 0; i < rows; i++) {
+                const float a = r[y0 + i];
+                hm_v4f v = { (a * k.x - lo) / d, (a * k.y - lo) / d, (a * k.z - lo) / d, (a * k.w - lo) / d };
+                __builtin_nontemporal_store(v, reinterpret_cast<hm_v4f*>(o + (size_t)(y0 + i) * W));
+                if (TOTALS) {
+                    S += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                    N += ((v.x > 0.0f ? 1.0f : 0.0f) + (v.y > 0.0f ? 1.0f : 0.0f)) + ((v.z > 0.0f ? 1.0f : 0.0f) + (v.w > 0.0f ? 1.0f : 0.0f));
+                }
+            }
+        } else {
+            const int n = min(4, W - x);
+            for (int i = 0; i < rows; i++) {
+                const float a = r[y0 + i];
+                for (int k = 0; k < n; k++) {
+                    const float v = (a * c[k] - lo) / d;
+                    o[(size_t)(y0 + i) * W + k] = v;
+                    if (TOTALS) { S += v * v; N += v > 0.0f ? 1.0f : 0.0f; }
+                }
+            }
         }
-    } else {
-        const int n = min(4, W - x);
-        for (int i = 0; i < rows; i++) {
-            const float a = r[y0 + i];
-            for (int k = 0; k < n; k++) o[(size_t)(y0 + i) * W + k] = (a * c[k] - lo) / d;
+    }
+    if (TOTALS) {   // <= 64 pixels per thread: S, N exact enough in fp32; across threads in fp64
+        const double tS = wave_sum_d((double)S), tN = wave_sum_d((double)N);
+        if ((threadIdx.x & 63) == 0) { s_t[0][threadIdx.x >> 6] = tS; s_t[1][threadIdx.x >> 6] = tN; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int v = vj / J;
+            atomicAdd(&totals[2 * v], (s_t[0][0] + s_t[0][1]) + (s_t[0][2] + s_t[0][3]));
+            atomicAdd(&totals[2 * v + 1], (s_t[1][0] + s_t[1][1]) + (s_t[1][2] + s_t[1][3]));
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// heat-map factors: the 1-D impulse responses `row`, `col` and the min-max constants of every (view, joint) plane,
+// one workgroup per plane (utils/general_utils.py:175-304; the arithmetic is skelsplat_amd/heatmaps.py's
+// ewa_lambdas_views + _impulse_response_1d + heatmap_factors, operation for operation: fp32 up to sqrt(lambda), fp64 for
+// the responses).  Note the reference's operand order (R J)^T Sigma^T (R J) -- see heatmaps.py.
+// ------------------------------------------------------------------------------------------------------------
+struct HmTan {
+    float x[SKS_MAX_VIEWS], y[SKS_MAX_VIEWS];
+};
+
+__device__ __forceinline__ double block_sum_d(double v, double* s_red)
+{
+    v = wave_sum_d(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+
+// scipy.ndimage.gaussian_filter1d of a unit impulse at integer p on an axis of n samples, mode='reflect', truncate=4:
+// writes scale * response (fp32) and returns this thread's (min, max) of what it wrote
+__device__ __forceinline__ void impulse_response(int n, int p, float sigma_f, float scale, float* __restrict__ out,
+                                                 double* s_red, float& vmin, float& vmax)
+{
+    const double sig = (double)sigma_f, ss = sig * sig;
+    const double radius = floor(4.0 * sig + 0.5);
+    double part = 0.0;   // kernel normalisation: sum over |j| <= radius of exp(-0.5 j^2 / sigma^2)
+    for (long long j = 1 + threadIdx.x; (double)j <= radius; j += 256) {
+        const double jj = (double)j;
+        part += exp(-0.5 * jj * jj / ss);
+    }
+    const double norm = 1.0 + 2.0 * block_sum_d(part, s_red);
+    const double src[3] = { (double)p, -1.0 - (double)p, 2.0 * n - 1.0 - (double)p };   // the impulse and its mirrors
+    vmin = FLT_MAX;
+    vmax = -FLT_MAX;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        double acc = 0.0;
+#pragma unroll
+        for (int m = 0; m < 3; m++) {
+            const double d = (double)i - src[m];
+            if (fabs(d) <= radius) acc += exp(-0.5 * d * d / ss);
+        }
+        const float v = scale * (float)(acc / norm);
+        out[i] = v;
+        vmin = fminf(vmin, v);
+        vmax = fmaxf(vmax, v);
+    }
+}
+
+__device__ __forceinline__ float block_minmax(float v, bool want_max, float* s_red)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float o = __shfl_xor(v, off);
+        v = want_max ? fmaxf(v, o) : fminf(v, o);
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return want_max ? fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]))
+                    : fminf(fminf(s_red[0], s_red[1]), fminf(s_red[2], s_red[3]));
+}
+
+__global__ __launch_bounds__(256) void k_heatmap_factors(int J, int W, int H, const float* __restrict__ means,
+                                                          const float* __restrict__ scales, const float* __restrict__ rots,
+                                                          float scale_modifier, const float* __restrict__ poses_2d,
+                                                          const float* __restrict__ viewmatrix, HmTan tan,
+                                                          float* __restrict__ row, float* __restrict__ col,
+                                                          float* __restrict__ cmin, float* __restrict__ den)
+{
+    __shared__ double s_red[4];
+    __shared__ float s_redf[4];
+    const int j = blockIdx.x, v = blockIdx.y, vj = v * J + j;
+    // ---- lambda1, lambda2 (every thread the same scalars) ----
+    const float q0 = rots[4 * j], q1 = rots[4 * j + 1], q2 = rots[4 * j + 2], q3 = rots[4 * j + 3];
+    const float qn = sqrtf(((q0 * q0 + q1 * q1) + q2 * q2) + q3 * q3);
+    const float r = q0 / qn, x = q1 / qn, y = q2 / qn, z = q3 / qn;
+    const float R[3][3] = { { 1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y) },
+                            { 2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x) },
+                            { 2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y) } };
+    float L[3][3], Sg[3][3];
+    for (int a = 0; a < 3; a++)
+        for (int k = 0; k < 3; k++) L[a][k] = R[a][k] * (scale_modifier * scales[3 * j + k]);
+    for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++) Sg[a][b] = (L[a][0] * L[b][0] + L[a][1] * L[b][1]) + L[a][2] * L[b][2];
+    const float* vm = viewmatrix + 16 * v;   // world_view_transform as stored (the matrix transposed): M[i][k] = vm[4k + i]
+    const float px = means[3 * j], py = means[3 * j + 1], pz = means[3 * j + 2];
+    float t[3];
+    for (int i = 0; i < 3; i++) t[i] = ((vm[i] * px + vm[4 + i] * py) + vm[8 + i] * pz) + vm[12 + i] * 1.0f;
+    const float tanx = tan.x[v], tany = tan.y[v];
+    const float fx = (float)W / (2.0f * tanx), fy = (float)H / (2.0f * tany);
+    const float tz = t[2];
+    const float tx = fminf(fmaxf(t[0] / tz, -1.3f * tanx), 1.3f * tanx) * tz;
+    const float ty = fminf(fmaxf(t[1] / tz, -1.3f * tany), 1.3f * tany) * tz;
+    const float Jm[3][3] = { { fx / tz, 0.0f, -(fx * tx) / (tz * tz) }, { 0.0f, fy / tz, -(fy * ty) / (tz * tz) }, { 0.0f, 0.0f, 0.0f } };
+    float T[3][3], A[3][3], cov[2][2];
+    for (int a = 0; a < 3; a++)
+        for (int c = 0; c < 3; c++) T[a][c] = (vm[a] * Jm[0][c] + vm[4 + a] * Jm[1][c]) + vm[8 + a] * Jm[2][c];
+    for (int a = 0; a < 3; a++)      // A = T^T Sigma^T
+        for (int b = 0; b < 3; b++) A[a][b] = (T[0][a] * Sg[b][0] + T[1][a] * Sg[b][1]) + T[2][a] * Sg[b][2];
+    for (int a = 0; a < 2; a++)      // cov = A T
+        for (int c = 0; c < 2; c++) cov[a][c] = (A[a][0] * T[0][c] + A[a][1] * T[1][c]) + A[a][2] * T[2][c];
+    const float cx = cov[0][0] + 0.3f, cy = cov[0][1], cz = cov[1][1] + 0.3f;
+    const float det = cx * cz - cy * cy;
+    const float mid = 0.5f * (cx + cz);
+    const float root = sqrtf(fmaxf(mid * mid - det, 0.1f));
+    const float l1 = mid + root, l2 = mid - root;
+    // ---- responses: sigma1 filters rows (axis 0), sigma2 columns; the impulse sits at the truncated 2D detection ----
+    const int xs = min(max((int)poses_2d[2 * vj], 0), W - 1), ys = min(max((int)poses_2d[2 * vj + 1], 0), H - 1);
+    float rmin, rmax, kmin, kmax;
+    impulse_response(H, ys, sqrtf(l1), 255.0f, row + (size_t)vj * H, s_red, rmin, rmax);
+    impulse_response(W, xs, sqrtf(l2), 1.0f, col + (size_t)vj * W, s_red, kmin, kmax);
+    rmin = block_minmax(rmin, false, s_redf);
+    rmax = block_minmax(rmax, true, s_redf);
+    kmin = block_minmax(kmin, false, s_redf);
+    kmax = block_minmax(kmax, true, s_redf);
+    if (threadIdx.x == 0) {
+        const float lo = rmin * kmin, hi = rmax * kmax;
+        cmin[vj] = lo;
+        den[vj] = (hi - lo) + 1e-8f;
     }
 }
 
@@ -364,12 +511,32 @@ int sks_knn3_meandist2_grid(int P, const float* points, float* mean_dist2, void*
 }
 
 int sks_heatmaps(int V, int J, int W, int H, const float* row, const float* col, const float* cmin, const float* den,
-                 float* out, void* stream)
+                 float* out, double* gt_totals, void* stream)
 {
     if (V < 1 || J < 1 || W < 1 || H < 1 || (long long)V * J > 65535) return fail2(-1, "heatmaps: bad shape");
     if (!row || !col || !cmin || !den || !out) return fail2(-2, "heatmaps: missing pointer");
     dim3 grid((W + 1023) / 1024, (H + 15) / 16, V * J);
-    hipLaunchKernelGGL(k_heatmaps, grid, dim3(256), 0, (hipStream_t)stream, W, H, row, col, cmin, den, out);
+    if (gt_totals) {
+        HIP_TRY2(hipMemsetAsync(gt_totals, 0, (size_t)V * 2 * sizeof(double), (hipStream_t)stream));
+        hipLaunchKernelGGL(k_heatmaps<true>, grid, dim3(256), 0, (hipStream_t)stream, W, H, J, row, col, cmin, den, out, gt_totals);
+    } else {
+        hipLaunchKernelGGL(k_heatmaps<false>, grid, dim3(256), 0, (hipStream_t)stream, W, H, J, row, col, cmin, den, out, nullptr);
+    }
+    HIP_TRY2(hipGetLastError());
+    return 0;
+}
+
+int sks_heatmap_factors(int V, int J, int W, int H, const float* means3D, const float* scales, const float* rotations,
+                        float scale_modifier, const float* poses_2d, const float* viewmatrix, const float* tanfovx,
+                        const float* tanfovy, float* row, float* col, float* cmin, float* den, void* stream)
+{
+    if (V < 1 || V > SKS_MAX_VIEWS || J < 1 || W < 1 || H < 1) return fail2(-1, "heatmap factors: bad shape");
+    if (!means3D || !scales || !rotations || !poses_2d || !viewmatrix || !tanfovx || !tanfovy || !row || !col || !cmin || !den)
+        return fail2(-2, "heatmap factors: missing pointer");
+    HmTan tan;
+    for (int v = 0; v < V; v++) { tan.x[v] = tanfovx[v]; tan.y[v] = tanfovy[v]; }
+    hipLaunchKernelGGL(k_heatmap_factors, dim3(J, V), dim3(256), 0, (hipStream_t)stream, J, W, H, means3D, scales, rotations,
+                       scale_modifier, poses_2d, viewmatrix, tan, row, col, cmin, den);
     HIP_TRY2(hipGetLastError());
     return 0;
 }

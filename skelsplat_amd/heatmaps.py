@@ -90,20 +90,54 @@ def _impulse_response_1d(pos, sigma, n, device):
     return (out / norm).to(torch.float32)
 
 
-def heatmap_factors(means, scaling, rotation_raw, poses_2d, cameras, scaling_modifier=1.0):
+def heatmap_factors(means, scaling, rotation_raw, poses_2d, cameras, scaling_modifier=1.0, views=None):
     """The separable description of the (V, J, H, W) heat-maps: row (V,J,H) = 255 * impulse response along y,
     col (V,J,W) = impulse response along x, cmin (V,J), den (V,J) with
     plane = (row[:, None] * col[None, :] - cmin) / den.
     The plane minimum / maximum are the products of the factor minima / maxima (everything is non-negative and fp32
-    multiplication is monotone), so the min-max normalisation of normalize_heatmaps (:300-304) needs no image pass."""
+    multiplication is monotone), so the min-max normalisation of normalize_heatmaps (:300-304) needs no image pass.
+    On a ROCm device one kernel launch (sks_heatmap_factors, no host synchronisation); on CPU tensors the tensor-op
+    form below, which the kernel restates operation for operation.  `views`: a rasterizer.ViewBatch of `cameras` to
+    reuse (scene streaming), else built here."""
     dev = means.device
     W, H = int(cameras[0].image_width), int(cameras[0].image_height)
-    cov3D = covariance_from_scaling_rotation(scaling, rotation_raw, scaling_modifier)
-    poses_2d = torch.as_tensor(poses_2d, device=dev)
     V = len(cameras)
     for cam in cameras:
         if int(cam.image_width) != W or int(cam.image_height) != H:
             raise ValueError("generate_heatmaps: all cameras must share (W, H)")
+    poses_2d = torch.as_tensor(poses_2d, device=dev)
+    if means.is_cuda:
+        from . import _lib
+        from .rasterizer import ViewBatch, _f32c
+        if views is None:
+            views = ViewBatch.from_cameras(cameras)
+        J = means.shape[0]
+        means, scaling, rotation_raw = _f32c(means, "means"), _f32c(scaling, "scaling"), _f32c(rotation_raw, "rotation")
+        p2d = poses_2d.to(torch.float32).contiguous()
+        if tuple(p2d.shape) != (V, J, 2):
+            raise ValueError(f"poses_2d must be (V, J, 2) = {(V, J, 2)}, got {tuple(p2d.shape)}")
+        row = torch.empty((V, J, H), dtype=torch.float32, device=dev)
+        col = torch.empty((V, J, W), dtype=torch.float32, device=dev)
+        cmin = torch.empty((V, J), dtype=torch.float32, device=dev)
+        den = torch.empty((V, J), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = _lib.load().sks_heatmap_factors(V, J, W, H, means.data_ptr(), scaling.data_ptr(), rotation_raw.data_ptr(),
+                                                 float(scaling_modifier), p2d.data_ptr(), views.viewmatrix.data_ptr(),
+                                                 views.tanfovx, views.tanfovy, row.data_ptr(), col.data_ptr(),
+                                                 cmin.data_ptr(), den.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(rc, "sks_heatmap_factors")
+        return row, col, cmin, den
+    return heatmap_factors_tensor_ops(means, scaling, rotation_raw, poses_2d, cameras, scaling_modifier)
+
+
+def heatmap_factors_tensor_ops(means, scaling, rotation_raw, poses_2d, cameras, scaling_modifier=1.0):
+    """heatmap_factors in plain tensor ops on the tensors' device (the form pinned against the reference's own
+    generate_heatmaps by tests/golden/reference_heatmaps.npz)."""
+    dev = means.device
+    W, H = int(cameras[0].image_width), int(cameras[0].image_height)
+    V = len(cameras)
+    poses_2d = torch.as_tensor(poses_2d, device=dev)
+    cov3D = covariance_from_scaling_rotation(scaling, rotation_raw, scaling_modifier)
     l1, l2 = ewa_lambdas_views(means, cov3D, cameras, W, H)           # (V, J) each
     J = l1.shape[1]
     xs = torch.clamp(poses_2d[:, :, 0].long(), 0, W - 1)              # .long() truncates like the reference (:275-278)
@@ -117,12 +151,15 @@ def heatmap_factors(means, scaling, rotation_raw, poses_2d, cameras, scaling_mod
     return row, col, cmin.contiguous(), den.contiguous()
 
 
-def generate_heatmaps(means, scaling, rotation_raw, poses_2d, cameras, scaling_modifier=1.0, out=None):
+def generate_heatmaps(means, scaling, rotation_raw, poses_2d, cameras, scaling_modifier=1.0, out=None, views=None,
+                      totals=None):
     """(V, J, H, W) normalised heat-maps; all cameras must share (W, H).  poses_2d: (V, J, 2) pixel (x, y).
-    general_utils.py:175-304 with dropout=False.  On a ROCm device the planes are written by one streaming kernel
-    (sks_heatmaps); on CPU tensors (tests against scipy) by the same formula in tensor ops.  `out`: optional
-    (V,J,H,W) fp32 buffer to write into (scene streaming: same storage for every frame)."""
-    row, col, cmin, den = heatmap_factors(means, scaling, rotation_raw, poses_2d, cameras, scaling_modifier)
+    general_utils.py:175-304 with dropout=False.  On a ROCm device two launches (sks_heatmap_factors, then the planes
+    by the streaming kernel sks_heatmaps); on CPU tensors (tests against scipy / the reference) the same formula in
+    tensor ops.  `out`: optional (V,J,H,W) fp32 buffer to write into (scene streaming: same storage for every frame);
+    `totals`: optional (V,2) fp64 tensor that receives each view's {sum gt^2, count gt > 0} (rasterizer.GtStats.totals)
+    while the planes are written, instead of a separate pass over them."""
+    row, col, cmin, den = heatmap_factors(means, scaling, rotation_raw, poses_2d, cameras, scaling_modifier, views=views)
     V, J, H = row.shape
     W = col.shape[2]
     if row.is_cuda:
@@ -131,13 +168,20 @@ def generate_heatmaps(means, scaling, rotation_raw, poses_2d, cameras, scaling_m
             out = torch.empty((V, J, H, W), dtype=torch.float32, device=row.device)
         elif out.shape != (V, J, H, W) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != row.device:
             raise ValueError("generate_heatmaps: `out` must be a contiguous fp32 (V,J,H,W) tensor on the parameters' device")
+        if totals is not None and (totals.shape != (V, 2) or totals.dtype != torch.float64 or not totals.is_contiguous()
+                                   or totals.device != row.device):
+            raise ValueError("generate_heatmaps: `totals` must be a contiguous fp64 (V,2) tensor on the parameters' device")
         with torch.cuda.device(row.device):
             rc = _lib.load().sks_heatmaps(V, J, W, H, row.data_ptr(), col.data_ptr(), cmin.data_ptr(), den.data_ptr(),
-                                          out.data_ptr(), torch.cuda.current_stream(row.device).cuda_stream)
+                                          out.data_ptr(), _lib.ptr(totals), torch.cuda.current_stream(row.device).cuda_stream)
         _lib.check(rc, "sks_heatmaps")
         return out
     res = (row[:, :, :, None] * col[:, :, None, :] - cmin[:, :, None, None]) / den[:, :, None, None]
     if out is not None:
         out.copy_(res)
-        return out
-    return res
+    else:
+        out = res
+    if totals is not None:
+        totals[:, 0] = (out.double() ** 2).sum(dim=(1, 2, 3))
+        totals[:, 1] = (out > 0).double().sum(dim=(1, 2, 3))
+    return out

@@ -187,8 +187,13 @@ class MultiViewLoop:
                         gt[i].copy_(heatmaps[v])
                 elif poses_2d is not None:
                     p2d = torch.as_tensor(poses_2d, device=self.device)[ids]
+                    # the planes and (when the sparse path wants them) their per-view totals in one pass
+                    fused = stats is not None and stats.tile_S is None
                     generate_heatmaps(gm._xyz.detach(), gm.get_scaling.detach(), gm._rotation.detach(), p2d,
-                                      [self.cameras[v] for v in ids], out=gt)
+                                      [self.cameras[v] for v in ids], out=gt, views=vb,
+                                      totals=stats.totals if fused else None)
+                    if fused:
+                        continue
                 else:
                     raise ValueError("new_scene needs poses_2d or heatmaps")
                 if stats is not None:

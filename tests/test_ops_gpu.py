@@ -353,6 +353,37 @@ def test_heatmap_kernel_equals_formula(device, W, H):
     assert float(out.max()) <= 1.0 and float(out.min()) >= 0.0
 
 
+@pytest.mark.parametrize("ds,V,W,H", [("h36m", 3, 200, 160), ("panoptic", 5, 330, 177), ("h36m", 2, 1000, 1000)],
+                         ids=["200x160", "330x177", "1000x1000"])
+def test_heatmap_factor_kernel_equals_tensor_ops(device, ds, V, W, H):
+    """sks_heatmap_factors against the tensor-op form (the one pinned to the reference's own generate_heatmaps by the
+    CPU suite), with rotated, anisotropic Gaussians so that the (R J)^T Sigma^T (R J) operand order matters."""
+    from skelsplat_amd.scene import SyntheticScene, GaussianModel
+    from skelsplat_amd import heatmaps as hmod
+    from skelsplat_amd import rasterizer as R
+    sc = SyntheticScene(ds, n_views=V, seed=7, W=W, H=H, device=device)
+    gm = GaussianModel().create_from_points(sc.pose_3d_init, sc.spatial_lr_scale, sc.n_joints, scene_type=ds, device=device)
+    g = torch.Generator().manual_seed(3)
+    J = sc.n_joints
+    scaling = (gm.get_scaling.detach() * (0.5 + torch.rand((J, 3), generator=g).to(device))).contiguous()
+    rot = torch.randn((J, 4), generator=g).to(device)
+    p2d = torch.tensor(sc.poses_2d, device=device)
+    p2d[0, 0] = torch.tensor([-7.5, 3.2])            # clamped to the image like the reference's impulse position
+    p2d[-1, -1] = torch.tensor([W + 20.0, H - 0.5])
+    args = (gm._xyz.detach(), scaling, rot, p2d, sc.cameras)
+    row, col, cmin, den = hmod.heatmap_factors(*args, scaling_modifier=1.3)
+    row_t, col_t, cmin_t, den_t = hmod.heatmap_factors_tensor_ops(*args, scaling_modifier=1.3)
+    for name, a, b in (("row", row, row_t), ("col", col, col_t), ("cmin", cmin, cmin_t), ("den", den, den_t)):
+        util.assert_close(name, a.cpu(), b.cpu(), rtol=2e-5, atol_scale=1e-6)
+    # the planes and their per-view totals in one pass == planes, then sks_gt_tile_stats over them
+    totals = torch.empty((V, 2), dtype=torch.float64, device=device)
+    out = hmod.generate_heatmaps(*args, scaling_modifier=1.3, totals=totals)
+    assert torch.equal(out, hmod.generate_heatmaps(*args, scaling_modifier=1.3))
+    st = R.gt_tile_stats(out)
+    assert torch.equal(totals[:, 1], st.totals[:, 1])
+    torch.testing.assert_close(totals[:, 0], st.totals[:, 0], rtol=1e-6, atol=0)
+
+
 @pytest.mark.parametrize("sparse", [True, False], ids=["sparse", "dense"])
 def test_scene_streaming_reuses_graphs(device, sparse):
     """MultiViewLoop.new_scene re-initialises parameters, optimiser state, heat-maps and tile statistics in place, so a
