@@ -229,6 +229,40 @@ def main():
         except Exception as e:
             extras["loop_error"] = repr(e)[:200]
 
+        try:
+            # the reference's own iteration (train.py:130-161) with the modules swapped and nothing else changed:
+            # render() of ONE view through the drop-in gaussian_renderer, masked-L2 in tensor ops, autograd backward
+            import types
+            from gaussian_renderer import render_functions
+            from skelsplat_amd.loop import l2_loss_gaussian
+            render = render_functions["diff-gaussian-rasterization-" + wl["dataset"]]
+            pipe = types.SimpleNamespace(debug=False, antialiasing=False, compute_cov3D_python=False, convert_SHs_python=False)
+            bgc = torch.zeros(3, device=dev)
+            gm2 = GaussianModel().create_from_points(ref_scene.pose_3d_init, scene.spatial_lr_scale, scene.n_joints,
+                                                     scene_type=wl["dataset"], device=dev)
+            gm2.training_setup()
+
+            def dropin_iteration(i):
+                cam = scene.cameras[i % V]
+                pkg = render(cam, gm2, pipe, bgc)
+                loss, _ = l2_loss_gaussian(pkg["render"], hm[i % V])   # (loss, error image) like loss_utils.py:100
+                loss.backward()
+                if (i + 1) % V == 0:
+                    gm2.optimizer.step()
+                    gm2.optimizer.zero_grad(set_to_none=True)
+
+            for i in range(2 * V):
+                dropin_iteration(i)
+            torch.cuda.synchronize()
+            td = time.perf_counter()
+            nd = max(2 * V, args.steps // 4)
+            for i in range(nd):
+                dropin_iteration(i)
+            torch.cuda.synchronize()
+            extras["dropin_iteration_ms"] = 1e3 * (time.perf_counter() - td) / nd
+        except Exception as e:
+            extras["dropin_error"] = repr(e)[:200]
+
     if rank == 0:
         views_total = V * world * args.steps
         res = {
