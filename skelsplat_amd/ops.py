@@ -37,6 +37,39 @@ def masked_l2_grad_fused(render, gt):
     return dL, (S / n).to(torch.float32), (1.0 / n).to(torch.float32)
 
 
+class _FusedL2LossGaussian(torch.autograd.Function):
+    """loss = mean (or sum) of (rendering - gt)^2 over {gt > 0 or rendering > 0}; one fused pass forward (sks_masked_l2:
+    read both images, write 2 (r - g) on the mask, S and N in fp64), one scaled copy backward; no host sync."""
+
+    @staticmethod
+    def forward(ctx, rendering, gt, mean):
+        r, g = _chk(rendering, "rendering"), _chk(gt, "gt_heatmap")
+        if r.shape != g.shape:
+            raise RuntimeError(f"rendering {tuple(r.shape)} and gt_heatmap {tuple(g.shape)} differ")
+        dL, S, N = masked_l2(r.reshape(1, -1), g.reshape(1, -1))
+        scale = (1.0 / N) if mean else torch.ones_like(N)       # N == 0 -> inf * 0 = nan, like the mean of nothing
+        ctx.save_for_backward(dL, scale.to(torch.float32))
+        ctx.shape = rendering.shape
+        return (S * scale).to(torch.float32).reshape(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        dL, scale = ctx.saved_tensors
+        return (dL * (gout.to(torch.float32) * scale)).reshape(ctx.shape), None, None
+
+
+def l2_loss_gaussian(rendering, gt_heatmap, gt_2d=None, lambda_loss=1.0, reduction="mean"):
+    """Fused drop-in for the reference's criterion `l2_loss_gaussian` (utils/loss_utils.py:86-100; selected through
+    `losses[training.loss_function]`, train.py:61,150): same arguments, same `(loss, error)` return for 'mean', where
+    the dense `error` image -- which train.py never reads -- is None."""
+    if reduction == "mean":
+        return _FusedL2LossGaussian.apply(rendering, gt_heatmap, True), None
+    if reduction == "sum":
+        return _FusedL2LossGaussian.apply(rendering, gt_heatmap, False)
+    mask = (gt_heatmap > 0) | (rendering > 0)            # 'none': the gathered vector, as tensor ops on the device
+    return ((rendering - gt_heatmap) ** 2)[mask]
+
+
 class FusedSSIMMap(torch.autograd.Function):
     """submodules/fused-ssim/fused_ssim/__init__.py:8-32."""
 

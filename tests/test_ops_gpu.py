@@ -123,6 +123,33 @@ def test_masked_l2_matches_reference_semantics(device, shape):
         util.assert_close("dL", (dL[v].double().cpu() / N[v].item()), r.grad, rtol=1e-5, atol_scale=1e-6)
 
 
+@pytest.mark.parametrize("reduction", ["mean", "sum", "none"])
+def test_fused_l2_loss_gaussian_criterion(device, reduction):
+    """The fused criterion a user registers in train.py's `losses` table equals utils/loss_utils.py:86-100 (restated in
+    skelsplat_amd.loop.l2_loss_gaussian, which the CPU suite pins to the reference's own function), value and gradient."""
+    from skelsplat_amd.ops import l2_loss_gaussian as fused
+    g = torch.Generator().manual_seed(2)
+    shape = (17, 90, 131)
+    r0 = (torch.rand(shape, generator=g) * (torch.rand(shape, generator=g) > 0.7)).to(device)
+    gt = (torch.rand(shape, generator=g) * (torch.rand(shape, generator=g) > 0.6)).to(device)
+    r = r0.clone().requires_grad_(True)
+    out = fused(r, gt, None, 1.0, reduction=reduction)
+    rr = r0.double().cpu().requires_grad_(True)
+    t = gt.double().cpu()
+    mask = (t > 0) | (rr > 0)
+    err = ((rr - t) ** 2)[mask]
+    if reduction == "none":
+        util.assert_close("loss vector", out.detach().cpu(), err.detach(), rtol=1e-6, atol_scale=1e-7)
+        return
+    loss = out[0] if reduction == "mean" else out
+    assert reduction == "sum" or out[1] is None
+    want = err.mean() if reduction == "mean" else err.sum()
+    (3.0 * loss).backward()
+    (3.0 * want).backward()
+    assert abs(loss.item() - want.item()) <= 1e-6 * abs(want.item())
+    util.assert_close("grad", r.grad.cpu(), rr.grad, rtol=1e-5, atol_scale=1e-6)
+
+
 def _make_loop_scene(dev, W=160, H=128, V=4, seed=3):
     from skelsplat_amd.scene import SyntheticScene, GaussianModel
     from skelsplat_amd.heatmaps import generate_heatmaps

@@ -63,5 +63,12 @@ for wl, tag in (("h36m", ""), ("panoptic", "_panoptic"), ("stress", "_stress")):
     if fwd:
         entry["fwd_bytes_per_launch"] = ks[fwd[0]]["hbm_bytes_per_launch"]
     traffic[NAMES[wl]] = entry
+    # bench.py read the traffic.json committed BEFORE this run; the copied bench line gets this run's own PMC figure
+    bj = os.path.join(DST, f"{rnd}_bench{tag}.json")
+    if fwd and os.path.exists(bj):
+        line = json.load(open(bj))
+        if "roofline" in line:
+            line["roofline"]["traffic"] = entry["fwd_bytes_per_launch"]
+            json.dump(line, open(bj, "w"))
 json.dump(traffic, open(os.path.join(DST, "traffic.json"), "w"), indent=1)
 print(open(os.path.join(DST, "traffic.json")).read()[:3000])
