@@ -127,7 +127,10 @@ template <int CG>
 void launch_bwd_small(const BwdArgs& a, int V, int gy, bool dfeat, hipStream_t st)
 {
     (void)gy;
-    dim3 grid(BWD_SPLITS, a.P, V);
+    // slot index slowest: a (view, Gaussian) only has work for its first ceil(pixels / 256) slots, so the idle workgroups
+    // (half of them on the skeleton scenes) come last in dispatch order instead of holding wave slots the working ones
+    // wait for (the fused-loss kernel fits 3 workgroups per CU: 768 of H36M's 1 088 at once)
+    dim3 grid(a.P, V, BWD_SPLITS);
     if (a.P <= 64 && !(a.flags & (1u << 20))) {  // wave-resident variant (bit 20: force the LDS variant, tests)
         if (dfeat) hipLaunchKernelGGL((k_render_bwd_wave<CG, true, false>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((k_render_bwd_wave<CG, false, false>), grid, dim3(256), 0, st, a);
@@ -321,7 +324,7 @@ int sks_backward_fused_loss(int V, int P, int C, int W, int H, const float* view
     for (int v = 0; v < V; v++) { vt.x[v] = tanfovx[v]; vt.y[v] = tanfovy[v]; }
     Geom g = geom_from(const_cast<void*>(geom), V, P, W, H);
     BwdArgs a{ P, C, W, H, flags | SKS_CLAMP01, g, features, bg, gt, nullptr, (float*)accum, tile_S, tile_N };
-    dim3 grid(BWD_SPLITS, P, V);
+    dim3 grid(P, V, BWD_SPLITS);   // see launch_bwd_small
     {
         ProfScope prof(1, st);
         switch (pick_cg(C)) {
@@ -385,7 +388,7 @@ int sks_loop_fused_step(int V, int P, int C, int W, int H, const float* viewmatr
     Geom g = geom_from(geom, V, P, W, H);
     g.cover = nullptr;   // no forward render on this path
     BwdArgs a{ P, C, W, H, flags, g, features, nullptr, gt, nullptr, (float*)accum, nullptr, nullptr };
-    dim3 grid(BWD_SPLITS, P, V);
+    dim3 grid(P, V, BWD_SPLITS);   // see launch_bwd_small
     {
         ProfScope prof(1, st);
         switch (pick_cg(C)) {
