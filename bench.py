@@ -78,6 +78,12 @@ def main():
                     "launches would mix into per-kernel averages of a rocprofv3 run)")
     args = ap.parse_args()
 
+    # Native libraries write to the process's stdout too (RCCL prints a version banner from C stdio, flushed at exit, i.e.
+    # AFTER the result line): fd 1 is pointed at stderr for the whole run and the one JSON line goes to the real stdout.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from skelsplat_amd import _lib
@@ -306,7 +312,7 @@ def main():
         res.update(extras)
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(ref_scene, params, n_views=2)
-        print(json.dumps(res))
+        os.write(real_stdout, (json.dumps(res) + "\n").encode())
     if use_dist:
         dist.destroy_process_group()
 
