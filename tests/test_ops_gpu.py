@@ -286,6 +286,34 @@ def test_sparse_loop_equals_dense_loop(device):
     util.assert_close("scaling", outs[0][1], outs[1][1], rtol=1e-4, atol_scale=1e-4)
 
 
+def test_full_scene_converges_to_the_reference_mpjpe(device):
+    """North-star parity bar: a whole scene (500 iterations, the LR schedule of configs/h36m.yaml) through the production
+    path (sparse fused step, hipGraphs) ends at the same MPJPE as the literal per-iteration reference loop on the
+    PyTorch oracle -- within 0.5 mm (in practice a few hundredths)."""
+    from skelsplat_amd.loop import MultiViewLoop, mpjpe
+    from skelsplat_amd.heatmaps import generate_heatmaps
+    from tests.ref_loop import run_reference_loop
+    import copy
+    sc, model = _make_loop_scene(device, W=112, H=96)   # (the CPU reference loop is what takes the time: ~40 s)
+    gm = model(device)
+    hm = generate_heatmaps(gm._xyz.detach(), gm.get_scaling.detach(), gm._rotation.detach(),
+                           torch.tensor(sc.poses_2d, device=device), sc.cameras)
+    loop = MultiViewLoop(gm, sc.cameras, hm, dataset="h36m", accumulation_steps=4, lambda_consistency=1e-5, use_graph=True)
+    assert loop.sparse and loop.use_graph
+    out = loop.run(500).cpu()
+    cams_cpu = [copy.copy(c).to("cpu") for c in sc.cameras]
+    ref = run_reference_loop(model("cpu"), cams_cpu, hm.cpu(), sc.W, sc.H, "h36m", 500)
+    gt = torch.tensor(sc.pose_3d_gt).float()
+    e0 = mpjpe(torch.tensor(sc.pose_3d_init).float(), gt)
+    e_hip, e_ref = mpjpe(out, gt), mpjpe(ref, gt)
+    moved = (ref - torch.tensor(sc.pose_3d_init).float()).norm(dim=1).mean().item()
+    print(f"MPJPE start {e0:.3f} mm -> HIP {e_hip:.4f} mm, reference loop {e_ref:.4f} mm; max joint distance "
+          f"{(out - ref).norm(dim=1).max().item():.4f} mm; joints moved {moved:.2f} mm on average")
+    assert moved > 1.0, f"the optimisation barely moved the joints ({moved} mm): test is vacuous"
+    assert abs(e_hip - e_ref) < 0.5, f"MPJPE {e_hip:.3f} mm (HIP) vs {e_ref:.3f} mm (reference loop), start {e0:.3f} mm"
+    assert (out - ref).norm(dim=1).max().item() < 0.5
+
+
 def test_loop_with_mixed_image_sizes(device):
     """H36M mixes 1000x1000 and 1002x1000 cameras (quirk Q11): views are grouped by size, one launch sequence per group,
     and the result equals the literal per-iteration reference loop."""
