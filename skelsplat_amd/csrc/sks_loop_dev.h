@@ -87,8 +87,20 @@ __device__ __forceinline__ void adam_block_begin(const AdamArgs& a, float* s_xyz
     }
 }
 
+// s_hyp: step sizes xyz / scaling / rotation / opacity, sqrt(bias_correction2), spare -- from adam_block_begin's s_d
+__device__ __forceinline__ void adam_step_sizes(const AdamArgs& a, const double* s_d, float* s_hyp)
+{
+    const double lr_xyz = s_d[0] * s_d[1];
+    const double bc1 = 1.0 - s_d[2];
+    s_hyp[0] = (float)(lr_xyz / bc1);
+    s_hyp[1] = (float)(a.lr_scaling / bc1);
+    s_hyp[2] = (float)(a.lr_rotation / bc1);
+    s_hyp[3] = (float)(a.lr_opacity / bc1);
+    s_hyp[4] = (float)sqrt(1.0 - s_d[3]);
+}
+
 __device__ __forceinline__ void adam_block_finish(const AdamArgs& a, float* s_xyz, float* s_hyp, double* s_d, int* s_it,
-                                                  const AdamLdsParams* mirror = nullptr)
+                                                  const AdamLdsParams* mirror = nullptr, bool step_sizes_ready = false)
 {
     const int p = threadIdx.x;
     const int P = a.P, V = a.V;
@@ -97,15 +109,7 @@ __device__ __forceinline__ void adam_block_finish(const AdamArgs& a, float* s_xy
     // s_hyp: step sizes xyz / scaling / rotation / opacity, sqrt(bias_correction2), spare.  Thread 0 forms them (a few
     // double divisions and a square root) while everybody else already gathers gradients, slots, moments and parameters:
     // the barrier that publishes s_hyp comes only right before the update, so those loads and the scalar work overlap.
-    if (p == 0) {
-        const double lr_xyz = s_d[0] * s_d[1];
-        const double bc1 = 1.0 - s_d[2];
-        s_hyp[0] = (float)(lr_xyz / bc1);
-        s_hyp[1] = (float)(a.lr_scaling / bc1);
-        s_hyp[2] = (float)(a.lr_rotation / bc1);
-        s_hyp[3] = (float)(a.lr_opacity / bc1);
-        s_hyp[4] = (float)sqrt(1.0 - s_d[3]);
-    }
+    if (p == 0 && !step_sizes_ready) adam_step_sizes(a, s_d, s_hyp);
     // limb-symmetry loss gradient: L = lambda * (| |la| - |ra| | + | |ll| - |rl| |)  (loss_utils.py:226-250);
     // every view's loss contains it, so every slot carries it (train.py:150-152,175)
     float gc[3] = { 0, 0, 0 };
