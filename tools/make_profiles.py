@@ -70,5 +70,9 @@ for wl, tag in (("h36m", ""), ("panoptic", "_panoptic"), ("stress", "_stress")):
         if "roofline" in line:
             line["roofline"]["traffic"] = entry["fwd_bytes_per_launch"]
             json.dump(line, open(bj, "w"))
+for name in ("bench_ssim.txt", "ssim_pmc_fwd.txt", "ssim_pmc_train.txt"):   # fused-SSIM timings and SQ counter passes
+    src = os.path.join(SRC, name)
+    if os.path.exists(src) and os.path.getsize(src):
+        shutil.copy(src, os.path.join(DST, f"{rnd}_{name}"))
 json.dump(traffic, open(os.path.join(DST, "traffic.json"), "w"), indent=1)
 print(open(os.path.join(DST, "traffic.json")).read()[:3000])

@@ -16,6 +16,10 @@ for WL in h36m panoptic; do
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stress_stats" -o stats -- python3 "$ROOT/tools/bench_stress.py" > "$OUT/stress.log" 2>&1
 cd "$ROOT"
+python3 tools/bench_ssim.py > "$OUT/bench_ssim.txt" 2>/dev/null
+bash tools/pmc_ssim.sh fwd 4,17,1000,1000 > "$OUT/ssim_pmc_fwd.txt" 2>&1
+bash tools/pmc_ssim.sh train 4,17,1000,1000 > "$OUT/ssim_pmc_train.txt" 2>&1
+cd "$ROOT"
 python3 bench.py > "$OUT/h36m_bench.json" 2> "$OUT/h36m_bench.log"
 python3 bench.py --workload panoptic --steps 50 --warmup 5 > "$OUT/panoptic_bench.json" 2> "$OUT/panoptic_bench.log"
 find "$OUT" -name "*.csv" | head -40
