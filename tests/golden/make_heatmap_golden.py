@@ -9,7 +9,7 @@ What is adapted so that the unmodified reference function runs without a GPU, fo
   * tensordict.TensorDict -> dict (only item assignment / lookup are used).
 Inputs (a synthetic 17-joint skeleton, 2 cameras, 96x72 images) and the function's outputs are stored; the reference
 itself does not travel.  This fixture is what caught that the reference's 2D covariance is NOT the rasterizer's
-(torch row-major transcription of glm column-major code, see skelsplat_amd/heatmaps.py:ewa_lambdas_views).
+(torch row-major transcription of glm column-major code, see oracle/heatmaps_ref.py:ewa_lambdas_views).
 """
 import os
 import sys

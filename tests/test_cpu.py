@@ -148,10 +148,12 @@ def test_ssim_oracle_matches_reference():
 
 
 def test_heatmaps_match_scipy_gaussian_filter():
-    """generate_heatmaps' closed form == scipy.ndimage.gaussian_filter (CPU twin of the cupy call, general_utils.py:289)
+    """the closed form of the heat-maps (oracle/heatmaps_ref.py, which the HIP kernels are held to on the GPU) ==
+    scipy.ndimage.gaussian_filter (CPU twin of the cupy call, general_utils.py:289)
     of a 255 impulse, then min-max normalised -- including a joint near the image border (reflect mode)."""
     from scipy.ndimage import gaussian_filter
-    from skelsplat_amd import heatmaps, scene
+    from skelsplat_amd import scene
+    from oracle import heatmaps_ref as heatmaps
     sc = scene.SyntheticScene("h36m", n_views=2, seed=4, W=160, H=128, ring=2500.0, fx=1145.0 * 0.16 * 1.5)
     gm = scene.GaussianModel().create_from_points(sc.pose_3d_init, 1.0, 17, scaling=3.9)
     p2d = sc.poses_2d.copy()
@@ -218,6 +220,12 @@ def test_product_refuses_cpu_tensors_and_bad_arguments():
     from skelsplat_amd import ops
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.fused_ssim(torch.rand(1, 1, 16, 16), torch.rand(1, 1, 16, 16))
+    from skelsplat_amd.heatmaps import generate_heatmaps
+    from skelsplat_amd.scene import SyntheticScene, GaussianModel
+    sc = SyntheticScene("h36m", n_views=2, seed=0, W=64, H=48)
+    gm = GaussianModel().create_from_points(sc.pose_3d_init, 1.0, 17)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):   # the tensor-op restatement lives in oracle/, for tests
+        generate_heatmaps(gm._xyz.detach(), gm.get_scaling.detach(), gm._rotation.detach(), torch.tensor(sc.poses_2d), sc.cameras)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.distCUDA2(torch.rand(5, 3))
     pkg = gaussian_renderer.RenderPackage(render=1, radii=torch.tensor([0, 3, 0, 2]))
@@ -262,7 +270,7 @@ def _loop_worker(rank, world, port, iters, ret):
         dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2)
     from skelsplat_amd.loop import MultiViewLoop
-    from skelsplat_amd.heatmaps import generate_heatmaps
+    from oracle.heatmaps_ref import generate_heatmaps
     from skelsplat_amd.scene import SyntheticScene, GaussianModel
     sc = SyntheticScene("h36m", n_views=3, seed=3, W=64, H=48, ring=2500.0, fx=1145.0 * 0.064 * 1.5)
     gm = GaussianModel().create_from_points(sc.pose_3d_init, sc.spatial_lr_scale, 17, scaling=3.9)
@@ -297,7 +305,7 @@ def test_view_sharded_loop_equals_single_process_and_reference():
     assert np.array_equal(w2[1], w1[1]) and np.array_equal(w2[2], w1[2])      # identical summation order -> bit-identical
     # and both equal the per-iteration reference loop (train.py:130-222 restated in tests/ref_loop.py)
     from tests.ref_loop import run_reference_loop
-    from skelsplat_amd.heatmaps import generate_heatmaps
+    from oracle.heatmaps_ref import generate_heatmaps
     from skelsplat_amd.scene import SyntheticScene, GaussianModel
     sc = SyntheticScene("h36m", n_views=3, seed=3, W=64, H=48, ring=2500.0, fx=1145.0 * 0.064 * 1.5)
     gm = GaussianModel().create_from_points(sc.pose_3d_init, sc.spatial_lr_scale, 17, scaling=3.9)
@@ -400,7 +408,7 @@ def test_heatmaps_against_reference_generate_heatmaps_golden():
     (utils/general_utils.py:175-304) run in the build container (tests/golden/make_heatmap_golden.py).  The closed-form
     generator must reproduce it, including the reference's own 2D covariance (which is not the rasterizer's)."""
     import types
-    from skelsplat_amd.heatmaps import generate_heatmaps
+    from oracle.heatmaps_ref import generate_heatmaps
     g = np.load(os.path.join(ROOT, "tests", "golden", "reference_heatmaps.npz"))
     W, H = int(g["W"]), int(g["H"])
     cams = [types.SimpleNamespace(image_width=W, image_height=H, world_view_transform=torch.tensor(g["world_view_transform"][v]),

@@ -411,8 +411,8 @@ def test_heatmap_kernel_equals_formula(device, W, H):
 @pytest.mark.parametrize("ds,V,W,H", [("h36m", 3, 200, 160), ("panoptic", 5, 330, 177), ("h36m", 2, 1000, 1000)],
                          ids=["200x160", "330x177", "1000x1000"])
 def test_heatmap_factor_kernel_equals_tensor_ops(device, ds, V, W, H):
-    """sks_heatmap_factors against the tensor-op form (the one pinned to the reference's own generate_heatmaps by the
-    CPU suite), with rotated, anisotropic Gaussians so that the (R J)^T Sigma^T (R J) operand order matters."""
+    """sks_heatmap_factors against the tensor-op restatement in oracle/ (the one pinned to the reference's own
+    generate_heatmaps by the CPU suite), with rotated, anisotropic Gaussians so that the (R J)^T Sigma^T (R J) operand order matters."""
     from skelsplat_amd.scene import SyntheticScene, GaussianModel
     from skelsplat_amd import heatmaps as hmod
     from skelsplat_amd import rasterizer as R
@@ -427,7 +427,8 @@ def test_heatmap_factor_kernel_equals_tensor_ops(device, ds, V, W, H):
     p2d[-1, -1] = torch.tensor([W + 20.0, H - 0.5])
     args = (gm._xyz.detach(), scaling, rot, p2d, sc.cameras)
     row, col, cmin, den = hmod.heatmap_factors(*args, scaling_modifier=1.3)
-    row_t, col_t, cmin_t, den_t = hmod.heatmap_factors_tensor_ops(*args, scaling_modifier=1.3)
+    from oracle import heatmaps_ref
+    row_t, col_t, cmin_t, den_t = heatmaps_ref.heatmap_factors(*args, scaling_modifier=1.3)
     for name, a, b in (("row", row, row_t), ("col", col, col_t), ("cmin", cmin, cmin_t), ("den", den, den_t)):
         util.assert_close(name, a.cpu(), b.cpu(), rtol=2e-5, atol_scale=1e-6)
     # the planes and their per-view totals in one pass == planes, then sks_gt_tile_stats over them
@@ -437,6 +438,25 @@ def test_heatmap_factor_kernel_equals_tensor_ops(device, ds, V, W, H):
     st = R.gt_tile_stats(out)
     assert torch.equal(totals[:, 1], st.totals[:, 1])
     torch.testing.assert_close(totals[:, 0], st.totals[:, 0], rtol=1e-6, atol=0)
+
+
+def test_heatmap_kernels_reproduce_the_reference_golden(device):
+    """tests/golden/reference_heatmaps.npz is the output of the REFERENCE's own generate_heatmaps + normalize_heatmaps
+    (utils/general_utils.py:175-304, run in the build container by tests/golden/make_heatmap_golden.py): the two HIP
+    kernels reproduce it directly, including the reference's own 2D covariance (which is not the rasterizer's)."""
+    import os
+    import types
+    from skelsplat_amd.heatmaps import generate_heatmaps
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_heatmaps.npz"))
+    W, H = int(g["W"]), int(g["H"])
+    t = lambda a: torch.tensor(a).to(device)
+    cams = [types.SimpleNamespace(image_width=W, image_height=H, world_view_transform=t(g["world_view_transform"][v]),
+                                  full_proj_transform=t(g["world_view_transform"][v]),   # (unused by the heat-maps)
+                                  FoVx=float(g["fov"][v, 0]), FoVy=float(g["fov"][v, 1])) for v in range(2)]
+    hm = generate_heatmaps(t(g["xyz"]), torch.exp(t(g["scaling_raw"])), t(g["rotation_raw"]), t(g["poses_2d"]), cams)
+    want = torch.tensor(g["heatmaps"])
+    assert hm.shape == want.shape
+    assert (hm.cpu() - want).abs().max().item() < 5e-6, (hm.cpu() - want).abs().max().item()
 
 
 @pytest.mark.parametrize("sparse", [True, False], ids=["sparse", "dense"])
