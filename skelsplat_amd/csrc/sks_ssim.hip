@@ -543,10 +543,8 @@ __global__ __launch_bounds__(NT) void k_ssim_bwd(int H, int W, int S, const floa
 // but the chip wants a few thousand workgroups
 int tiles_per_strip(int tiles_x, int tiles_y, int planes)
 {
-    static const long long min_blocks = [] {
-        const char* e = getenv("SKS_SSIM_MIN_BLOCKS");   // tuning switch
-        return e ? atoll(e) : 2048ll;
-    }();
+    const char* e = getenv("SKS_SSIM_MIN_BLOCKS");   // tuning / test switch (read per call: tests force long strips)
+    const long long min_blocks = e ? atoll(e) : 2048ll;
     int S = 8;
     while (S > 1 && (long long)tiles_x * ((tiles_y + S - 1) / S) * planes < min_blocks) S /= 2;
     return S;

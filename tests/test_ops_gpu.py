@@ -81,6 +81,39 @@ def test_fused_ssim_matches_conv2d_ssim(device, shape, padding):
         assert abs(fused_ssim(img1.detach(), img2, padding=padding, train=False).item() - val.item()) <= 1e-7
 
 
+@pytest.mark.parametrize("min_blocks", ["1", "40"], ids=["strips-of-8", "strips-of-2"])
+def test_fused_ssim_long_strips(device, min_blocks, monkeypatch):
+    """The kernels walk strips of tiles down the image and carry 10 filtered rows from tile to tile; small test images
+    would always get one-tile strips (the launch wants >= 2 048 workgroups), so the strip length is forced here."""
+    from fused_ssim import fused_ssim, FusedSSIMMap
+    monkeypatch.setenv("SKS_SSIM_MIN_BLOCKS", min_blocks)
+    g = torch.Generator().manual_seed(4)
+    shape = (2, 3, 300, 136)   # 10 tile rows (the last one partial), 3 tile columns
+    img1 = torch.rand(shape, generator=g).to(device).requires_grad_(True)
+    img2 = torch.rand(shape, generator=g).to(device)
+    m = FusedSSIMMap.apply(0.01 ** 2, 0.03 ** 2, img1, img2, "same", True)
+    wgt = torch.rand(shape, generator=g)
+    (m * wgt.to(device)).sum().backward()
+    ref1 = img1.detach().double().cpu().requires_grad_(True)
+    mr = ssim_torch(ref1, img2.double().cpu())
+    (mr * wgt.double()).sum().backward()
+    util.assert_close("ssim_map", m.detach().cpu(), mr.detach(), rtol=2e-5, atol_scale=5e-6)
+    util.assert_close("dL_dimg1", img1.grad.cpu(), ref1.grad, rtol=1e-3, atol_scale=1e-4)
+    # the mean form (fused sum + scalar-gradient backward), "valid" crop
+    a = img1.detach().clone().requires_grad_(True)
+    val = fused_ssim(a, img2, padding="valid")
+    val.backward()
+    b = img1.detach().double().cpu().requires_grad_(True)
+    want = ssim_torch(b, img2.double().cpu())[:, :, 5:-5, 5:-5].mean()
+    want.backward()
+    assert abs(val.item() - want.item()) <= 2e-5 * abs(want.item())
+    util.assert_close("dL_dimg1 (mean)", a.grad.cpu(), b.grad, rtol=1e-3, atol_scale=1e-4)
+    # and strips of any length give the same bits as one-tile strips
+    monkeypatch.setenv("SKS_SSIM_MIN_BLOCKS", "1000000")
+    m1 = FusedSSIMMap.apply(0.01 ** 2, 0.03 ** 2, img1.detach(), img2, "same", False)
+    assert torch.equal(m1, m.detach())
+
+
 def test_fused_ssim_empty_valid_map_is_nan(device):
     from fused_ssim import fused_ssim
     a = torch.rand(1, 2, 9, 40, device=device)
