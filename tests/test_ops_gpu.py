@@ -114,6 +114,37 @@ def test_fused_ssim_long_strips(device, min_blocks, monkeypatch):
     assert torch.equal(m1, m.detach())
 
 
+def test_fused_ssim_random_shapes(device, monkeypatch):
+    """60 random (B, CH, H, W) including degenerate ones (one row, one column, W % 4 != 0, fewer than 11 rows), both
+    paddings, random strip lengths: map, gradient and the fused mean against conv2d SSIM."""
+    import random
+    from skelsplat_amd import ops
+    rnd = random.Random(1)
+    for _ in range(60):
+        B, CH = rnd.choice([1, 2, 3]), rnd.choice([1, 2, 5])
+        H = rnd.choice([1, 2, 5, 9, 10, 11, 16, 31, 32, 33, 63, 64, 65, 100])
+        W = rnd.choice([1, 2, 3, 4, 7, 8, 12, 16, 60, 63, 64, 65, 68, 128, 132, 200])
+        monkeypatch.setenv("SKS_SSIM_MIN_BLOCKS", rnd.choice(["1", "3", "2048"]))
+        pad = rnd.choice(["same", "valid"])
+        a = torch.rand((B, CH, H, W), device=device, requires_grad=True)
+        b = torch.rand((B, CH, H, W), device=device)
+        m = ops.FusedSSIMMap.apply(1e-4, 9e-4, a, b, pad, True)
+        ref1 = a.detach().double().cpu().requires_grad_(True)
+        mr = ssim_torch(ref1, b.double().cpu())
+        if pad == "valid":
+            mr = mr[:, :, 5:-5, 5:-5]
+        if mr.numel() == 0:
+            assert m.numel() == 0
+            continue
+        w = torch.rand(mr.shape)
+        (m * w.to(device)).sum().backward()
+        (mr * w.double()).sum().backward()
+        tag = f"{(B, CH, H, W)} {pad}"
+        assert (m.detach().cpu().double() - mr.detach()).abs().max().item() < 2e-5, tag
+        assert (a.grad.cpu().double() - ref1.grad).abs().max().item() <= 2e-4 * max(ref1.grad.abs().max().item(), 1e-9), tag
+        assert abs(ops.fused_ssim(a.detach(), b, padding=pad, train=False).item() - mr.mean().item()) < 2e-5, tag
+
+
 def test_fused_ssim_empty_valid_map_is_nan(device):
     from fused_ssim import fused_ssim
     a = torch.rand(1, 2, 9, 40, device=device)
