@@ -143,8 +143,40 @@ __device__ __forceinline__ void adam_block_finish(const AdamArgs& a, float* s_xy
     const int pl = live ? p : 0;
     float* mp = a.m + (size_t)pl * 11;
     float* vp = a.vv + (size_t)pl * 11;
+    // With many views (Panoptic: 31) one thread per joint walking its V slots is a chain of V dependent round trips
+    // (21 us for 31 views): all threads update the (view, joint) slots side by side and park them in LDS, then the
+    // joint's thread adds them up in view order as before (same values, same order: bit-identical).
+    constexpr int SLOT_LDS = 8192;
+    __shared__ float s_gc[256 * 3];
+    __shared__ float s_slot[SLOT_LDS];
+    const bool wide = V > 8 && V * P * 3 <= SLOT_LDS;   // (block-uniform)
+    if (wide) {
+        if (live) { s_gc[3 * p] = gc[0]; s_gc[3 * p + 1] = gc[1]; s_gc[3 * p + 2] = gc[2]; }
+        __syncthreads();
+        for (int i = p; i < V * P; i += (int)blockDim.x) {
+            const int v = i / P, pp = i - v * P;
+            float* sl = a.slots + (size_t)i * 3;
+            float val[3];
+            if ((a.group_mask >> v) & 1ull) {
+                const float* gr = a.grads + (size_t)i * 11;
+#pragma unroll
+                for (int c = 0; c < 3; c++) { val[c] = gr[c] + s_gc[3 * pp + c]; sl[c] = val[c]; }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 3; c++) val[c] = sl[c];
+            }
+#pragma unroll
+            for (int c = 0; c < 3; c++) s_slot[3 * i + c] = val[c];
+        }
+        __syncthreads();
+    }
     if (live) {
         for (int v = 0; v < V; v++) {
+            if (wide) {
+#pragma unroll
+                for (int c = 0; c < 3; c++) g11[c] += s_slot[3 * (v * P + p) + c];
+                continue;
+            }
             float* sl = a.slots + ((size_t)v * P + p) * 3;
             if ((a.group_mask >> v) & 1ull) {
                 const float* gr = a.grads + ((size_t)v * P + p) * 11;
