@@ -313,6 +313,13 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(ref_scene, params, n_views=2)
         os.write(real_stdout, (json.dumps(res) + "\n").encode())
+    # nothing may follow the result line on either stream: what native libraries still hold in their stdio buffers (RCCL's
+    # banner) or print while tearing down goes to /dev/null from here on
+    sys.stdout.flush()
+    sys.stderr.flush()
+    devnull = os.open(os.devnull, os.O_WRONLY)
+    os.dup2(devnull, 1)
+    os.dup2(devnull, 2)
     if use_dist:
         dist.destroy_process_group()
 
