@@ -1,16 +1,25 @@
 #!/usr/bin/env python3
 """bench.py -- rendered+backpropagated views/s of the skeletal-Gaussian rasterizer hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W     (N > 1: one rank per GPU under torch.distributed.run; a plain
+                                                        `python bench.py --gpus N` starts that launcher itself)
 
-A "step" is one accumulation group of the reference loop (train.py:130-222, accumulation_steps = V = 4): the V views
-that share the Gaussian parameters are rendered (forward) and back-propagated (backward) with the upstream
-gradient dL/d(render) already resident in HBM, followed for N > 1 by the exchange of per-view joint gradients
-(all_gather over RCCL) that the view-sharded loop needs.  Work per GPU is fixed (V views) -> weak scaling.
-Workload at N = 1: BASELINE.json configs[1], H36M 17 joints, 4 views @ 1000x1000 (synthetic skeleton + cameras).
+A "step" is one accumulation group of the reference loop (train.py:130-222): the V views that share the Gaussian
+parameters are rendered (forward) and back-propagated (backward) through the C ABI with the upstream gradient
+dL/d(render) already resident in HBM, then the per-view joint gradients are averaged (train.py:215-217).
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (forward compositor): algorithmic bytes per
-launch = 4*H*W*(C+1)*V (dense colour + inverse-depth planes it must write) / its average launch
+N = 1 (default): BASELINE.json configs[1] -- H36M, 17 joints, 4 views @ 1000x1000 (synthetic skeleton + cameras).
+    Extras on the same line: configs[2] (Panoptic 31 views @ 1920x1080), configs[4] (stress, binned path), the real H36M
+    sensor mix (1002- and 1000-wide views in one group), the full loop step (render + masked-L2 + backward + Adam).
+N > 1: BASELINE.json configs[3] -- the SAME 31 Panoptic views split over the ranks (view v -> rank v % N, strong
+    scaling), each rank renders and back-propagates its views, ONE all_gather_into_tensor (RCCL) of the per-view joint
+    gradients per step rebuilds the V slots on every rank.  `value` = 31 views x steps / time; `strong_scaling` holds the
+    same step run by one GPU alone (measured in the same run, all ranks side by side without communication), the speed-up,
+    and the same pair for the loop's dense step and its sparse fused step; frame sharding (every rank its own frames, no
+    communication) is reported as frames/s.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (forward fill + compositor): algorithmic bytes per
+launch = 4*H*W*(C+1)*V_local (the dense colour + inverse-depth planes it must write) / its average launch
 duration measured with hipEvents on the launch stream.  `cpu_baseline` times the pure-PyTorch restatement
 (oracle/torch_ref.py) on the host cores for a bounded sample of the same workload.
 """
@@ -29,6 +38,17 @@ WORKLOADS = {
     "h36m": dict(dataset="h36m", V=4, name="h36m_4view_1000x1000_P17_C17"),
     "panoptic": dict(dataset="panoptic", V=31, name="panoptic_31view_1920x1080_P19_C19"),
 }
+METRIC = "rendered+backpropagated views/s (differentiable skeletal-Gaussian rasterizer fwd+bwd)"
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(scene, params, n_views):
@@ -36,7 +56,8 @@ def cpu_baseline(scene, params, n_views):
     import math
     import torch
     from oracle import torch_ref
-    torch.set_num_threads(min(32, os.cpu_count() or 1))  # small ops: more threads only add sync overhead
+    threads = min(32, os.cpu_count() or 1)   # small ops: more threads only add sync overhead
+    torch.set_num_threads(threads)
     means, feat, opac, scales, quats = [p.detach().cpu() for p in params]
     W, H = scene.W, scene.H
     g = torch.Generator().manual_seed(0)
@@ -63,7 +84,502 @@ def cpu_baseline(scene, params, n_views):
             break
     dt = time.perf_counter() - t0
     return dict(value=done / dt, unit="views/s", cores=torch.get_num_threads(), kind="port",
+                host_cpus=os.cpu_count(), cpu_model=cpu_model(), threads=torch.get_num_threads(),
                 sample=f"{done} views fwd+bwd of the same scene, oracle/torch_ref.py (pure PyTorch, fp32), {dt:.1f}s")
+
+
+class ApiStep:
+    """One step through the C ABI: sks_forward + sks_backward of this process's views (dL resident), [all_gather of the
+    per-view joint gradients,] mean over the V views (train.py:175, 215-217)."""
+
+    def __init__(self, views, params, dL, V_total=None, exchange=None):
+        import torch
+        from skelsplat_amd import rasterizer as R
+        self.R, self.views, self.params, self.dL = R, views, params, dL
+        self.exchange = exchange          # None, or (world, rank, group)
+        if exchange is not None:
+            world, rank, _ = exchange
+            dev, P = params[0].device, params[0].shape[0]
+            vmax = (V_total + world - 1) // world
+            self.shard = torch.zeros((vmax, P, 3), device=dev)      # pad rows stay zero
+            self.allg = torch.empty((world * vmax, P, 3), device=dev)
+            # view v = row (v % world) * vmax + v // world of the gathered buffer: one precomputed index
+            self.rows = torch.tensor([(v % world) * vmax + v // world for v in range(V_total)], dtype=torch.long, device=dev)
+        self.ws = R.Workspace()
+
+    def __call__(self):
+        import torch.distributed as dist
+        R = self.R
+        gx = None
+        if self.views is not None:
+            color, inv, radii, st = R.forward_views(self.views, *self.params, None, workspace=self.ws)
+            g = R.backward_views(st, *self.params, None, self.dL, workspace=self.ws)
+            gx = g["means3D"]
+        if self.exchange is not None:
+            if gx is not None:
+                self.shard[:gx.shape[0]].copy_(gx)
+            dist.all_gather_into_tensor(self.allg, self.shard, group=self.exchange[2])
+            gx = self.allg.index_select(0, self.rows)
+        return gx.mean(dim=0)
+
+
+def timed(fn, steps, warmup, sync):
+    """`warmup` untimed + `steps` timed calls, bracketed by `sync` (barrier + device synchronise); seconds."""
+    for _ in range(warmup):
+        fn()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = fn()
+    sync()
+    return time.perf_counter() - t0, out
+
+
+def roofline_entry(alg_bytes, prof_fwd, wl_name, launches, kernel="k_render_fwd_sparse (forward fill + sparse compositor)"):
+    fwd_ms, fwd_n, fwd_q = prof_fwd
+    avg_s = fwd_ms * 1e-3 / fwd_n
+    traffic, src = None, None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(wl_name, {}).get("fwd_bytes_per_launch")
+            src = "profiles/traffic.json (rocprofv3 --pmc passes of this command, collected separately: not measured in this run)"
+        except Exception:
+            traffic = None
+    return {"bound": "hbm", "kernel": kernel, "achieved": alg_bytes / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": alg_bytes / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src if traffic else None,
+            "avg_launch_us": avg_s * 1e6, "launch_us_p10_p50_p90": [round(1e3 * x, 2) for x in fwd_q],
+            "launches_timed": fwd_n, "launches": launches, "algorithmic_bytes_per_launch": alg_bytes}
+
+
+def make_scene(torch, wl, dev, seed=0):
+    """Synthetic scene + Gaussians + activated parameter tuple for the C ABI."""
+    from skelsplat_amd.scene import SyntheticScene, GaussianModel
+    scene = SyntheticScene(wl["dataset"], n_views=wl["V"], seed=seed, device=dev)
+    gm = GaussianModel().create_from_points(scene.pose_3d_init, scene.spatial_lr_scale, scene.n_joints,
+                                            scene_type=wl["dataset"], device=dev)
+    P, C = scene.n_points, scene.n_joints
+    with torch.no_grad():
+        params = (gm.get_xyz.detach().clone(), gm.get_features.reshape(P, C).contiguous(), gm.get_opacity.detach().clone(),
+                  gm.get_scaling.detach().clone(), gm.get_rotation.detach().clone())
+    return scene, gm, params
+
+
+def fresh_model(scene, dataset, dev):
+    from skelsplat_amd.scene import GaussianModel
+    gm = GaussianModel().create_from_points(scene.pose_3d_init, scene.spatial_lr_scale, scene.n_joints, scene_type=dataset, device=dev)
+    gm.training_setup()
+    return gm
+
+
+def loop_ms(torch, loop, n, sync):
+    for _ in range(3):
+        loop.step_group()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        loop.step_group()
+    sync()
+    return 1e3 * (time.perf_counter() - t0) / n
+
+
+# ------------------------------------------------------------------------------------------------------------
+# N = 1: BASELINE configs[1] + extras
+# ------------------------------------------------------------------------------------------------------------
+def run_single(args, torch, dev, wl):
+    from skelsplat_amd import _lib
+    from skelsplat_amd import rasterizer as R
+    from skelsplat_amd.scene import SyntheticScene
+
+    def sync():
+        torch.cuda.synchronize()
+
+    V = wl["V"]
+    scene, gm, params = make_scene(torch, wl, dev)
+    W, H, P, C = scene.W, scene.H, scene.n_points, scene.n_joints
+    views = R.ViewBatch.from_cameras(scene.cameras)
+    dL = torch.randn((V, C, H, W), device=dev, generator=torch.Generator(device=dev).manual_seed(0))
+    step = ApiStep(views, params, dL)
+    prof = not args.no_prof
+    for _ in range(args.warmup):
+        step()
+    sync()
+    if prof:
+        # the kernels of every 8th step are bracketed with hipEvents on the launch stream: >= 25 samples of the timed
+        # region at the default 200 steps, without the ~12 us per step that four event records per step would add
+        _lib.prof_enable(True, every=max(1, min(8, args.steps // 8)))
+        _lib.prof_read(0), _lib.prof_read(1)
+    dt, out = timed(step, args.steps, 0, sync)
+    pf = pb = None
+    if prof:
+        pf = _lib.prof_read_quantiles(0)
+        pb = _lib.prof_read_quantiles(1)
+        _lib.prof_enable(False)
+    assert torch.isfinite(out).all()
+    res = {
+        "metric": METRIC, "value": V * args.steps / dt, "unit": "views/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": wl["name"], "views_per_step": V, "P": P, "C": C, "W": W, "H": H, "parallelism": "single GPU",
+                   "path": "C ABI sks_forward + sks_backward, eager launches, outputs in a reused workspace"},
+    }
+    if pf and pf[1]:
+        res["roofline"] = roofline_entry(4.0 * H * W * (C + 1) * V, pf, wl["name"], args.steps)
+        if pb and pb[1]:
+            res["bwd_kernel_avg_us"] = pb[0] * 1e3 / pb[1]
+            res["bwd_kernel_us_p10_p50_p90"] = [round(1e3 * x, 2) for x in pb[2]]
+    if args.no_extras:
+        return res, scene, params
+
+    extras = {}
+    # ---- the same step replayed as a hipGraph --------------------------------------------------------------------
+    try:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step()
+        for _ in range(5):
+            graph.replay()
+        tg, _ = timed(graph.replay, args.steps, 0, sync)
+        extras["graph_replay_views_per_s"] = V * args.steps / tg
+        extras["graph_replay_ms_per_step"] = 1e3 * tg / args.steps
+    except Exception as e:  # capture is an optimisation, never a requirement
+        extras["graph_replay_error"] = repr(e)[:200]
+    # ---- the full loop step: render + masked-L2 + backward + Adam (train.py:130-222) -----------------------------
+    try:
+        from skelsplat_amd.loop import MultiViewLoop
+        from skelsplat_amd.heatmaps import generate_heatmaps
+        gm.training_setup()
+        p2d = torch.tensor(scene.poses_2d, device=dev)
+        hm = generate_heatmaps(gm._xyz.detach(), gm.get_scaling.detach(), gm._rotation.detach(), p2d, scene.cameras)
+        nl = max(10, args.steps // 2)
+        for tag, ug in (("", False), ("_hipgraph", True)):
+            loop = MultiViewLoop(gm, scene.cameras, hm, dataset=wl["dataset"], accumulation_steps=V, use_graph=ug)
+            ms = loop_ms(torch, loop, nl, sync)
+            extras["grad_step_ms" + tag] = ms
+            extras["loop_views_per_s" + tag] = V / ms * 1e3
+        # one whole scene like configs/h36m.yaml (500 iterations), accumulation groups captured 25 per hipGraph
+        loop = MultiViewLoop(gm, scene.cameras, hm, dataset=wl["dataset"], accumulation_steps=V, use_graph=True)
+        loop.run(500)                      # captures
+        sync()
+        ts = time.perf_counter()
+        for _ in range(3):
+            loop.iteration = 0             # parameters keep evolving; the work per iteration does not change
+            loop.run(500)
+        sync()
+        ts = (time.perf_counter() - ts) / 3
+        extras["scene_500it_ms_hipgraph"] = 1e3 * ts
+        extras["grad_step_ms_scene_hipgraph"] = 1e3 * ts / (500 / V)
+        # frames streamed through one loop object (train.py:74-99 per frame: re-initialise the Gaussians, generate the
+        # heat-maps from the 2D detections, 500 iterations), everything in place so the hipGraphs are reused
+        pts = torch.tensor(scene.pose_3d_init, device=dev, dtype=torch.float32)
+        loop.new_scene(pts, poses_2d=p2d)
+        loop.run(500)
+        sync()
+        tf = time.perf_counter()
+        for _ in range(5):
+            loop.new_scene(pts, poses_2d=p2d)
+            loop.run(500)
+        sync()
+        extras["frame_stream_ms"] = 1e3 * (time.perf_counter() - tf) / 5
+        del loop, hm
+    except Exception as e:
+        extras["loop_error"] = repr(e)[:300]
+    # ---- the reference's own iteration with only the modules swapped (train.py:130-161) --------------------------
+    if not args.no_dropin:
+        try:
+            extras.update(dropin_iteration(args, torch, dev, wl, scene))
+        except Exception as e:
+            extras["dropin_error"] = repr(e)[:200]
+    # ---- other BASELINE configs, as extras of the same line ------------------------------------------------------
+    if wl["dataset"] == "h36m":
+        for name, fn in (("h36m_mixed_1002", extra_mixed), ("panoptic", extra_panoptic), ("stress", extra_stress)):
+            try:
+                extras[name] = fn(args, torch, dev, sync)
+            except Exception as e:
+                extras[name] = {"error": repr(e)[:300]}
+            torch.cuda.empty_cache()
+    res.update(extras)
+    return res, scene, params
+
+
+def dropin_iteration(args, torch, dev, wl, scene):
+    """render() of ONE view through the drop-in gaussian_renderer, masked-L2, autograd backward, Adam every V views."""
+    import types
+    from gaussian_renderer import render_functions
+    from skelsplat_amd.loop import l2_loss_gaussian
+    from skelsplat_amd.ops import l2_loss_gaussian as l2_loss_gaussian_fused
+    from skelsplat_amd.heatmaps import generate_heatmaps
+    V = wl["V"]
+    render = render_functions["diff-gaussian-rasterization-" + wl["dataset"]]
+    pipe = types.SimpleNamespace(debug=False, antialiasing=False, compute_cov3D_python=False, convert_SHs_python=False)
+    bgc = torch.zeros(3, device=dev)
+    gm2 = fresh_model(scene, wl["dataset"], dev)
+    hm = generate_heatmaps(gm2._xyz.detach(), gm2.get_scaling.detach(), gm2._rotation.detach(),
+                           torch.tensor(scene.poses_2d, device=dev), scene.cameras)
+
+    def it(i, criterion):
+        pkg = render(scene.cameras[i % V], gm2, pipe, bgc)
+        loss, _ = criterion(pkg["render"], hm[i % V])   # (loss, error image) like loss_utils.py:100
+        loss.backward()
+        if (i + 1) % V == 0:
+            gm2.optimizer.step()
+            gm2.optimizer.zero_grad(set_to_none=True)
+
+    out = {}
+    # tensor-op criterion as in the reference, then the fused criterion registered in its `losses` table
+    for tag, crit in (("dropin_iteration_ms", l2_loss_gaussian), ("dropin_iteration_fused_loss_ms", l2_loss_gaussian_fused)):
+        for i in range(2 * V):
+            it(i, crit)
+        torch.cuda.synchronize()
+        td = time.perf_counter()
+        nd = max(2 * V, args.steps // 4)
+        for i in range(nd):
+            it(i, crit)
+        torch.cuda.synchronize()
+        out[tag] = 1e3 * (time.perf_counter() - td) / nd
+    return out
+
+
+def extra_mixed(args, torch, dev, sync):
+    """The real H36M sensor mix (scene/dataset_readers.py:68-80: 1002- and 1000-wide cameras in every subject): the API
+    step as two size groups (the dense tensors cannot mix sizes), the sparse loop group as ONE launch sequence."""
+    from skelsplat_amd import _lib
+    from skelsplat_amd import rasterizer as R
+    from skelsplat_amd.scene import SyntheticScene
+    from skelsplat_amd.loop import MultiViewLoop
+    from skelsplat_amd.heatmaps import generate_heatmaps
+    a = SyntheticScene("h36m", n_views=4, seed=0, device=dev, W=1000, H=1000)
+    b = SyntheticScene("h36m", n_views=4, seed=0, device=dev, W=1002, H=1000)
+    cams = [b.cameras[0], a.cameras[1], a.cameras[2], b.cameras[3]]          # widths 1002, 1000, 1000, 1002
+    _, gm, params = make_scene(torch, WORKLOADS["h36m"], dev)
+    C = 17
+    out = {}
+    # all four views 1002 wide through the API: the 16-byte fill with half-masked float4s vs the 1000-wide headline
+    v1002 = R.ViewBatch.from_cameras(b.cameras)
+    dLb = torch.randn((4, C, 1000, 1002), device=dev)
+    step = ApiStep(v1002, params, dLb)
+    n = max(20, args.steps // 2)
+    _lib.prof_enable(True, every=4)
+    _lib.prof_read(0)
+    dt, _ = timed(step, n, 5, sync)
+    pf = _lib.prof_read_quantiles(0)
+    _lib.prof_enable(False)
+    out["api_4x1002_ms_per_step"] = 1e3 * dt / n
+    out["api_4x1002_views_per_s"] = 4 * n / dt
+    if pf[1]:
+        out["fwd_kernel_us_4x1002"] = pf[0] * 1e3 / pf[1]
+        out["fwd_frac_of_hbm_peak_4x1002"] = 4.0 * 1000 * 1002 * (C + 1) * 4 / (pf[0] * 1e-3 / pf[1]) / 1e9 / HBM_PEAK_GBS
+    del step, dLb
+    # the mix: two API calls of two views each
+    groups = []
+    for sc, ids in ((b, [0, 3]), (a, [1, 2])):
+        vb = R.ViewBatch.from_cameras([sc.cameras[i] for i in ids])
+        groups.append(ApiStep(vb, params, torch.randn((2, C, sc.H, sc.W), device=dev)))
+
+    def mixed_step():
+        return groups[0]() + groups[1]()
+    dt, _ = timed(mixed_step, n, 5, sync)
+    out["api_mixed_ms_per_step"] = 1e3 * dt / n
+    out["api_mixed_views_per_s"] = 4 * n / dt
+    del groups
+    # the loop: one sparse fused group over all four views
+    gm.training_setup()
+    hms = [generate_heatmaps(gm._xyz.detach(), gm.get_scaling.detach(), gm._rotation.detach(),
+                             torch.tensor((b if cams[v].image_width == 1002 else a).poses_2d[v:v + 1], device=dev), [cams[v]])[0]
+           for v in range(4)]
+    for tag, ug in (("", False), ("_hipgraph", True)):
+        loop = MultiViewLoop(gm, cams, hms, dataset="h36m", accumulation_steps=4, use_graph=ug)
+        out["loop_mixed_grad_step_ms" + tag] = loop_ms(torch, loop, n, sync)
+        out["loop_mixed_launch_sequences"] = 1 if loop.views_all is not None and loop.views_all.mixed else len(loop.size_groups)
+    return out
+
+
+def extra_panoptic(args, torch, dev, sync):
+    """BASELINE configs[2]: Panoptic, 19 joints, 31 HD views, one GPU."""
+    from skelsplat_amd import _lib
+    from skelsplat_amd import rasterizer as R
+    from skelsplat_amd.loop import MultiViewLoop
+    from skelsplat_amd.heatmaps import generate_heatmaps
+    wl = WORKLOADS["panoptic"]
+    scene, gm, params = make_scene(torch, wl, dev)
+    V, W, H, C = wl["V"], scene.W, scene.H, scene.n_joints
+    views = R.ViewBatch.from_cameras(scene.cameras)
+    dL = torch.randn((V, C, H, W), device=dev)
+    step = ApiStep(views, params, dL)
+    n = max(10, args.steps // 10)
+    _lib.prof_enable(True, every=1)
+    _lib.prof_read(0), _lib.prof_read(1)
+    dt, _ = timed(step, n, 3, sync)
+    pf, pb = _lib.prof_read_quantiles(0), _lib.prof_read_quantiles(1)
+    _lib.prof_enable(False)
+    out = {"workload": wl["name"], "ms_per_step": 1e3 * dt / n, "views_per_s": V * n / dt}
+    if pf[1]:
+        alg = 4.0 * H * W * (C + 1) * V
+        out["fwd_kernel_us"] = pf[0] * 1e3 / pf[1]
+        out["fwd_frac_of_hbm_peak"] = alg / (pf[0] * 1e-3 / pf[1]) / 1e9 / HBM_PEAK_GBS
+    if pb[1]:
+        out["bwd_kernel_us"] = pb[0] * 1e3 / pb[1]
+    del step, dL
+    gm.training_setup()
+    hm = generate_heatmaps(gm._xyz.detach(), gm.get_scaling.detach(), gm._rotation.detach(),
+                           torch.tensor(scene.poses_2d, device=dev), scene.cameras)
+    for tag, kw in (("loop_sparse_grad_step_ms", dict(use_graph=False)), ("loop_sparse_grad_step_ms_hipgraph", dict(use_graph=True)),
+                    ("loop_dense_grad_step_ms", dict(sparse=False))):
+        loop = MultiViewLoop(gm, scene.cameras, hm, dataset="panoptic", accumulation_steps=V, **kw)
+        out[tag] = loop_ms(torch, loop, n, sync)
+        del loop
+    return out
+
+
+def extra_stress(args, torch, dev, sync):
+    """BASELINE configs[4]: 256 skeletons (P = 4352, C = 17), 8 views @ 2048x2048, binned path."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import util
+    from skelsplat_amd import _lib
+    from skelsplat_amd import rasterizer as R
+    V, C, H, W = 8, 17, 2048, 2048
+    big = util.make_case(seed=42, W=W, H=H, n_views=V, scale_log=3.0, n_skeletons=256, pitch=1500.0, ring=20000.0,
+                         fxmul=2300.0 / (1145.0 * 2.048), onehot=True, opac=1.0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    views = R.ViewBatch.from_cameras([cam.to(dev) for cam in big.cams])
+    params = (t(big.means), t(big.feat), t(big.opac), t(big.scales), t(big.quats))
+    dL = torch.randn((V, C, H, W), device=dev)
+    ws = R.Workspace()
+
+    def step():
+        color, inv, radii, st = R.forward_views(views, *params, None, bin_capacity=400000, workspace=ws)
+        return R.backward_views(st, *params, None, dL, workspace=ws)["means3D"]
+    n = max(10, args.steps // 10)
+    _lib.prof_enable(True, every=1)
+    _lib.prof_read(0), _lib.prof_read(1)
+    dt, _ = timed(step, n, 3, sync)
+    pf, pb = _lib.prof_read_quantiles(0), _lib.prof_read_quantiles(1)
+    _lib.prof_enable(False)
+    out = {"workload": "stress_256skeletons_8view_2048x2048_P4352_C17", "ms_per_step": 1e3 * dt / n, "views_per_s": V * n / dt}
+    if pf[1]:
+        out["fwd_kernel_us"] = pf[0] * 1e3 / pf[1]
+        out["fwd_frac_of_hbm_peak"] = 4.0 * H * W * (C + 1) * V / (pf[0] * 1e-3 / pf[1]) / 1e9 / HBM_PEAK_GBS
+    if pb[1]:
+        out["bwd_kernel_us"] = pb[0] * 1e3 / pb[1]
+        out["bwd_kernel_us_p10_p50_p90"] = [round(1e3 * x, 1) for x in pb[2]]
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------
+# N > 1: BASELINE configs[3], the same views split over the ranks (strong scaling)
+# ------------------------------------------------------------------------------------------------------------
+def run_sharded(args, torch, dist, dev, wl, world, rank):
+    from skelsplat_amd import _lib
+    from skelsplat_amd import rasterizer as R
+    from skelsplat_amd.loop import MultiViewLoop
+    from skelsplat_amd.heatmaps import generate_heatmaps
+
+    def sync():
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        t = torch.tensor([x], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    V = wl["V"]
+    scene, gm, params = make_scene(torch, wl, dev)          # the same frame and cameras on every rank (seed 0)
+    W, H, P, C = scene.W, scene.H, scene.n_points, scene.n_joints
+    local = [v for v in range(V) if v % world == rank]
+    gen = torch.Generator(device=dev).manual_seed(0)
+    dL_all = torch.randn((V, C, H, W), device=dev, generator=gen)     # identical on every rank
+    n_ref = max(5, args.steps // 10)
+    # (A) one GPU alone: every rank runs the whole 31-view step side by side, no communication.  Its time is the N = 1
+    #     reference of this run; N x 31 views / that time is the weak-scaling aggregate.
+    full = ApiStep(R.ViewBatch.from_cameras(scene.cameras), params, dL_all)
+    dt_full, _ = timed(full, n_ref, 3, sync)
+    dt_full = max_over_ranks(dt_full)
+    one_gpu_ms = 1e3 * dt_full / n_ref
+    del full
+    # (B) the timed region: the same V views, view v on rank v % world, one all_gather of the joint gradients per step
+    lviews = R.ViewBatch.from_cameras([scene.cameras[v] for v in local]) if local else None
+    dL = dL_all[local].contiguous() if local else None
+    del dL_all
+    torch.cuda.empty_cache()
+    step = ApiStep(lviews, params, dL, V_total=V, exchange=(world, rank, None))
+    for _ in range(args.warmup):
+        step()
+    sync()
+    prof = not args.no_prof and bool(local)
+    if prof:
+        _lib.prof_enable(True, every=max(1, min(8, args.steps // 8)))
+        _lib.prof_read(0), _lib.prof_read(1)
+    dt, out = timed(step, args.steps, 0, sync)
+    dt = max_over_ranks(dt)
+    pf = None
+    if prof:
+        pf = _lib.prof_read_quantiles(0)
+        _lib.prof_enable(False)
+    assert torch.isfinite(out).all()
+    del step, dL
+    ms = 1e3 * dt / args.steps
+    vmax = (V + world - 1) // world
+    strong = {"ideal_speedup": V / vmax,
+              "api_step": {"one_gpu_ms_per_step": one_gpu_ms, "ms_per_step": ms, "speedup": one_gpu_ms / ms}}
+    res = {
+        "metric": METRIC, "value": V * args.steps / dt, "unit": "views/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": wl["name"], "views_total": V, "views_on_rank0": len(local), "P": P, "C": C, "W": W, "H": H,
+                   "parallelism": f"views sharded v % {world} over {world} ranks; one all_gather_into_tensor (RCCL) of the "
+                                  f"({vmax},P,3) joint gradients per step",
+                   "path": "C ABI sks_forward + sks_backward, eager launches"},
+        "weak_scaling_views_per_s": world * V * n_ref / dt_full,
+    }
+    if pf and pf[1]:
+        res["roofline"] = roofline_entry(4.0 * H * W * (C + 1) * len(local), pf, "-", args.steps)
+        res["roofline"]["note"] = f"rank 0's launch: its {len(local)} local views"
+    if not args.no_extras:
+        # (C, D) the loop's own step -- render + masked-L2 + backward + [all_gather] + Adam (train.py:130-222): dense and
+        # sparse fused, each alone on one GPU (shard_views=False, all ranks side by side) and sharded over the ranks
+        try:
+            p2d = torch.tensor(scene.poses_2d, device=dev)
+            gm.training_setup()
+            hm = generate_heatmaps(gm._xyz.detach(), gm.get_scaling.detach(), gm._rotation.detach(), p2d, scene.cameras)
+            nl = max(5, args.steps // 10)
+            graph_dist = os.environ.get("SKS_GRAPH_COLLECTIVES") == "1"
+            for tag, kw in (("loop_dense", dict(sparse=False)), ("loop_sparse", dict(sparse=True))):
+                one = MultiViewLoop(fresh_model(scene, wl["dataset"], dev), scene.cameras, hm, dataset=wl["dataset"],
+                                    accumulation_steps=V, shard_views=False, **kw)
+                t1 = max_over_ranks(loop_ms(torch, one, nl, sync))
+                del one
+                shl = MultiViewLoop(fresh_model(scene, wl["dataset"], dev), scene.cameras, hm, dataset=wl["dataset"],
+                                    accumulation_steps=V, **kw)
+                tn = max_over_ranks(loop_ms(torch, shl, nl, sync))
+                strong[tag] = {"one_gpu_ms_per_step": t1, "ms_per_step": tn, "speedup": t1 / tn}
+                del shl
+                if graph_dist:   # the sharded group, RCCL all_gather included, replayed as a hipGraph (opt-in)
+                    shg = MultiViewLoop(fresh_model(scene, wl["dataset"], dev), scene.cameras, hm, dataset=wl["dataset"],
+                                        accumulation_steps=V, use_graph=True, graph_collectives=True, **kw)
+                    strong[tag]["ms_per_step_hipgraph"] = max_over_ranks(loop_ms(torch, shg, nl, sync))
+                    del shg
+            # (E) frame sharding: every rank optimises its own frames (500 iterations each, hipGraphs), no communication
+            fl = MultiViewLoop(fresh_model(scene, wl["dataset"], dev), scene.cameras, hm, dataset=wl["dataset"],
+                               accumulation_steps=V, shard_views=False, use_graph=True)
+            pts = torch.tensor(scene.pose_3d_init, device=dev, dtype=torch.float32)
+            fl.new_scene(pts, poses_2d=p2d)
+            fl.run(500)
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                fl.new_scene(pts, poses_2d=p2d)
+                fl.run(500)
+            sync()
+            tf = max_over_ranks((time.perf_counter() - t0) / 3)
+            res["frame_sharded"] = {"frame_ms": 1e3 * tf, "frames_per_s_all_ranks": world / tf,
+                                    "note": "500 iterations per frame incl. heat-map generation; zero communication"}
+        except Exception as e:
+            res["loop_error"] = repr(e)[:300]
+    res["strong_scaling"] = strong
+    return res
 
 
 def main():
@@ -71,12 +587,23 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="h36m", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="default: h36m on one GPU (BASELINE configs[1]), panoptic when sharded (configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with hipEvents")
     ap.add_argument("--no-dropin", action="store_true", help="skip the literal drop-in iteration extra (its single-view "
                     "launches would mix into per-kernel averages of a rocprofv3 run)")
+    ap.add_argument("--no-extras", action="store_true", help="only the headline measurement")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # asked for N GPUs without a launcher around us: start one rank per GPU as CHILD processes (nothing here has
+        # touched the GPU yet, and nothing is exec'ed) and hand their result line and exit code through
+        import subprocess
+        port = 29500 + os.getpid() % 2000
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd).returncode)
 
     # Native libraries write to the process's stdout too (RCCL prints a version banner from C stdio, flushed at exit, i.e.
     # AFTER the result line): fd 1 is pointed at stderr for the whole run and the one JSON line goes to the real stdout.
@@ -86,232 +613,33 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from skelsplat_amd import _lib
-    from skelsplat_amd import rasterizer as R
-    from skelsplat_amd.scene import SyntheticScene, GaussianModel
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}: launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    use_dist = world > 1 or os.environ.get("SKS_BENCH_FORCE_DIST") == "1"   # the env switch exercises RCCL at world 1
+    use_dist = world > 1 or os.environ.get("SKS_BENCH_FORCE_DIST") == "1"   # the env switch runs the sharded path at world 1
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
-    assert world == args.gpus or world == 1, (world, args.gpus)
 
-    wl = WORKLOADS[args.workload]
-    V = wl["V"]
-    # every rank renders V views of the same skeleton from its own cameras (V * world views of one frame)
-    scene = SyntheticScene(wl["dataset"], n_views=V, seed=rank, device=dev)
-    ref_scene = SyntheticScene(wl["dataset"], n_views=V, seed=0)
-    gm = GaussianModel().create_from_points(ref_scene.pose_3d_init, scene.spatial_lr_scale, scene.n_joints,
-                                            scene_type=wl["dataset"], device=dev)
-    W, H, P, C = scene.W, scene.H, scene.n_points, scene.n_joints
-    views = R.ViewBatch.from_cameras(scene.cameras)
-    with torch.no_grad():
-        params = (gm.get_xyz.detach().clone(), gm.get_features.reshape(P, C).contiguous(), gm.get_opacity.detach().clone(),
-                  gm.get_scaling.detach().clone(), gm.get_rotation.detach().clone())
-    means, feat, opac, scales, quats = params
-    dL = torch.randn((V, C, H, W), device=dev, generator=torch.Generator(device=dev).manual_seed(rank))
-    gathered = torch.empty((world * V, P, 3), device=dev) if use_dist else None
-
-    def step():
-        color, inv, radii, st = R.forward_views(views, means, feat, opac, scales, quats, None)
-        g = R.backward_views(st, means, feat, opac, scales, quats, None, dL)
-        gx = g["means3D"]
-        if use_dist:  # view-sharded loop: every rank needs all per-view joint gradients (train.py:175,215-217)
-            dist.all_gather_into_tensor(gathered, gx)
-            gx = gathered
-        return gx.mean(dim=0)
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
+    wl = WORKLOADS[args.workload or ("panoptic" if use_dist else "h36m")]
     if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    prof = not args.no_prof
-    if prof:
-        # the kernels of every 8th step are bracketed with hipEvents on the launch stream: >= 25 samples of the timed
-        # region at the default 200 steps, without the ~12 us per step that four event records per step would add
-        _lib.prof_enable(True, every=max(1, min(8, args.steps // 8)))
-        _lib.prof_read(0), _lib.prof_read(1)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    fwd_ms = fwd_n = bwd_ms = bwd_n = 0
-    fwd_q = bwd_q = (0.0, 0.0, 0.0)
-    if prof:
-        fwd_ms, fwd_n, fwd_q = _lib.prof_read_quantiles(0)
-        bwd_ms, bwd_n, bwd_q = _lib.prof_read_quantiles(1)
-        _lib.prof_enable(False)
-    if use_dist:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    assert torch.isfinite(out).all()
-
-    # ---- extras (not part of `value`): hipGraph replay of the same step, and the full loop step ----------------
-    extras = {}
-    if world == 1 and not use_dist:
-        try:
-            graph = torch.cuda.CUDAGraph()
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(3):
-                    step()
-            torch.cuda.current_stream().wait_stream(side)
-            with torch.cuda.graph(graph):
-                gout = step()
-            for _ in range(5):
-                graph.replay()
-            torch.cuda.synchronize()
-            tg = time.perf_counter()
-            for _ in range(args.steps):
-                graph.replay()
-            torch.cuda.synchronize()
-            tg = time.perf_counter() - tg
-            extras["graph_replay_views_per_s"] = V * args.steps / tg
-            extras["graph_replay_ms_per_step"] = 1e3 * tg / args.steps
-        except Exception as e:  # capture is an optimisation, never a requirement
-            extras["graph_replay_error"] = repr(e)[:200]
-        try:
-            from skelsplat_amd.loop import MultiViewLoop
-            from skelsplat_amd.heatmaps import generate_heatmaps
-            gm.training_setup()
-            hm = generate_heatmaps(gm._xyz.detach(), gm.get_scaling.detach(), gm._rotation.detach(),
-                                   torch.tensor(ref_scene.poses_2d, device=dev), scene.cameras)
-            for tag, ug in (("", False), ("_hipgraph", True)):
-                loop = MultiViewLoop(gm, scene.cameras, hm, dataset=wl["dataset"], accumulation_steps=V, use_graph=ug)
-                for _ in range(5):
-                    loop.step_group()
-                torch.cuda.synchronize()
-                tl = time.perf_counter()
-                nl = max(10, args.steps // 2)
-                for _ in range(nl):
-                    loop.step_group()
-                torch.cuda.synchronize()
-                tl = time.perf_counter() - tl
-                # V views rendered + fused masked-L2 + backward + device-side Adam step (train.py:130-222)
-                extras["grad_step_ms" + tag] = 1e3 * tl / nl
-                extras["loop_views_per_s" + tag] = V * nl / tl
-            # one whole scene like configs/h36m.yaml (500 iterations), accumulation groups captured 25 per hipGraph
-            loop = MultiViewLoop(gm, scene.cameras, hm, dataset=wl["dataset"], accumulation_steps=V, use_graph=True)
-            loop.run(500)                      # captures
-            torch.cuda.synchronize()
-            ts = time.perf_counter()
-            for _ in range(3):
-                loop.iteration = 0             # parameters keep evolving; the work per iteration does not change
-                loop.run(500)
-            torch.cuda.synchronize()
-            ts = (time.perf_counter() - ts) / 3
-            extras["scene_500it_ms_hipgraph"] = 1e3 * ts
-            extras["loop_views_per_s_scene_hipgraph"] = 500 / ts
-            extras["grad_step_ms_scene_hipgraph"] = 1e3 * ts / (500 / V)
-            # frames streamed through one loop object (train.py:74-99 per frame: re-initialise the Gaussians, generate the
-            # heat-maps from the 2D detections, 500 iterations), everything in place so the hipGraphs are reused
-            p2d = torch.tensor(ref_scene.poses_2d, device=dev)
-            pts = torch.tensor(ref_scene.pose_3d_init, device=dev, dtype=torch.float32)
-            loop.new_scene(pts, poses_2d=p2d)
-            loop.run(500)
-            torch.cuda.synchronize()
-            tf = time.perf_counter()
-            for _ in range(5):
-                loop.new_scene(pts, poses_2d=p2d)
-                loop.run(500)
-            torch.cuda.synchronize()
-            extras["frame_stream_ms"] = 1e3 * (time.perf_counter() - tf) / 5
-        except Exception as e:
-            extras["loop_error"] = repr(e)[:200]
-
-        try:
-            if args.no_dropin:
-                raise StopIteration
-            # the reference's own iteration (train.py:130-161) with the modules swapped and nothing else changed:
-            # render() of ONE view through the drop-in gaussian_renderer, masked-L2 in tensor ops, autograd backward
-            import types
-            from gaussian_renderer import render_functions
-            from skelsplat_amd.loop import l2_loss_gaussian
-            render = render_functions["diff-gaussian-rasterization-" + wl["dataset"]]
-            pipe = types.SimpleNamespace(debug=False, antialiasing=False, compute_cov3D_python=False, convert_SHs_python=False)
-            bgc = torch.zeros(3, device=dev)
-            gm2 = GaussianModel().create_from_points(ref_scene.pose_3d_init, scene.spatial_lr_scale, scene.n_joints,
-                                                     scene_type=wl["dataset"], device=dev)
-            gm2.training_setup()
-
-            from skelsplat_amd.ops import l2_loss_gaussian as l2_loss_gaussian_fused
-
-            def dropin_iteration(i, criterion):
-                cam = scene.cameras[i % V]
-                pkg = render(cam, gm2, pipe, bgc)
-                loss, _ = criterion(pkg["render"], hm[i % V])   # (loss, error image) like loss_utils.py:100
-                loss.backward()
-                if (i + 1) % V == 0:
-                    gm2.optimizer.step()
-                    gm2.optimizer.zero_grad(set_to_none=True)
-
-            # tensor-op criterion as in the reference, then the fused criterion registered in its `losses` table
-            for tag, crit in (("dropin_iteration_ms", l2_loss_gaussian), ("dropin_iteration_fused_loss_ms", l2_loss_gaussian_fused)):
-                for i in range(2 * V):
-                    dropin_iteration(i, crit)
-                torch.cuda.synchronize()
-                td = time.perf_counter()
-                nd = max(2 * V, args.steps // 4)
-                for i in range(nd):
-                    dropin_iteration(i, crit)
-                torch.cuda.synchronize()
-                extras[tag] = 1e3 * (time.perf_counter() - td) / nd
-        except StopIteration:
-            pass
-        except Exception as e:
-            extras["dropin_error"] = repr(e)[:200]
-
+        res = run_sharded(args, torch, dist, dev, wl, world, rank)
+    else:
+        res, scene, params = run_single(args, torch, dev, wl)
+        if not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(scene, params, n_views=2)
     if rank == 0:
-        views_total = V * world * args.steps
-        res = {
-            "metric": "rendered+backpropagated views/s (differentiable skeletal-Gaussian rasterizer fwd+bwd)",
-            "value": views_total / dt, "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": wl["name"], "views_per_gpu_step": V, "P": P, "C": C, "W": W, "H": H,
-                       "parallelism": f"view-sharded x{world}" if world > 1 else "single GPU",
-                       "path": "C ABI sks_forward + sks_backward, eager launches"},
-        }
-        if prof and fwd_n:
-            alg_bytes = 4.0 * H * W * (C + 1) * V   # per launch: V views of (C colour + 1 inverse-depth) fp32 planes
-            avg_s = fwd_ms * 1e-3 / fwd_n
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tpath):
-                try:
-                    traffic = json.load(open(tpath)).get(wl["name"], {}).get("fwd_bytes_per_launch")
-                except Exception:
-                    traffic = None
-            res["roofline"] = {"bound": "hbm", "kernel": "k_render_fwd_sparse (forward fill + sparse compositor)",
-                               "achieved": alg_bytes / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": alg_bytes / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-                               "avg_launch_us": avg_s * 1e6, "launch_us_p10_p50_p90": [round(1e3 * x, 2) for x in fwd_q],
-                               "launches_timed": fwd_n, "launches": args.steps,
-                               "algorithmic_bytes_per_launch": alg_bytes}
-            if bwd_n:
-                res["bwd_kernel_avg_us"] = bwd_ms * 1e3 / bwd_n
-                res["bwd_kernel_us_p10_p50_p90"] = [round(1e3 * x, 2) for x in bwd_q]
-        res.update(extras)
-        if not args.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline(ref_scene, params, n_views=2)
         os.write(real_stdout, (json.dumps(res) + "\n").encode())
     # nothing may follow the result line on either stream: what native libraries still hold in their stdio buffers (RCCL's
     # banner) or print while tearing down goes to /dev/null from here on

@@ -185,12 +185,18 @@ int sks_knn3_meandist2_grid(int P, const float* points, float* mean_dist2, void*
  *      re-composites each covered pixel, forms 2 (clamp(r) - gt) on the mask {gt > 0 or r > 0} on the fly, and
  *      returns per-view {S, N} (loss_v = S/N) in loss_sums = gt_totals + the corrections of the pixels with a
  *      positive render; gradients are UNSCALED (multiply by 1/N_v, e.g. with sks_loop_pack_grads).  P <= 64.
- *      tile_S / tile_N are not read (may be NULL). */
+ *      tile_S / tile_N are not read (may be NULL).
+ *  Views of different image sizes in ONE launch sequence (H36M mixes 1000- and 1002-wide sensors,
+ *  scene/dataset_readers.py:68-80): nothing dense is written on this path, so sks_geometry, sks_backward_fused_loss
+ *  and sks_loop_fused_step accept view_wh = V x {W_v, H_v} (W, H arguments: the largest) and, for the heat-maps,
+ *  gt_offsets = V offsets in floats from `gt` to view v's (C,H_v,W_v) planes inside one flat buffer.  NULL = all W x H
+ *  and gt is one (V,C,H,W) tensor.  A `geom` filled with view_wh serves the fused-loss calls, not sks_forward. */
 int sks_gt_tile_stats(int V, int C, int W, int H, const float* gt, float* tile_S, float* tile_N, double* totals, void* stream);
 int sks_geometry(int V, int P, int C, int W, int H, const float* viewmatrix, const float* projmatrix,
                  const float* tanfovx /*HOST V*/, const float* tanfovy /*HOST V*/, const float* means3D,
                  const float* opacities, const float* scales, const float* rotations, const float* cov3D_precomp,
-                 float scale_modifier, unsigned flags, int* radii, void* geom, void* stream);
+                 float scale_modifier, unsigned flags, int* radii, void* geom,
+                 const int* view_wh /*HOST V x {W,H} or NULL: see below*/, void* stream);
 int sks_backward_fused_loss(int V, int P, int C, int W, int H, const float* viewmatrix, const float* projmatrix,
                             const float* tanfovx /*HOST V*/, const float* tanfovy /*HOST V*/, const float* bg,
                             const float* means3D, const float* features, const float* opacities, const float* scales,
@@ -200,6 +206,7 @@ int sks_backward_fused_loss(int V, int P, int C, int W, int H, const float* view
                             float* dL_dopacity, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
                             double* loss_sums, float* packed_raw_grads /* optional (V,P,11), see sks_loop_pack_grads:
                             with SKS_RAW_PARAMS the activation Jacobians and the 1/N_v scale are applied here */,
+                            const int* view_wh /*HOST V x {W,H} or NULL*/, const size_t* gt_offsets /*HOST V or NULL*/,
                             void* stream);
 
 /* Device-side tail of the multi-view loop (train.py:160-222), so that one accumulation group is a fixed launch
@@ -220,7 +227,11 @@ int sks_loop_adam_step(int V, int P, const float* grads, float* slots, unsigned 
                        float* xyz, float* scaling, float* rotation, float* opacity, float* exp_avg, float* exp_avg_sq,
                        int* counters, int acc_steps, const double* lr_sched /*HOST 5: init, final, delay_mult, delay_steps, max_steps*/,
                        const double* lrs /*HOST 3: scaling, rotation, opacity*/, const double* adam /*HOST 3: beta1, beta2, eps*/,
-                       float lambda_consistency, const int* limb /*HOST 8 ints or NULL*/, void* stream);
+                       float lambda_consistency, const int* limb /*HOST 8 ints or NULL*/,
+                       int shard_world /* layout of grads: 1 = (V,P,11) view-major; N > 1 = the buffer all_gather leaves when
+                       view v is local view v / N of rank v % N and every rank contributes ceil(V / N) rows: (N, ceil(V/N), P, 11),
+                       read in place -- the exchange step of the view-sharded loop needs no re-ordering pass */,
+                       void* stream);
 
 /* One accumulation group of the sparse loop on ONE GPU in two launches (train.py:130-222 for acc_steps views):
  * the fused-loss compositing backward (as sks_backward_fused_loss) and a single-workgroup tail that runs the geometry
@@ -236,7 +247,9 @@ int sks_loop_fused_step(int V, int P, int C, int W, int H, const float* viewmatr
                         unsigned long long group_mask, int last_view, float* xyz, float* scaling, float* rotation,
                         float* opacity, float* exp_avg, float* exp_avg_sq, int* counters, int acc_steps,
                         const double* lr_sched /*HOST 5*/, const double* lrs /*HOST 3*/, const double* adam /*HOST 3*/,
-                        float lambda_consistency, const int* limb /*HOST 8 or NULL*/, void* stream);
+                        float lambda_consistency, const int* limb /*HOST 8 or NULL*/,
+                        const int* view_wh /*HOST V x {W,H} or NULL*/, const size_t* gt_offsets /*HOST V or NULL*/,
+                        void* stream);
 
 /* Measurement hook used by bench.py (no reference counterpart): while enabled, the dominant kernel of sks_forward
  * (kind 0: forward compositor) and of sks_backward (kind 1: backward compositor) is bracketed by hipEvents recorded

@@ -99,13 +99,13 @@ int sks_loop_adam_step(int V, int P, const float* grads, float* slots, unsigned 
                        float* xyz, float* scaling, float* rotation, float* opacity, float* exp_avg, float* exp_avg_sq,
                        int* counters, int acc_steps, const double* lr_sched /*HOST 5: init, final, delay_mult, delay_steps, max_steps*/,
                        const double* lrs /*HOST 3: scaling, rotation, opacity*/, const double* adam /*HOST 3: beta1, beta2, eps*/,
-                       float lambda_consistency, const int* limb /*HOST 8 or NULL*/, void* stream)
+                       float lambda_consistency, const int* limb /*HOST 8 or NULL*/, int shard_world, void* stream)
 {
     if (V < 1 || V > SKS_MAX_VIEWS || P < 1 || P > SKS_SMALL_P) return fail3(-1, "loop_adam: V or P out of range");
     AdamArgs a;
     if (const char* err = sksloop::fill_adam_args(a, V, P, grads, slots, group_mask, last_view, xyz, scaling, rotation, opacity,
                                                   exp_avg, exp_avg_sq, counters, acc_steps, lr_sched, lrs, adam,
-                                                  lambda_consistency, limb))
+                                                  lambda_consistency, limb, shard_world))
         return fail3(-2, err);
     hipLaunchKernelGGL(k_loop_adam, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
     hipError_t e = hipGetLastError();

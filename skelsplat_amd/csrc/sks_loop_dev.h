@@ -23,7 +23,19 @@ struct AdamArgs {
     float lambda_consistency;
     int limb[8];               // l_arm, r_arm, l_leg, r_leg joint index pairs (loss_utils.py:226-250); limb[0] < 0: none
     int n_joints;              // joints per skeleton (limb indices address the first skeleton, like the reference)
+    // layout of `grads`: world == 1: view-major (V,P,11).  world > 1: what all_gather_into_tensor leaves when view v is
+    // rendered by rank v % world as that rank's local view v / world and every rank contributes vmax = ceil(V / world)
+    // rows: (world, vmax, P, 11), so the step reads the gathered buffer in place (no re-ordering pass in between)
+    int world, vmax;
 };
+
+// row of view v's gradients in AdamArgs::grads
+__device__ __forceinline__ int grad_row(const AdamArgs& a, int v)
+{
+    if (a.world == 1) return v;
+    const int r = v % a.world;
+    return r * a.vmax + (v - r) / a.world;
+}
 
 // torch.optim.Adam single-tensor path (python scalars are doubles, tensor math is fp32):
 //   exp_avg.lerp_(grad, 1-beta1); exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2);
@@ -158,7 +170,7 @@ __device__ __forceinline__ void adam_block_finish(const AdamArgs& a, float* s_xy
             float* sl = a.slots + (size_t)i * 3;
             float val[3];
             if ((a.group_mask >> v) & 1ull) {
-                const float* gr = a.grads + (size_t)i * 11;
+                const float* gr = a.grads + ((size_t)grad_row(a, v) * P + pp) * 11;
 #pragma unroll
                 for (int c = 0; c < 3; c++) { val[c] = gr[c] + s_gc[3 * pp + c]; sl[c] = val[c]; }
             } else {
@@ -179,7 +191,7 @@ __device__ __forceinline__ void adam_block_finish(const AdamArgs& a, float* s_xy
             }
             float* sl = a.slots + ((size_t)v * P + p) * 3;
             if ((a.group_mask >> v) & 1ull) {
-                const float* gr = a.grads + ((size_t)v * P + p) * 11;
+                const float* gr = a.grads + ((size_t)grad_row(a, v) * P + p) * 11;
 #pragma unroll
                 for (int c = 0; c < 3; c++) sl[c] = gr[c] + gc[c];
             }
@@ -188,7 +200,7 @@ __device__ __forceinline__ void adam_block_finish(const AdamArgs& a, float* s_xy
         }
 #pragma unroll
         for (int c = 0; c < 3; c++) g11[c] /= (float)V;
-        const float* gl = a.grads + ((size_t)a.last_view * P + p) * 11;
+        const float* gl = a.grads + ((size_t)grad_row(a, a.last_view) * P + p) * 11;
 #pragma unroll
         for (int c = 3; c < 11; c++) g11[c] = gl[c];
 #pragma unroll
@@ -230,8 +242,11 @@ __device__ __forceinline__ void adam_block_finish(const AdamArgs& a, float* s_xy
 inline const char* fill_adam_args(AdamArgs& a, int V, int P, const float* grads, float* slots, unsigned long long group_mask,
                                   int last_view, float* xyz, float* scaling, float* rotation, float* opacity, float* exp_avg,
                                   float* exp_avg_sq, int* counters, int acc_steps, const double* lr_sched, const double* lrs,
-                                  const double* adam, float lambda_consistency, const int* limb)
+                                  const double* adam, float lambda_consistency, const int* limb, int shard_world = 1)
 {
+    if (shard_world < 1) return "loop_adam: shard_world must be >= 1";
+    a.world = shard_world;
+    a.vmax = (V + shard_world - 1) / shard_world;
     if (!grads || !slots || !xyz || !scaling || !rotation || !opacity || !exp_avg || !exp_avg_sq || !counters || !lr_sched || !lrs || !adam)
         return "loop_adam: missing pointer";
     if (last_view < 0 || last_view >= V) return "loop_adam: last_view out of range";

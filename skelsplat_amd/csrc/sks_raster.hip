@@ -61,14 +61,18 @@ int check_common(int V, int P, int C, int W, int H)
 // `pb` is returned NEGATIVE = -(rows per block).  Otherwise linear mode, pb passes of 4 KB per block: every pass is
 // 32 whole lines whatever the width (at W = 1000 a row is 31.25 lines and the row-aligned mode loses 7% to the
 // partial lines at both ends of every row).
+// 16-byte stores need every band of every plane on a 16-byte boundary: W % 4 == 0, or W % 4 == 2 with an even H (then a
+// float4 is two independently masked pairs, fwd_fill_role<.., HALF>); anything else streams 4 bytes per lane
+inline bool fill_half_mode(const FwdArgs& a) { return a.W % 4 == 2 && a.H % 2 == 0 && !(a.flags & SKS_NO_NT_STORES); }
+
 inline void fill_geometry(const FwdArgs& a, bool have_cover, bool binned, int& fsplit, int& pb)
 {
-    const int ppt = a.W % 4 == 0 ? 4 : 1;
+    const int ppt = (a.W % 4 == 0 || fill_half_mode(a)) ? 4 : 1;
     const int passes = (TILE * a.W + 256 * ppt - 1) / (256 * ppt);
     const int tune = (int)((a.flags >> 8) & 0xff);                    // tuning knob: passes (or rows) per fill block
     const int chunks = (a.W + 1023) / 1024;
-    const bool rowmode = ((ppt == 4 && have_cover && a.W % 32 == 0 && (long long)a.W * 10 >= (long long)chunks * 1024 * 9) ||
-                          (ppt == 4 && have_cover && (a.flags & SKS_FILL_ROWS))) && !(a.flags & SKS_FILL_LINEAR);
+    const bool rowmode = ((ppt == 4 && a.W % 4 == 0 && have_cover && a.W % 32 == 0 && (long long)a.W * 10 >= (long long)chunks * 1024 * 9) ||
+                          (ppt == 4 && a.W % 4 == 0 && have_cover && (a.flags & SKS_FILL_ROWS))) && !(a.flags & SKS_FILL_LINEAR);
     if (rowmode) {
         int pbr = tune;
         // rows per block, interleaved A/B on one box: 1920 wide small path 2 rows 860 us / 3: 898 / 4: 907 / 6: 915;
@@ -102,6 +106,8 @@ void launch_fwd_small(const FwdArgs& a_in, int V, int gy, hipStream_t st)
     if (a.W % 4 == 0) {
         if (nt) hipLaunchKernelGGL((k_render_fwd_sparse<CG, 4, true>), grid, dim3(256), lds, st, a, a.cp1_magic, gy, fsplit, pb, (const uint32_t*)a.g.cover);
         else hipLaunchKernelGGL((k_render_fwd_sparse<CG, 4, false>), grid, dim3(256), lds, st, a, a.cp1_magic, gy, fsplit, pb, (const uint32_t*)a.g.cover);
+    } else if (fill_half_mode(a)) {
+        hipLaunchKernelGGL((k_render_fwd_sparse<CG, 4, true, true>), grid, dim3(256), lds, st, a, a.cp1_magic, gy, fsplit, pb, (const uint32_t*)a.g.cover);
     } else {
         hipLaunchKernelGGL((k_render_fwd_sparse<CG, 1, false>), grid, dim3(256), lds, st, a, a.cp1_magic, gy, fsplit, pb, (const uint32_t*)a.g.cover);
     }
@@ -118,13 +124,15 @@ void launch_fwd_binned(const FwdArgs& a, const BinView& bv, int V, int gx, int g
     if (a.W % 4 == 0) {
         if (nt) hipLaunchKernelGGL((k_render_fwd_binned<CG, 4, true>), grid, dim3(256), 0, st, a, bv, gx, gy, fsplit, pb, cover);
         else hipLaunchKernelGGL((k_render_fwd_binned<CG, 4, false>), grid, dim3(256), 0, st, a, bv, gx, gy, fsplit, pb, cover);
+    } else if (fill_half_mode(a)) {
+        hipLaunchKernelGGL((k_render_fwd_binned<CG, 4, true, true>), grid, dim3(256), 0, st, a, bv, gx, gy, fsplit, pb, cover);
     } else {
         hipLaunchKernelGGL((k_render_fwd_binned<CG, 1, false>), grid, dim3(256), 0, st, a, bv, gx, gy, fsplit, pb, cover);
     }
 }
 
 template <int CG>
-void launch_bwd_small(const BwdArgs& a, int V, int gy, bool dfeat, hipStream_t st)
+void launch_bwd_small(const BwdArgs& a, const ViewTan& vt, const ViewOff& vo, int V, int gy, bool dfeat, hipStream_t st)
 {
     (void)gy;
     // slot index slowest: a (view, Gaussian) only has work for its first ceil(pixels / 256) slots, so the idle workgroups
@@ -132,8 +140,8 @@ void launch_bwd_small(const BwdArgs& a, int V, int gy, bool dfeat, hipStream_t s
     // wait for (the fused-loss kernel fits 3 workgroups per CU: 768 of H36M's 1 088 at once)
     dim3 grid(a.P, V, BWD_SPLITS);
     if (a.P <= 64 && !(a.flags & (1u << 20))) {  // wave-resident variant (bit 20: force the LDS variant, tests)
-        if (dfeat) hipLaunchKernelGGL((k_render_bwd_wave<CG, true, false>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((k_render_bwd_wave<CG, false, false>), grid, dim3(256), 0, st, a);
+        if (dfeat) hipLaunchKernelGGL((k_render_bwd_wave<CG, true, false>), grid, dim3(256), 0, st, a, vt, vo);
+        else hipLaunchKernelGGL((k_render_bwd_wave<CG, false, false>), grid, dim3(256), 0, st, a, vt, vo);
         return;
     }
     const size_t lds = GatherLds<CG>::bytes((a.P + 15) & ~15, CG, a.C);
@@ -156,7 +164,7 @@ void sks_set_error_(const char* msg)  // used by the other translation units of 
 {
     snprintf(g_err, sizeof(g_err), "%s", msg);
 }
-int sks_version(void) { return 1; }
+int sks_version(void) { return 2; }
 
 int sks_scratch_bytes(int V, int P, int C, int W, int H, size_t bin_capacity, size_t* geom, size_t* binning, size_t* accum)
 {
@@ -189,7 +197,8 @@ int sks_forward(int V, int P, int C, int W, int H, const float* viewmatrix, cons
         return fail(-2, "missing required pointer");
     if (!cov3D_precomp && (!scales || !rotations)) return fail(-2, "need scales+rotations or cov3D_precomp");
     ViewTan vt;
-    for (int v = 0; v < V; v++) { vt.x[v] = tanfovx[v]; vt.y[v] = tanfovy[v]; }
+    ViewOff vo;
+    fill_views(vt, &vo, V, C, W, H, tanfovx, tanfovy, nullptr, nullptr);
     Geom g = geom_from(geom, V, P, W, H);
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE, NT = gx * gy;
 
@@ -257,7 +266,8 @@ int sks_backward(int V, int P, int C, int W, int H, const float* viewmatrix, con
         return fail(-2, "missing required pointer");
     if (!cov3D_precomp && (!scales || !rotations)) return fail(-2, "need scales+rotations or cov3D_precomp");
     ViewTan vt;
-    for (int v = 0; v < V; v++) { vt.x[v] = tanfovx[v]; vt.y[v] = tanfovy[v]; }
+    ViewOff vo;
+    fill_views(vt, &vo, V, C, W, H, tanfovx, tanfovy, nullptr, nullptr);
     Geom g = geom_from(const_cast<void*>(geom), V, P, W, H);
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE, NT = gx * gy;
     BwdArgs a{ P, C, W, H, flags, g, features, bg, dL_dout_color, dL_dout_invdepth, (float*)accum, nullptr, nullptr };
@@ -267,10 +277,10 @@ int sks_backward(int V, int P, int C, int W, int H, const float* viewmatrix, con
     if (small) {
         ProfScope prof(1, st);
         switch (cg) {
-            case 4: launch_bwd_small<4>(a, V, gy, dfeat, st); break;
-            case 16: launch_bwd_small<16>(a, V, gy, dfeat, st); break;
-            case 20: launch_bwd_small<20>(a, V, gy, dfeat, st); break;
-            default: launch_bwd_small<32>(a, V, gy, dfeat, st); break;
+            case 4: launch_bwd_small<4>(a, vt, vo, V, gy, dfeat, st); break;
+            case 16: launch_bwd_small<16>(a, vt, vo, V, gy, dfeat, st); break;
+            case 20: launch_bwd_small<20>(a, vt, vo, V, gy, dfeat, st); break;
+            default: launch_bwd_small<32>(a, vt, vo, V, gy, dfeat, st); break;
         }
         STAGE_CHECK("render-backward(small)");
     } else {
@@ -311,7 +321,8 @@ int sks_backward_fused_loss(int V, int P, int C, int W, int H, const float* view
                             const void* geom, const float* gt, const float* tile_S, const float* tile_N,
                             const double* gt_totals, void* accum, float* dL_dmeans3D, float* dL_dmeans2D,
                             float* dL_dopacity, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
-                            double* loss_sums, float* packed_raw_grads, void* stream)
+                            double* loss_sums, float* packed_raw_grads, const int* view_wh, const size_t* gt_offsets,
+                            void* stream)
 {
     if (int rc = check_common(V, P, C, W, H)) return rc;
     if (P < 1 || P > 64) return fail(-1, "fused-loss backward needs 1 <= P <= 64 (got %d)", P);
@@ -321,17 +332,20 @@ int sks_backward_fused_loss(int V, int P, int C, int W, int H, const float* view
         return fail(-2, "missing required pointer");
     if (!cov3D_precomp && (!scales || !rotations)) return fail(-2, "need scales+rotations or cov3D_precomp");
     ViewTan vt;
-    for (int v = 0; v < V; v++) { vt.x[v] = tanfovx[v]; vt.y[v] = tanfovy[v]; }
+    ViewOff vo;
+    if (!fill_views(vt, &vo, V, C, W, H, tanfovx, tanfovy, view_wh, gt_offsets))
+        return fail(-1, "view_wh: every view's size must be within [1, W] x [1, H] (pass the largest as W, H)");
+    if ((view_wh != nullptr) != (gt_offsets != nullptr)) return fail(-2, "view_wh and gt_offsets go together");
     Geom g = geom_from(const_cast<void*>(geom), V, P, W, H);
     BwdArgs a{ P, C, W, H, flags | SKS_CLAMP01, g, features, bg, gt, nullptr, (float*)accum, tile_S, tile_N };
     dim3 grid(P, V, BWD_SPLITS);   // see launch_bwd_small
     {
         ProfScope prof(1, st);
         switch (pick_cg(C)) {
-            case 4: hipLaunchKernelGGL((k_render_bwd_wave<4, false, true>), grid, dim3(256), 0, st, a); break;
-            case 16: hipLaunchKernelGGL((k_render_bwd_wave<16, false, true>), grid, dim3(256), 0, st, a); break;
-            case 20: hipLaunchKernelGGL((k_render_bwd_wave<20, false, true>), grid, dim3(256), 0, st, a); break;
-            default: hipLaunchKernelGGL((k_render_bwd_wave<32, false, true>), grid, dim3(256), 0, st, a); break;
+            case 4: hipLaunchKernelGGL((k_render_bwd_wave<4, false, true>), grid, dim3(256), 0, st, a, vt, vo); break;
+            case 16: hipLaunchKernelGGL((k_render_bwd_wave<16, false, true>), grid, dim3(256), 0, st, a, vt, vo); break;
+            case 20: hipLaunchKernelGGL((k_render_bwd_wave<20, false, true>), grid, dim3(256), 0, st, a, vt, vo); break;
+            default: hipLaunchKernelGGL((k_render_bwd_wave<32, false, true>), grid, dim3(256), 0, st, a, vt, vo); break;
         }
     }
     STAGE_CHECK("fused loss + render-backward");
@@ -346,7 +360,7 @@ int sks_backward_fused_loss(int V, int P, int C, int W, int H, const float* view
 int sks_geometry(int V, int P, int C, int W, int H, const float* viewmatrix, const float* projmatrix, const float* tanfovx,
                  const float* tanfovy, const float* means3D, const float* opacities, const float* scales,
                  const float* rotations, const float* cov3D_precomp, float scale_modifier, unsigned flags, int* radii,
-                 void* geom, void* stream)
+                 void* geom, const int* view_wh, void* stream)
 {
     if (int rc = check_common(V, P, C, W, H)) return rc;
     if (P < 1) return fail(-1, "P must be positive");
@@ -355,8 +369,10 @@ int sks_geometry(int V, int P, int C, int W, int H, const float* viewmatrix, con
     if (!cov3D_precomp && (!scales || !rotations)) return fail(-2, "need scales+rotations or cov3D_precomp");
     hipStream_t st = (hipStream_t)stream;
     ViewTan vt;
-    for (int v = 0; v < V; v++) { vt.x[v] = tanfovx[v]; vt.y[v] = tanfovy[v]; }
+    if (!fill_views(vt, nullptr, V, C, W, H, tanfovx, tanfovy, view_wh, nullptr))
+        return fail(-1, "view_wh: every view's size must be within [1, W] x [1, H] (pass the largest as W, H)");
     Geom g = geom_from(geom, V, P, W, H);
+    if (view_wh) g.cover = nullptr;   // the cover rows serve the dense forward, which needs one image size
     hipLaunchKernelGGL(k_geom_fwd, dim3((P + 255) / 256, V), dim3(256), 0, st, P, W, H, vt, viewmatrix, projmatrix,
                        means3D, opacities, scales, rotations, cov3D_precomp, scale_modifier, flags, g, radii);
     STAGE_CHECK("geometry");
@@ -369,7 +385,7 @@ int sks_loop_fused_step(int V, int P, int C, int W, int H, const float* viewmatr
                         double* loss_sums, float* packed, float* slots, unsigned long long group_mask, int last_view,
                         float* xyz, float* scaling, float* rotation, float* opacity, float* exp_avg, float* exp_avg_sq,
                         int* counters, int acc_steps, const double* lr_sched, const double* lrs, const double* adam,
-                        float lambda_consistency, const int* limb, void* stream)
+                        float lambda_consistency, const int* limb, const int* view_wh, const size_t* gt_offsets, void* stream)
 {
     if (int rc = check_common(V, P, C, W, H)) return rc;
     if (P < 1 || P > 64) return fail(-1, "fused step needs 1 <= P <= 64 (got %d)", P);
@@ -378,7 +394,10 @@ int sks_loop_fused_step(int V, int P, int C, int W, int H, const float* viewmatr
         return fail(-2, "missing required pointer");
     hipStream_t st = (hipStream_t)stream;
     ViewTan vt;
-    for (int v = 0; v < V; v++) { vt.x[v] = tanfovx[v]; vt.y[v] = tanfovy[v]; }
+    ViewOff vo;
+    if (!fill_views(vt, &vo, V, C, W, H, tanfovx, tanfovy, view_wh, gt_offsets))
+        return fail(-1, "view_wh: every view's size must be within [1, W] x [1, H] (pass the largest as W, H)");
+    if ((view_wh != nullptr) != (gt_offsets != nullptr)) return fail(-2, "view_wh and gt_offsets go together");
     flags |= SKS_RAW_PARAMS | SKS_CLAMP01;
     sksloop::AdamArgs aa;
     if (const char* err = sksloop::fill_adam_args(aa, V, P, packed, slots, group_mask, last_view, xyz, scaling, rotation, opacity,
@@ -392,10 +411,10 @@ int sks_loop_fused_step(int V, int P, int C, int W, int H, const float* viewmatr
     {
         ProfScope prof(1, st);
         switch (pick_cg(C)) {
-            case 4: hipLaunchKernelGGL((k_render_bwd_wave<4, false, true>), grid, dim3(256), 0, st, a); break;
-            case 16: hipLaunchKernelGGL((k_render_bwd_wave<16, false, true>), grid, dim3(256), 0, st, a); break;
-            case 20: hipLaunchKernelGGL((k_render_bwd_wave<20, false, true>), grid, dim3(256), 0, st, a); break;
-            default: hipLaunchKernelGGL((k_render_bwd_wave<32, false, true>), grid, dim3(256), 0, st, a); break;
+            case 4: hipLaunchKernelGGL((k_render_bwd_wave<4, false, true>), grid, dim3(256), 0, st, a, vt, vo); break;
+            case 16: hipLaunchKernelGGL((k_render_bwd_wave<16, false, true>), grid, dim3(256), 0, st, a, vt, vo); break;
+            case 20: hipLaunchKernelGGL((k_render_bwd_wave<20, false, true>), grid, dim3(256), 0, st, a, vt, vo); break;
+            default: hipLaunchKernelGGL((k_render_bwd_wave<32, false, true>), grid, dim3(256), 0, st, a, vt, vo); break;
         }
     }
     STAGE_CHECK("render-backward(fused loss)");

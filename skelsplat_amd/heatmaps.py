@@ -60,15 +60,39 @@ def heatmap_factors(means, scaling, rotation_raw, poses_2d, cameras, scaling_mod
     return row, col, cmin, den
 
 
+def draw_dropout(n_views, n_joints, generator=None):
+    """The reference's heat-map dropout (general_utils.py:267-283, `training.dropout`): three camera indices from
+    torch.randint(4, (3,)) and three joint indices from torch.randint(n_joints, (3,)) -- the same two draws from the same
+    (default, CPU) generator -- and in those cameras those joints get NO impulse, so their planes stay zero.  Returns the
+    (n_views, n_joints) bool mask of dropped planes."""
+    cams = torch.randint(4, (3,), generator=generator)
+    joints = torch.randint(n_joints, (3,), generator=generator)
+    mask = torch.zeros((n_views, n_joints), dtype=torch.bool)
+    for c in cams.tolist():
+        if c < n_views:
+            mask[c, joints] = True
+    return mask
+
+
 def generate_heatmaps(means, scaling, rotation_raw, poses_2d, cameras, scaling_modifier=1.0, out=None, views=None,
-                      totals=None):
+                      totals=None, dropout=False, drop_mask=None):
     """(V, J, H, W) normalised heat-maps on the parameters' ROCm device; all cameras must share (W, H).  poses_2d:
     (V, J, 2) pixel (x, y).  general_utils.py:175-304 with dropout=False, as two launches (sks_heatmap_factors, then the
     planes by the streaming kernel sks_heatmaps).  `out`: optional (V,J,H,W) fp32 buffer to write into (scene
     streaming: same storage for every frame); `totals`: optional (V,2) fp64 tensor that receives each view's
-    {sum gt^2, count gt > 0} (rasterizer.GtStats.totals) while the planes are written, instead of a separate pass."""
+    {sum gt^2, count gt > 0} (rasterizer.GtStats.totals) while the planes are written, instead of a separate pass.
+    `dropout=True` draws the reference's dropped (camera, joint) planes (draw_dropout); `drop_mask` (V,J) bool gives them
+    explicitly.  A dropped plane has no impulse: it is all zero before and after normalize_heatmaps (0 / 1e-8), which the
+    separable form states as row = 0, cmin = 0, den = 1."""
     from . import _lib
     row, col, cmin, den = heatmap_factors(means, scaling, rotation_raw, poses_2d, cameras, scaling_modifier, views=views)
+    if dropout and drop_mask is None:
+        drop_mask = draw_dropout(row.shape[0], row.shape[1])
+    if drop_mask is not None:
+        dm = torch.as_tensor(drop_mask, dtype=torch.bool).to(row.device)
+        row.masked_fill_(dm[:, :, None], 0.0)
+        cmin.masked_fill_(dm, 0.0)
+        den.masked_fill_(dm, 1.0)
     V, J, H = row.shape
     W = col.shape[2]
     if out is None:

@@ -64,14 +64,50 @@ def activation_chain(gm, g):
     return d_scaling, d_rotation, d_opacity
 
 
+class OptEarlyStopping:
+    """utils/general_utils.py:467-491: stop when the last `window_size` losses repeat the `window_size` before them to
+    within `repeat_tolerance` (compared as fp32 tensors, like the reference's torch.tensor(list) of loss.item())."""
+
+    def __init__(self, window_size=4, repeat_tolerance=1e-6):
+        self.window_size = window_size
+        self.repeat_tolerance = repeat_tolerance
+        self.loss_history = []
+
+    def __call__(self, current_loss):
+        self.loss_history.append(current_loss)
+        if len(self.loss_history) < 2 * self.window_size:
+            return False
+        w1 = torch.tensor(self.loss_history[-2 * self.window_size:-self.window_size])
+        w2 = torch.tensor(self.loss_history[-self.window_size:])
+        return bool(torch.all(torch.abs(w1 - w2) < self.repeat_tolerance))
+
+
+class NotStopping:
+    """utils/general_utils.py:493-498."""
+
+    def __call__(self, current_loss):
+        return False
+
+
+early_stopping_strategy = {"opt_early_stopping": OptEarlyStopping, "no_stopping": NotStopping}   # utils/__init__.py:31-34
+
+
 class MultiViewLoop:
-    """One scene.  `heatmaps`: (V,C,H,W) pseudo-GT on this rank's device (only the local views are read).
+    """One scene.  `heatmaps`: (V,C,H,W) pseudo-GT on this rank's device, or a list of V (C,H_v,W_v) tensors when the
+    cameras differ in size (only the local views are read).
     `loss_grad`: callable (render, gt) -> (dL_unscaled, per-view loss, per-view scale); default: the fused HIP kernel
-    (ops.masked_l2_grad_fused); loop.masked_l2_grad_torch is the same thing in tensor ops."""
+    (ops.masked_l2_grad_fused); loop.masked_l2_grad_torch is the same thing in tensor ops.
+    `shard_views=False`: this process runs all V views itself even when torch.distributed is initialised (frame
+    sharding: every rank optimises its own frames, no communication at all -- SURVEY §8e axis 2).
+    `early_stopping`: a key of `early_stopping_strategy` (configs/*.yaml `training.early_stopping`) or a callable
+    loss -> bool; anything but "no_stopping" makes the host read the group's losses (one sync per group), so it
+    excludes use_graph."""
 
     def __init__(self, gaussians, cameras, heatmaps, dataset="h36m", accumulation_steps=4, lambda_consistency=1e-5,
                  bg=None, antialiasing=False, loss_grad=None, group=None, view_grad_fn=None, device_tail=None,
-                 use_graph=False, sparse=None, fused_tail=None):
+                 use_graph=False, sparse=None, fused_tail=None, shard_views=True, graph_collectives=None,
+                 early_stopping="no_stopping"):
+        import os
         self.gm = gaussians
         self.dataset = dataset
         self.V = len(cameras)
@@ -79,8 +115,12 @@ class MultiViewLoop:
         self.lambda_consistency = float(lambda_consistency)
         self.antialiasing = antialiasing
         self.group = group
-        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
-        self.rank = dist.get_rank(group) if self.world > 1 else 0
+        sharded = bool(shard_views) and dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if sharded else 1
+        self.rank = dist.get_rank(group) if sharded else 0
+        # the exchange step runs whenever views are sharded over a process group -- also a group of ONE rank, which is how
+        # the single-GPU tests drive the very code path 8 GPUs take (RCCL all_gather included)
+        self.exchange = sharded
         dev = gaussians._xyz.device
         self.device = dev
         self.local_ids = [v for v in range(self.V) if v % self.world == self.rank]
@@ -88,33 +128,45 @@ class MultiViewLoop:
         # only the multi-process CPU tests use it (gloo has no GPU), the product path is _local_view_grads.
         self.view_grad_fn = view_grad_fn
         self.cameras = cameras
-        # `heatmaps`: one (V,C,H,W) tensor, or a list of V (C,H_v,W_v) tensors when the cameras differ in size
-        # (H36M mixes 1000x1000 and 1002x1000 sensors, quirk Q11).  Local views are grouped by image size; every
-        # size group is one batched launch sequence.  self.order = local slot -> position in the concatenated groups.
-        hm_of = (lambda v: heatmaps[v])
-        by_size = {}
-        for k, v in enumerate(self.local_ids):
-            key = (int(cameras[v].image_width), int(cameras[v].image_height))
-            by_size.setdefault(key, []).append(k)
-        self.size_groups = []   # (local slots, ViewBatch or None, gt (Vg,C,H,W), stats or None)
-        for key, slots in by_size.items():
-            vb = (R.ViewBatch.from_cameras([cameras[self.local_ids[k]] for k in slots]) if view_grad_fn is None else None)
-            gt = torch.stack([hm_of(self.local_ids[k]) for k in slots]).contiguous()
-            self.size_groups.append([slots, vb, gt, None])
-        self.gt = self.size_groups[0][2] if len(self.size_groups) == 1 else None   # single-size convenience (tests, view_grad_fn)
-        self.views = self.size_groups[0][1] if len(self.size_groups) == 1 else None
+        P = gaussians._xyz.shape[0]
+        self.P = P
+        Vl = len(self.local_ids)
+        # Local heat-maps live in ONE flat buffer (rasterizer.HeatmapSet): views of one size are adjacent -- a (Vg,C,H,W)
+        # tensor for the dense entry points -- and the sparse fused step addresses all of them, whatever their sizes,
+        # through per-view offsets in a single launch (H36M mixes 1000x1000 and 1002x1000 sensors, quirk Q11).
+        sizes = [(int(cameras[v].image_width), int(cameras[v].image_height)) for v in self.local_ids]
+        if torch.is_tensor(heatmaps) and heatmaps.dim() == 4 and Vl == self.V and heatmaps.is_contiguous() \
+                and heatmaps.dtype == torch.float32 and len(set(sizes)) == 1:
+            self.hset = R.HeatmapSet.adopt(heatmaps)            # all views local, one size: no copy
+        elif Vl:
+            C_hm = int(heatmaps[self.local_ids[0]].shape[0])
+            self.hset = R.HeatmapSet(sizes, C_hm, heatmaps[self.local_ids[0]].device)
+            for k, v in enumerate(self.local_ids):
+                self.hset.planes[k].copy_(heatmaps[v])
+        else:
+            self.hset = None
+        # size groups: local slots per image size, each one batched launch sequence of the DENSE path (and of the
+        # per-frame heat-map generation); entries: [slots, ViewBatch, gt (Vg,C,H,W), GtStats or None, slot index tensor]
+        self.size_groups = []
+        if self.hset is not None:
+            for key, slots in self.hset.groups.items():
+                vb = (R.ViewBatch.from_cameras([cameras[self.local_ids[k]] for k in slots]) if view_grad_fn is None else None)
+                idx = torch.tensor(slots, dtype=torch.long, device=dev)
+                self.size_groups.append([slots, vb, self.hset.group(key), None, idx])
+        single = len(self.size_groups) == 1
+        self.gt = self.size_groups[0][2] if single else None   # single-size convenience (tests, view_grad_fn)
+        self.views = self.size_groups[0][1] if single else None
         self.bg = bg
         default_loss = loss_grad is None
         if loss_grad is None and view_grad_fn is None:
             from .ops import masked_l2_grad_fused
             loss_grad = masked_l2_grad_fused
         self.loss_grad = loss_grad
-        P = gaussians._xyz.shape[0]
-        self.P = P
         # V-slot buffer of per-view xyz gradients (train.py:121); persists across groups (quirk Q8)
         self.accumulated_grads = torch.zeros((self.V, P, 3), device=dev)
         self.iteration = 0
         self.last_losses = None
+        self.stopped_at = None       # iteration at which early stopping ended the scene (train.py:155,227-233)
         # all_gather needs equal shard sizes: pad every rank to ceil(V / world) views
         self.vmax = (self.V + self.world - 1) // self.world
         # device-side tail (sks_loop_pack_grads + sks_loop_adam_step): default whenever the HIP path is used with the
@@ -122,19 +174,41 @@ class MultiViewLoop:
         if device_tail is None:
             device_tail = view_grad_fn is None and default_loss and dev.type == "cuda" and P <= 256
         self.device_tail = bool(device_tail)
-        self.use_graph = bool(use_graph) and self.device_tail and self.world == 1
+        if callable(early_stopping):
+            self.early_stopping = early_stopping
+        else:
+            self.early_stopping = early_stopping_strategy[early_stopping]()
+        self._stopping = not isinstance(self.early_stopping, NotStopping)
+        if self._stopping and use_graph:
+            raise ValueError("early stopping reads every iteration's loss on the host (train.py:155): use_graph must be False")
+        # hipGraph capture of a group that contains the RCCL all_gather: opt-in (graph_collectives=True or
+        # SKS_GRAPH_COLLECTIVES=1); the sequence itself is fixed and allocation-free either way
+        if graph_collectives is None:
+            graph_collectives = os.environ.get("SKS_GRAPH_COLLECTIVES") == "1"
+        self.use_graph = bool(use_graph) and self.device_tail and (not self.exchange or bool(graph_collectives))
         self._graph = None
         # sparse fused step: render + clamp + masked-L2 + backward only on the tiles some Gaussian rect covers, using
-        # per-tile statistics of the constant heat-maps (sks_gt_tile_stats); no dense image / gradient is ever written
+        # per-view statistics of the constant heat-maps (sks_gt_tile_stats); no dense image / gradient is ever written
         if sparse is None:
             sparse = self.device_tail and P <= 64
         self.sparse = bool(sparse) and self.device_tail and P <= 64
-        if self.sparse:
+        self.views_all = None        # sparse path: ALL local views in one batch (sizes may differ)
+        self.stats_all = None
+        if self.sparse and Vl:
             for grp in self.size_groups:
                 grp[3] = R.gt_tile_stats(grp[2])
+            if single:
+                self.views_all, self.stats_all = self.size_groups[0][1], self.size_groups[0][3]
+            else:
+                self.views_all = R.ViewBatch.from_cameras([cameras[v] for v in self.local_ids], allow_mixed=True)
+                st = R.GtStats()
+                st.gt, st.tile_S, st.tile_N = self.hset.flat, None, None
+                st.totals = torch.empty((Vl, 2), dtype=torch.float64, device=dev)
+                st.offsets = self.hset.offsets
+                self.stats_all = st
+                self._merge_totals()
         if self.device_tail:
             import ctypes
-            from . import _lib
             cfg = gaussians.opt_cfg
             self._sched = (ctypes.c_double * 5)(cfg["lr_init"], cfg["lr_final"], cfg["lr_delay_mult"],
                                                 float(cfg["lr_delay_steps"]), float(cfg["lr_max_steps"]))
@@ -145,24 +219,43 @@ class MultiViewLoop:
             self.exp_avg = torch.zeros((P, 11), device=dev)
             self.exp_avg_sq = torch.zeros((P, 11), device=dev)
             self.counters = torch.zeros(2, dtype=torch.int32, device=dev)
-        # one GPU, one image size, sparse step: the whole group is two launches (sks_loop_fused_step); the geometry of
-        # the current parameters lives in a persistent state that every step leaves up to date for the next one
+            # persistent buffers of the group (allocated here, never inside a graph capture): this rank's packed
+            # raw-parameter gradients -- with the exchange padded to vmax rows, the pad rows stay zero for ever -- and what
+            # all_gather_into_tensor leaves, which sks_loop_adam_step reads in place (rank-major layout, `shard_world`)
+            self._shard = torch.zeros((self.vmax if self.exchange else max(Vl, 1), P, 11), device=dev)
+            self._allg = torch.empty((self.world * self.vmax, P, 11), device=dev) if self.exchange else None
+            self._sums = torch.zeros((max(Vl, 1), 2), dtype=torch.float64, device=dev)
+            self._sums_all = (torch.zeros((self.world * self.vmax, 2), dtype=torch.float64, device=dev)
+                              if self.exchange and self._stopping else None)
+            if self.exchange:
+                # RCCL builds its communicator on the first collective: do that here, eagerly, never inside a graph
+                # capture or a timed step (the gathered rows are overwritten by every group)
+                dist.all_gather_into_tensor(self._allg, self._shard, group=self.group)
+        elif self._stopping:
+            raise ValueError("early stopping is implemented on the device-tail path (default loss, ROCm tensors)")
+        # one GPU, sparse step: the whole group is two launches (sks_loop_fused_step); the geometry of the current
+        # parameters lives in a persistent state that every step leaves up to date for the next one
         # (the single-workgroup tail walks the views four at a time: a win for a handful of views -- H36M's 4 --, a loss
         # for Panoptic's 31, where the one-block-per-view kernels stay)
-        self.fused_tail = (self.sparse and self.world == 1 and len(self.size_groups) == 1 and bg is None
+        self.fused_tail = (self.sparse and not self.exchange and Vl > 0 and bg is None and not self._stopping
                            and (fused_tail is True or (fused_tail is None and self.V <= 8)))
         self._fstate = None          # persistent ForwardState (geom + radii) of the fused tail
         self._geom_valid = False     # does it describe the current parameters?
         if self.fused_tail:          # persistent buffers are allocated here, never inside a graph capture
-            slots, vb, gt, stats = self.size_groups[0]
             with torch.no_grad():
-                self._fstate = R.geometry_views(vb, gaussians._xyz.detach(), gaussians.get_features.reshape(P, -1).shape[1],
-                                                gaussians._opacity, gaussians._scaling, gaussians._rotation, None,
+                self._fstate = R.geometry_views(self.views_all, gaussians._xyz.detach(),
+                                                gaussians.get_features.reshape(P, -1).shape[1], gaussians._opacity,
+                                                gaussians._scaling, gaussians._rotation, None,
                                                 antialiasing=self.antialiasing, raw_params=True)
-            self._fbuf = (torch.empty((self.V, P, 11), device=dev), torch.empty((self.V, 2), dtype=torch.float64, device=dev))
+            self._fbuf = (self._shard, self._sums)
+
+    def _merge_totals(self):
+        """Mixed sizes: the per-size-group heat-map totals -> the (V_local,2) table of the all-views batch."""
+        for slots, vb, gt, stats, idx in self.size_groups:
+            self.stats_all.totals.index_copy_(0, idx, stats.totals)
 
     # -- scene streaming ---------------------------------------------------------------------------------------
-    def new_scene(self, points, poses_2d=None, heatmaps=None):
+    def new_scene(self, points, poses_2d=None, heatmaps=None, dropout=False):
         """Next frame seen by the SAME cameras (the reference's outer loop, train.py:74-99: new GaussianModel, new
         heat-maps, iteration counter back to 0).  Everything is re-initialised in place -- parameters, Adam moments,
         step counters, V-slot buffer, heat-maps and their tile statistics keep their storage -- so the hipGraphs
@@ -179,8 +272,12 @@ class MultiViewLoop:
                 self.counters.zero_()
             elif gm.optimizer is not None:
                 gm.training_setup()
+            drop = None
+            if dropout and poses_2d is not None:
+                from .heatmaps import draw_dropout
+                drop = draw_dropout(self.V, self.P)
             for grp in self.size_groups:
-                slots, vb, gt, stats = grp
+                slots, vb, gt, stats, idx = grp
                 ids = [self.local_ids[k] for k in slots]
                 if heatmaps is not None:
                     for i, v in enumerate(ids):
@@ -191,13 +288,19 @@ class MultiViewLoop:
                     fused = stats is not None and stats.tile_S is None
                     generate_heatmaps(gm._xyz.detach(), gm.get_scaling.detach(), gm._rotation.detach(), p2d,
                                       [self.cameras[v] for v in ids], out=gt, views=vb,
-                                      totals=stats.totals if fused else None)
+                                      totals=stats.totals if fused else None,
+                                      drop_mask=None if drop is None else drop[ids])
                     if fused:
                         continue
                 else:
                     raise ValueError("new_scene needs poses_2d or heatmaps")
                 if stats is not None:
                     R.gt_tile_stats(gt, out=stats)
+            if self.sparse and len(self.size_groups) > 1:
+                self._merge_totals()
+        if isinstance(self.early_stopping, (OptEarlyStopping, NotStopping)):
+            self.early_stopping = type(self.early_stopping)()
+        self.stopped_at = None
         self._geom_valid = False
         self.iteration = 0    # (last_losses keeps pointing at the buffers the captured graphs write)
         return self
@@ -215,15 +318,15 @@ class MultiViewLoop:
             quats = gm.get_rotation.detach()
             packed = torch.empty((len(self.local_ids), P, 11), device=means.device)
             losses = torch.empty(len(self.local_ids), device=means.device)
-            for slots, vb, gt, _ in self.size_groups:
+            for slots, vb, gt, _, idx in self.size_groups:
                 color, inv, radii, st = R.forward_views(vb, means, feats, opac, scales, quats, None,
                                                         antialiasing=self.antialiasing, clamp01=True)
                 dL, lv, scale = self.loss_grad(color, gt)
                 g = R.backward_views(st, means, feats, opac, scales, quats, None, dL, None, bg=self.bg)
                 d_scaling, d_rotation, d_opacity = activation_chain(gm, g)
                 pk = torch.cat([g["means3D"], d_scaling, d_rotation, d_opacity], dim=-1)  # (Vg, P, 11)
-                packed[slots] = pk * scale[:, None, None]   # 1 / N_mask of each view (the backward is linear in dL)
-                losses[slots] = lv
+                packed.index_copy_(0, idx, pk * scale[:, None, None])   # 1 / N_mask of each view (the backward is linear in dL)
+                losses.index_copy_(0, idx, lv.to(losses.dtype))
         return packed, losses
 
     def _consistency_grad(self):
@@ -233,88 +336,116 @@ class MultiViewLoop:
         return gx, loss.detach()
 
     # -- device-side tail ----------------------------------------------------------------------------------
-    def _device_group(self, group_mask, last_view, n_iters):
-        """forward -> fused masked-L2 -> backward -> pack -> [all_gather] -> Adam, all enqueued, no host sync."""
+    def _device_grads(self):
+        """This rank's views -> self._shard[:V_local] (packed raw-parameter gradients) and self._sums ({S, N} per view):
+        a fixed, allocation-light launch sequence (sparse: sks_geometry + sks_backward_fused_loss for ALL local views,
+        whatever their sizes; dense: forward + masked-L2 + backward + pack per size group)."""
         from . import _lib
         from .ops import masked_l2
         lib = _lib.load()
         gm, P, dev = self.gm, self.P, self.device
+        Vl = len(self.local_ids)
         stream = torch.cuda.current_stream(dev).cuda_stream
+        means = gm._xyz.detach()
+        feats = gm.get_features.reshape(P, -1)
+        packed = self._shard[:Vl]
+        if self.sparse:
+            # leaf parameters straight into the kernels: activations, their Jacobians and the 1/N scale all run inside
+            # sks_geometry / sks_backward_fused_loss (SKS_RAW_PARAMS)
+            st = R.geometry_views(self.views_all, means, feats.shape[1], gm._opacity, gm._scaling, gm._rotation, None,
+                                  antialiasing=self.antialiasing, raw_params=True)
+            R.backward_fused_loss(st, self.stats_all, means, feats, gm._opacity, gm._scaling, gm._rotation, None,
+                                  bg=self.bg, packed_out=packed, sums_out=self._sums)
+            return
+        opac, scales, quats = gm.get_opacity.detach(), gm.get_scaling.detach(), gm.get_rotation.detach()
+        single = len(self.size_groups) == 1
+        for slots, vb, gt, stats, idx in self.size_groups:
+            color, inv, radii, st = R.forward_views(vb, means, feats, opac, scales, quats, None,
+                                                    antialiasing=self.antialiasing, clamp01=True)
+            dL, S, N = masked_l2(color, gt)
+            g = R.backward_views(st, means, feats, opac, scales, quats, None, dL, None, bg=self.bg)
+            sums = torch.stack([S, N], dim=1).contiguous()
+            Vg = len(slots)
+            pk = packed if single else torch.empty((Vg, P, 11), device=dev)
+            _lib.check(lib.sks_loop_pack_grads(Vg, P, g["means3D"].data_ptr(), g["scales"].data_ptr(),
+                                               g["rotations"].data_ptr(), g["opacities"].data_ptr(),
+                                               gm._scaling.data_ptr(), gm._rotation.data_ptr(), gm._opacity.data_ptr(),
+                                               sums.data_ptr(), pk.data_ptr(), stream), "sks_loop_pack_grads")
+            if not single:
+                packed.index_copy_(0, idx, pk)
+            self._sums[:Vl].index_copy_(0, idx, sums)
+
+    def _device_adam(self, group_mask, last_view, n_iters):
+        """[all_gather of the shards ->] sks_loop_adam_step on the view-major (one rank) or rank-major (gathered) table."""
+        from . import _lib
+        lib = _lib.load()
+        gm, dev = self.gm, self.device
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        if self.exchange:
+            # every rank needs every view's gradients (train.py:175, 215-218): ONE all_gather of the padded shards over
+            # RCCL; the optimiser kernel reads the gathered buffer in place (view v = row (v % world) * vmax + v // world)
+            dist.all_gather_into_tensor(self._allg, self._shard, group=self.group)
+            full, world = self._allg, self.world
+        else:
+            full, world = self._shard, 1
+        _lib.check(lib.sks_loop_adam_step(self.V, self.P, full.data_ptr(), self.accumulated_grads.data_ptr(), group_mask,
+                                          last_view, gm._xyz.data_ptr(), gm._scaling.data_ptr(), gm._rotation.data_ptr(),
+                                          gm._opacity.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                                          self.counters.data_ptr(), n_iters, self._sched, self._lrs, self._adam,
+                                          float(self.lambda_consistency), self._limb, world, stream), "sks_loop_adam_step")
+
+    def _device_group(self, group_mask, last_view, n_iters):
+        """forward -> fused masked-L2 -> backward -> pack -> [all_gather] -> Adam, all enqueued, no host sync."""
+        gm, P = self.gm, self.P
         with torch.no_grad():
             if self.fused_tail:
-                slots, vb, gt, stats = self.size_groups[0]
                 feats = gm.get_features.reshape(P, -1)
                 if not self._geom_valid:
-                    self._fstate = R.geometry_views(vb, gm._xyz.detach(), feats.shape[1], gm._opacity, gm._scaling, gm._rotation,
-                                                    None, antialiasing=self.antialiasing, raw_params=True, out=self._fstate)
+                    self._fstate = R.geometry_views(self.views_all, gm._xyz.detach(), feats.shape[1], gm._opacity, gm._scaling,
+                                                    gm._rotation, None, antialiasing=self.antialiasing, raw_params=True,
+                                                    out=self._fstate)
                     self._geom_valid = True
                 packed, sums = self._fbuf
-                R.loop_fused_step(self._fstate, stats, feats, packed, sums, self.accumulated_grads, group_mask, last_view,
-                                  gm._xyz, gm._scaling, gm._rotation, gm._opacity, self.exp_avg, self.exp_avg_sq, self.counters,
-                                  n_iters, self._sched, self._lrs, self._adam, float(self.lambda_consistency), self._limb)
+                R.loop_fused_step(self._fstate, self.stats_all, feats, packed, sums, self.accumulated_grads, group_mask,
+                                  last_view, gm._xyz, gm._scaling, gm._rotation, gm._opacity, self.exp_avg, self.exp_avg_sq,
+                                  self.counters, n_iters, self._sched, self._lrs, self._adam, float(self.lambda_consistency),
+                                  self._limb)
                 self.last_losses = (sums[:, 0], sums[:, 1])
                 return
             if self.local_ids:
-                means = gm._xyz.detach()
-                feats = gm.get_features.reshape(P, -1)
-                if not self.sparse:
-                    opac, scales, quats = gm.get_opacity.detach(), gm.get_scaling.detach(), gm.get_rotation.detach()
+                self._device_grads()
                 Vl = len(self.local_ids)
-                packed = torch.empty((self.vmax if self.world > 1 else Vl, P, 11), device=dev)
-                if self.world > 1 and Vl < self.vmax:
-                    packed[Vl:].zero_()
-                single = len(self.size_groups) == 1
-                all_sums = None if single else torch.empty((Vl, 2), dtype=torch.float64, device=dev)
-                for slots, vb, gt, stats in self.size_groups:
-                    if self.sparse:
-                        # leaf parameters straight into the kernels: activations, their Jacobians and the 1/N scale
-                        # all run inside sks_geometry / sks_backward_fused_loss (SKS_RAW_PARAMS)
-                        st = R.geometry_views(vb, means, feats.shape[1], gm._opacity, gm._scaling, gm._rotation, None,
-                                              antialiasing=self.antialiasing, raw_params=True)
-                        pk = packed if single else torch.empty((len(slots), P, 11), device=dev)
-                        g, sums = R.backward_fused_loss(st, stats, means, feats, gm._opacity, gm._scaling, gm._rotation,
-                                                        None, bg=self.bg, packed_out=pk)
-                        if single:
-                            all_sums = sums
-                        else:
-                            packed[slots] = pk
-                            all_sums[slots] = sums
-                        continue
-                    else:
-                        color, inv, radii, st = R.forward_views(vb, means, feats, opac, scales, quats, None,
-                                                                antialiasing=self.antialiasing, clamp01=True)
-                        dL, S, N = masked_l2(color, gt)
-                        g = R.backward_views(st, means, feats, opac, scales, quats, None, dL, None, bg=self.bg)
-                        sums = torch.stack([S, N], dim=1).contiguous()
-                    Vg = len(slots)
-                    pk = packed if single else torch.empty((Vg, P, 11), device=dev)
-                    _lib.check(lib.sks_loop_pack_grads(Vg, P, g["means3D"].data_ptr(), g["scales"].data_ptr(),
-                                                       g["rotations"].data_ptr(), g["opacities"].data_ptr(),
-                                                       gm._scaling.data_ptr(), gm._rotation.data_ptr(), gm._opacity.data_ptr(),
-                                                       sums.data_ptr(), pk.data_ptr(), stream), "sks_loop_pack_grads")
-                    if single:
-                        all_sums = sums
-                    else:
-                        packed[slots] = pk
-                        all_sums[slots] = sums
-                self.last_losses = (all_sums[:, 0], all_sums[:, 1])
-            else:
-                packed = torch.zeros((self.vmax, P, 11), device=dev)
-            if self.world > 1:
-                allg = torch.empty((self.world * self.vmax, P, 11), device=dev)
-                dist.all_gather_into_tensor(allg, packed, group=self.group)
-                full = torch.empty((self.V, P, 11), device=dev)
-                for r in range(self.world):     # rank r, slot k  <->  view r + k * world
-                    ids = [v for v in range(self.V) if v % self.world == r]
-                    if ids:
-                        full[ids] = allg[r * self.vmax:r * self.vmax + len(ids)]
-            else:
-                full = packed
-            _lib.check(lib.sks_loop_adam_step(self.V, P, full.data_ptr(), self.accumulated_grads.data_ptr(), group_mask,
-                                              last_view, gm._xyz.data_ptr(), gm._scaling.data_ptr(), gm._rotation.data_ptr(),
-                                              gm._opacity.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
-                                              self.counters.data_ptr(), n_iters, self._sched, self._lrs, self._adam,
-                                              float(self.lambda_consistency), self._limb, stream), "sks_loop_adam_step")
+                self.last_losses = (self._sums[:Vl, 0], self._sums[:Vl, 1])
+            if self._stopping:
+                group_mask, last_view, n_iters = self._early_stop_cut(group_mask, last_view, n_iters)
+            self._device_adam(group_mask, last_view, n_iters)
+
+    def _early_stop_cut(self, group_mask, last_view, n_iters):
+        """train.py:155-233 with the group's views batched: feed the criterion the losses of the group's iterations in
+        order; if it fires at the k-th, only the first k views' slots are refreshed, view k's scaling / rotation /
+        opacity gradients win, the optimiser steps at once and the scene ends.  One host sync per group."""
+        Vl = len(self.local_ids)
+        if self.exchange:
+            pad = torch.zeros((self.vmax, 2), dtype=torch.float64, device=self.device)
+            pad[:Vl] = self._sums[:Vl]
+            dist.all_gather_into_tensor(self._sums_all, pad, group=self.group)
+            rows = [(v % self.world) * self.vmax + v // self.world for v in range(self.V)]
+            sums = self._sums_all[rows].cpu()
+        else:
+            sums = self._sums[:Vl].cpu()
+        l2 = (sums[:, 0] / sums[:, 1].clamp_min(1.0)).to(torch.float32)
+        cons = torch.zeros((), dtype=torch.float32)
+        if self.lambda_consistency != 0.0:
+            cons = (limb_3d_consistency_loss(self.gm._xyz.detach(), self.dataset) * self.lambda_consistency).float().cpu()
+        it0 = self.iteration + 1
+        mask = 0
+        for k in range(n_iters):
+            v = (it0 + k - 1) % self.V
+            mask |= 1 << v
+            if self.early_stopping(float(l2[v] + cons)):
+                self.stopped_at = it0 + k
+                return mask, v, k + 1
+        return group_mask, last_view, n_iters
 
     def step_group(self):
         """Runs iterations self.iteration+1 .. up to the next optimiser step (train.py:130-222)."""
@@ -324,6 +455,8 @@ class MultiViewLoop:
         while it1 % self.acc_steps != 0:
             it1 += 1
         view_of_iter = [(it - 1) % self.V for it in range(it0, it1 + 1)]   # train.py:136-138
+        if self.stopped_at is not None:
+            return self.iteration
         if self.device_tail:
             mask = 0
             for v in view_of_iter:
@@ -331,7 +464,7 @@ class MultiViewLoop:
             key = (mask, view_of_iter[-1], it1 - it0 + 1)
             if self.use_graph:
                 if self._graph is None or self._graph[0] != key:
-                    # warm up on a side stream, then capture one group; replays advance the device counters themselves
+                    # capture one group; replays advance the device counters themselves
                     graph = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(graph):
                         self._geom_valid = False    # (see run(): a replay never assumes who ran before it)
@@ -341,8 +474,8 @@ class MultiViewLoop:
             else:
                 self._geom_valid = False    # eager steps never assume the parameters were left untouched since the last one
                 self._device_group(*key)
-            self.iteration = it1
-            return it1
+            self.iteration = it1 if self.stopped_at is None else self.stopped_at
+            return self.iteration
         if not self.local_ids:
             packed, losses = None, None
         elif self.view_grad_fn is not None:
@@ -350,18 +483,17 @@ class MultiViewLoop:
         else:
             packed, losses = self._local_view_grads()
         dev = self.device
-        if self.world > 1:
+        if self.exchange:
             shard = torch.zeros((self.vmax, self.P, 11), device=dev)
             if packed is not None:
                 shard[:packed.shape[0]] = packed
             allg = torch.empty((self.world * self.vmax, self.P, 11), device=dev)
             dist.all_gather_into_tensor(allg, shard, group=self.group)
-            # rank r, slot k  <->  view r + k * world
-            full = torch.zeros((self.V, self.P, 11), device=dev)
-            for r in range(self.world):
-                ids = [v for v in range(self.V) if v % self.world == r]
-                if ids:
-                    full[ids] = allg[r * self.vmax:r * self.vmax + len(ids)]
+            # rank r, slot k  <->  view r + k * world: one precomputed row index, view order
+            if getattr(self, "_rows", None) is None:
+                self._rows = torch.tensor([(v % self.world) * self.vmax + v // self.world for v in range(self.V)],
+                                          dtype=torch.long, device=dev)
+            full = allg.index_select(0, self._rows)
         else:
             full = packed
         gcons, _ = self._consistency_grad() if self.lambda_consistency != 0.0 else (0.0, None)
@@ -388,7 +520,8 @@ class MultiViewLoop:
         """Runs the loop up to `iterations`.  With use_graph, `groups_per_graph` consecutive accumulation groups are
         captured into ONE hipGraph (the step has no host state: counters, LR schedule and Adam live on the device), so
         a 500-iteration scene is a handful of graph launches."""
-        if self.use_graph and self.acc_steps % self.V == 0 and self.iteration % self.acc_steps == 0:
+        if self.use_graph and self.acc_steps % self.V == 0 and self.iteration % self.acc_steps == 0 \
+                and self.stopped_at is None:
             mask = (1 << self.V) - 1
             key = (mask, (self.acc_steps - 1) % self.V, self.acc_steps)
             remaining = (iterations - self.iteration) // self.acc_steps
@@ -408,7 +541,7 @@ class MultiViewLoop:
                     self._multi[1].replay()
                     self.iteration += G * self.acc_steps
                     remaining -= G
-        while self.iteration < iterations:
+        while self.iteration < iterations and self.stopped_at is None:
             self.step_group()
         return self.gm._xyz.detach()
 

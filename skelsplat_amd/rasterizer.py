@@ -54,6 +54,26 @@ def reset_scratch():
     _accum_cache.clear()
 
 
+class Workspace:
+    """Reusable outputs and scratch of forward_views / backward_views.  A caller that runs the same shapes every step
+    (a training loop: train.py:130-222 renders the same cameras 500 times per frame) passes the same Workspace to every
+    call and the calls allocate nothing: a dozen caching-allocator round trips per step are ~20 us of host time next
+    to ~78 us of kernels on the H36M step.  What the calls return are the workspace's tensors: the NEXT call with the same
+    shapes overwrites them (the reference's own outputs are fresh tensors per call; callers that keep results across
+    calls simply do not pass a workspace).  Every kernel writes every element, so nothing is ever cleared."""
+
+    def __init__(self):
+        self._t = {}
+
+    def get(self, name, shape, dtype, device):
+        key = (name, tuple(shape), dtype, device)
+        t = self._t.get(key)
+        if t is None:
+            t = torch.empty(shape, dtype=dtype, device=device)
+            self._t[key] = t
+        return t
+
+
 def _need_gpu(t, name):
     if not t.is_cuda:
         raise RuntimeError(f"skelsplat_amd: `{name}` must live on a ROCm device (got {t.device}); "
@@ -70,9 +90,13 @@ def _f32c(t, name):
 
 
 class ViewBatch:
-    """V cameras that share one image size, packed for sks_forward / sks_backward."""
+    """V cameras packed for one launch sequence.  The dense entry points (sks_forward / sks_backward write and read
+    (V,C,H,W) tensors) need one image size; the sparse fused-loss path writes nothing dense and takes a batch whose
+    views differ in size (`sizes`: per-view (W, H); H36M mixes 1000- and 1002-wide sensors, dataset_readers.py:68-80):
+    then W, H are the largest and `wh` is the HOST array the C ABI's `view_wh` argument wants."""
 
-    def __init__(self, viewmatrices, projmatrices, tanfovx, tanfovy, W, H):
+    def __init__(self, viewmatrices, projmatrices, tanfovx, tanfovy, W, H, sizes=None):
+        import ctypes
         self.viewmatrix = _f32c(viewmatrices, "viewmatrix").reshape(-1, 16)
         self.projmatrix = _f32c(projmatrices, "projmatrix").reshape(-1, 16)
         self.V = self.viewmatrix.shape[0]
@@ -82,17 +106,21 @@ class ViewBatch:
         self.tanfovy = _lib.farray(tanfovy)
         assert len(tanfovx) == self.V and len(tanfovy) == self.V
         self.W, self.H = int(W), int(H)
+        self.sizes = [(self.W, self.H)] * self.V if sizes is None else [(int(w), int(h)) for w, h in sizes]
+        assert len(self.sizes) == self.V
+        self.mixed = any(sz != (self.W, self.H) for sz in self.sizes)
+        self.wh = (ctypes.c_int * (2 * self.V))(*[x for sz in self.sizes for x in sz]) if self.mixed else None
 
     @classmethod
-    def from_cameras(cls, cams):
+    def from_cameras(cls, cams, allow_mixed=False):
         import math
-        W, H = int(cams[0].image_width), int(cams[0].image_height)
-        for c in cams:
-            if int(c.image_width) != W or int(c.image_height) != H:
-                raise RuntimeError("all views of a batch must share the image size")
+        sizes = [(int(c.image_width), int(c.image_height)) for c in cams]
+        W, H = max(s[0] for s in sizes), max(s[1] for s in sizes)
+        if not allow_mixed and any(sz != (W, H) for sz in sizes):
+            raise RuntimeError("all views of a batch must share the image size")
         vm = torch.stack([c.world_view_transform.reshape(16) for c in cams])
         pm = torch.stack([c.full_proj_transform.reshape(16) for c in cams])
-        return cls(vm, pm, [math.tan(c.FoVx * 0.5) for c in cams], [math.tan(c.FoVy * 0.5) for c in cams], W, H)
+        return cls(vm, pm, [math.tan(c.FoVx * 0.5) for c in cams], [math.tan(c.FoVy * 0.5) for c in cams], W, H, sizes)
 
     @classmethod
     def from_settings(cls, rs):
@@ -108,9 +136,12 @@ class ForwardState:
 
 def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotations, cov3D_precomp,
                   scale_modifier=1.0, antialiasing=False, clamp01=False, debug=False, force_binned=False,
-                  bin_capacity=None, want_aux=False, tune_flags=0, check_capacity=True):
-    """Raw batched forward.  Returns (color (V,C,H,W), invdepth (V,1,H,W), radii (V,P) int32, state[, final_T, n_contrib])."""
+                  bin_capacity=None, want_aux=False, tune_flags=0, check_capacity=True, workspace=None):
+    """Raw batched forward.  Returns (color (V,C,H,W), invdepth (V,1,H,W), radii (V,P) int32, state[, final_T, n_contrib]).
+    `workspace`: a Workspace whose tensors receive the outputs (see there)."""
     lib = _lib.load()
+    if views.mixed:
+        raise RuntimeError("the dense forward writes one (V,C,H,W) tensor: all views of the batch must share the image size")
     if means3D is None or means3D.dim() != 2 or means3D.shape[1] != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")  # DGR/rasterize_points.cu:58-60
     _need_gpu(means3D, "means3D")
@@ -140,13 +171,18 @@ def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotati
     if binned and bin_capacity is None:
         bin_capacity = max(4096, 16 * P)
     cap = int(bin_capacity or 0)
-    gbytes, bbytes, _ = _lib.scratch_bytes(V, max(P, 1), C, W, H, cap)
-    color = torch.empty((V, C, H, W), dtype=torch.float32, device=dev)
-    invdepth = torch.empty((V, 1, H, W), dtype=torch.float32, device=dev)
-    radii = torch.empty((V, P), dtype=torch.int32, device=dev)
-    geom = torch.empty(gbytes, dtype=torch.uint8, device=dev)
-    binning = torch.empty(bbytes, dtype=torch.uint8, device=dev) if binned else None
-    nrend = torch.zeros(V + 1, dtype=torch.int32, device=dev) if binned else None
+    gbytes, bbytes, _ = _scratch_bytes_cached(V, max(P, 1), C, W, H, cap)
+    def new(name, shape, dtype):
+        if workspace is None:
+            return torch.empty(shape, dtype=dtype, device=dev)
+        return workspace.get(("fwd", name), shape, dtype, dev)
+
+    color = new("color", (V, C, H, W), torch.float32)
+    invdepth = new("invdepth", (V, 1, H, W), torch.float32)
+    radii = new("radii", (V, P), torch.int32)
+    geom = new("geom", (gbytes,), torch.uint8)
+    binning = new("binning", (bbytes,), torch.uint8) if binned else None
+    nrend = new("nrend", (V + 1,), torch.int32) if binned else None   # [0, V): written by k_bin_scan
     final_T = torch.empty((V, H, W), dtype=torch.float32, device=dev) if want_aux else None
     n_contrib = torch.empty((V, H, W), dtype=torch.int32, device=dev) if want_aux else None
     stream = torch.cuda.current_stream(dev).cuda_stream
@@ -164,13 +200,24 @@ def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotati
         if need > cap:
             return forward_views(views, means3D, features, opacities, scales, rotations, cov3D_precomp, scale_modifier,
                                  antialiasing, clamp01, debug, force_binned, int(need * 1.25) + 1024, want_aux, tune_flags,
-                                 check_capacity)
+                                 check_capacity, workspace)
     st = ForwardState()
     st.views, st.P, st.C, st.flags, st.scale_modifier = views, P, C, flags, float(scale_modifier)
     st.geom, st.binning, st.bin_capacity, st.radii, st.num_rendered_dev = geom, binning, cap, radii, nrend
     if want_aux:
         return color, invdepth, radii, st, final_T, n_contrib
     return color, invdepth, radii, st
+
+
+_SCRATCH_BYTES = {}
+
+
+def _scratch_bytes_cached(V, P, C, W, H, cap):
+    key = (V, P, C, W, H, cap)
+    r = _SCRATCH_BYTES.get(key)
+    if r is None:
+        r = _SCRATCH_BYTES[key] = _lib.scratch_bytes(V, P, C, W, H, cap)
+    return r
 
 
 _BG_CACHE = {}
@@ -202,8 +249,8 @@ def _bg_channels(bg, C, dev):
 
 
 def backward_views(st: ForwardState, means3D, features, opacities, scales, rotations, cov3D_precomp, dL_dcolor,
-                   dL_dinvdepth=None, bg=None, want_dfeatures=False, tune_flags=0):
-    """Raw batched backward: per-view gradients, dict of (V,P,...) tensors."""
+                   dL_dinvdepth=None, bg=None, want_dfeatures=False, tune_flags=0, workspace=None):
+    """Raw batched backward: per-view gradients, dict of (V,P,...) tensors (`workspace`: see Workspace)."""
     lib = _lib.load()
     if st.P == 0:
         dev, V, C = means3D.device, st.views.V, st.C
@@ -222,11 +269,14 @@ def backward_views(st: ForwardState, means3D, features, opacities, scales, rotat
     if dL_dcolor.numel() != V * C * H * W:
         raise RuntimeError("dL_dout_color has the wrong number of elements")
     bgC = _bg_channels(bg, C, dev)
-    e = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
-    out = dict(means3D=e(V, P, 3), means2D=e(V, P, 3), opacities=e(V, P, 1), cov3D=e(V, P, 6),
-               scales=e(V, P, 3) if scales is not None else None,
-               rotations=e(V, P, 4) if rotations is not None else None,
-               features=e(V, P, C) if want_dfeatures else None)
+    if workspace is None:
+        e = lambda name, *s: torch.empty(s, dtype=torch.float32, device=dev)
+    else:
+        e = lambda name, *s: workspace.get(("bwd", name), s, torch.float32, dev)
+    out = dict(means3D=e("m3", V, P, 3), means2D=e("m2", V, P, 3), opacities=e("op", V, P, 1), cov3D=e("cov", V, P, 6),
+               scales=e("sc", V, P, 3) if scales is not None else None,
+               rotations=e("rot", V, P, 4) if rotations is not None else None,
+               features=e("feat", V, P, C) if want_dfeatures else None)
     stream = torch.cuda.current_stream(dev).cuda_stream
     accum = _accum(dev, stream, V, P, C)
     with torch.cuda.device(dev):
@@ -408,8 +458,60 @@ def decode_geom(st: ForwardState):
 # ------------------------------------------------------------------------------------------------------------
 class GtStats:
     """Per-scene statistics of the constant pseudo-GT heat-maps (V,C,H,W): what the masked-L2 loss sees wherever the
-    render is zero."""
-    __slots__ = ("gt", "tile_S", "tile_N", "totals")
+    render is zero.  `offsets` (HOST size_t array or None): views of different sizes -- `gt` is then a flat fp32 buffer
+    and offsets[v] the start (in floats) of view v's (C,H_v,W_v) planes (HeatmapSet)."""
+    __slots__ = ("gt", "tile_S", "tile_N", "totals", "offsets")
+
+    def __init__(self):
+        self.offsets = None
+
+
+class HeatmapSet:
+    """The heat-maps of V views whose image sizes may differ, in ONE flat buffer (so that a single launch can address
+    all of them): `planes[v]` is view v's (C,H_v,W_v) tensor, a view into `flat`; views of equal size are adjacent, so
+    `group(key)` is a (Vg,C,H,W) tensor for the dense entry points.  offsets: HOST size_t array for the C ABI."""
+
+    def __init__(self, sizes, C, device):
+        import ctypes
+        self.sizes = [(int(w), int(h)) for w, h in sizes]
+        self.C = int(C)
+        order = {}
+        for v, sz in enumerate(self.sizes):
+            order.setdefault(sz, []).append(v)
+        self.groups = order                         # (W,H) -> views, in first-appearance order of the sizes
+        total = sum(self.C * w * h * len(vs) for (w, h), vs in order.items())
+        self.flat = torch.empty(total, dtype=torch.float32, device=device)
+        off = [0] * len(self.sizes)
+        self._group_t = {}
+        pos = 0
+        for (w, h), vs in order.items():
+            n = self.C * w * h
+            self._group_t[(w, h)] = self.flat[pos:pos + n * len(vs)].view(len(vs), self.C, h, w)
+            for i, v in enumerate(vs):
+                off[v] = pos + i * n
+            pos += n * len(vs)
+        self.offsets_list = off
+        self.offsets = (ctypes.c_size_t * len(off))(*off)
+        self.planes = [self.flat[off[v]:off[v] + self.C * w * h].view(self.C, h, w) for v, (w, h) in enumerate(self.sizes)]
+
+    def group(self, key):
+        return self._group_t[key]
+
+    @classmethod
+    def adopt(cls, tensor):
+        """A contiguous (V,C,H,W) tensor as a (single-size) set, without a copy."""
+        import ctypes
+        V, C, H, W = tensor.shape
+        self = cls.__new__(cls)
+        self.sizes, self.C = [(W, H)] * V, C
+        self.groups = {(W, H): list(range(V))}
+        self.flat = tensor.view(-1)
+        self._group_t = {(W, H): tensor}
+        n = C * H * W
+        self.offsets_list = [v * n for v in range(V)]
+        self.offsets = (ctypes.c_size_t * V)(*self.offsets_list)
+        self.planes = [tensor[v] for v in range(V)]
+        return self
 
 
 def gt_tile_stats(gt, out=None, tiles=False):
@@ -421,7 +523,7 @@ def gt_tile_stats(gt, out=None, tiles=False):
     NT = ((W + 15) // 16) * ((H + 15) // 16)
     dev = gt.device
     if out is not None:
-        if out.totals.shape != (V, 2) or out.totals.device != dev or out.gt.shape != gt.shape:
+        if out.totals.shape != (V, 2) or out.totals.device != dev or out.gt.shape != gt.shape or out.offsets is not None:
             raise ValueError("gt_tile_stats: `out` was made for another shape / device")
         st = out
     else:
@@ -459,12 +561,24 @@ def geometry_views(views: ViewBatch, means3D, C, opacities, scales, rotations, c
         rc = lib.sks_geometry(V, P, C, W, H, views.viewmatrix.data_ptr(), views.projmatrix.data_ptr(), views.tanfovx,
                               views.tanfovy, _lib.ptr(means3D), _lib.ptr(opacities), _lib.ptr(scales), _lib.ptr(rotations),
                               _lib.ptr(cov3D_precomp), float(scale_modifier), flags, radii.data_ptr(), geom.data_ptr(),
-                              torch.cuda.current_stream(dev).cuda_stream)
+                              views.wh, torch.cuda.current_stream(dev).cuda_stream)
     _lib.check(rc, "sks_geometry")
     st = ForwardState()
     st.views, st.P, st.C, st.flags, st.scale_modifier = views, P, C, flags, float(scale_modifier)
     st.geom, st.binning, st.bin_capacity, st.radii, st.num_rendered_dev = geom, None, 0, radii, None
     return st
+
+
+def _check_heatmaps(views, C, stats):
+    """The heat-maps must be what the views address: one (V,C,H,W) tensor, or (mixed sizes) a HeatmapSet's flat buffer."""
+    if views.mixed:
+        if stats.offsets is None or len(stats.offsets) != views.V:
+            raise RuntimeError("views of different sizes need heat-maps in one flat buffer with per-view offsets (HeatmapSet)")
+        need = max(int(o) + C * w * h for o, (w, h) in zip(stats.offsets, views.sizes))
+        if stats.gt.numel() < need:
+            raise RuntimeError(f"heat-map buffer of {stats.gt.numel()} floats is too small for the views ({need})")
+    elif stats.offsets is None and tuple(stats.gt.shape) != (views.V, C, views.H, views.W):
+        raise RuntimeError(f"heat-maps {tuple(stats.gt.shape)} do not match the views {(views.V, C, views.H, views.W)}")
 
 
 def loop_fused_step(st: ForwardState, stats: GtStats, features, packed, sums, slots, group_mask, last_view, xyz, scaling,
@@ -476,8 +590,7 @@ def loop_fused_step(st: ForwardState, stats: GtStats, features, packed, sums, sl
     dev = xyz.device
     V, P, C = st.views.V, st.P, st.C
     W, H = st.views.W, st.views.H
-    if tuple(stats.gt.shape) != (V, C, H, W):
-        raise RuntimeError(f"heat-maps {tuple(stats.gt.shape)} do not match the views {(V, C, H, W)}")
+    _check_heatmaps(st.views, C, stats)
     feat2 = _f32c(features, "features").reshape(P, -1)
     stream = torch.cuda.current_stream(dev).cuda_stream
     accum = _accum(dev, stream, V, P, C)
@@ -488,12 +601,12 @@ def loop_fused_step(st: ForwardState, stats: GtStats, features, packed, sums, sl
                                      accum.data_ptr(), sums.data_ptr(), packed.data_ptr(), slots.data_ptr(), group_mask,
                                      last_view, xyz.data_ptr(), scaling.data_ptr(), rotation.data_ptr(), opacity.data_ptr(),
                                      exp_avg.data_ptr(), exp_avg_sq.data_ptr(), counters.data_ptr(), acc_steps, lr_sched, lrs,
-                                     adam, float(lambda_consistency), limb, stream)
+                                     adam, float(lambda_consistency), limb, st.views.wh, stats.offsets, stream)
     _lib.check(rc, "sks_loop_fused_step")
 
 
 def backward_fused_loss(st: ForwardState, stats: GtStats, means3D, features, opacities, scales, rotations, cov3D_precomp,
-                        bg=None, packed_out=None):
+                        bg=None, packed_out=None, sums_out=None):
     """Render + clamp + masked-L2 + backward on the covered tiles only.  Returns (grads dict of (V,P,..) UNSCALED
     gradients, loss_sums (V,2) f64 = per-view {S, N}); the true gradient is grads / N_v, loss_v = S_v / N_v."""
     lib = _lib.load()
@@ -501,8 +614,7 @@ def backward_fused_loss(st: ForwardState, stats: GtStats, means3D, features, opa
     dev = means3D.device
     V, P, C = st.views.V, st.P, st.C
     W, H = st.views.W, st.views.H
-    if tuple(stats.gt.shape) != (V, C, H, W):
-        raise RuntimeError(f"heat-maps {tuple(stats.gt.shape)} do not match the views {(V, C, H, W)}")
+    _check_heatmaps(st.views, C, stats)
     feat2 = _f32c(features, "features").reshape(P, -1)
     opacities = _f32c(opacities, "opacities")
     scales, rotations, cov3D_precomp = _f32c(scales, "scales"), _f32c(rotations, "rotations"), _f32c(cov3D_precomp, "cov3D_precomp")
@@ -510,7 +622,14 @@ def backward_fused_loss(st: ForwardState, stats: GtStats, means3D, features, opa
     e = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
     out = dict(means3D=e(V, P, 3), means2D=e(V, P, 3), opacities=e(V, P, 1), cov3D=e(V, P, 6),
                scales=e(V, P, 3) if scales is not None else None, rotations=e(V, P, 4) if rotations is not None else None)
-    sums = torch.empty((V, 2), dtype=torch.float64, device=dev)
+    if sums_out is None:
+        sums = torch.empty((V, 2), dtype=torch.float64, device=dev)
+    else:
+        sums = sums_out[:V]
+        if sums.shape != (V, 2) or sums.dtype != torch.float64 or not sums.is_contiguous():
+            raise ValueError("sums_out must be a contiguous fp64 tensor with at least V rows of 2")
+    if packed_out is not None and (tuple(packed_out.shape) != (V, P, 11) or not packed_out.is_contiguous()):
+        raise ValueError(f"packed_out must be a contiguous (V,P,11) = {(V, P, 11)} tensor")
     stream = torch.cuda.current_stream(dev).cuda_stream
     accum = _accum(dev, stream, V, P, C)
     with torch.cuda.device(dev):
@@ -522,6 +641,6 @@ def backward_fused_loss(st: ForwardState, stats: GtStats, means3D, features, opa
                                          stats.totals.data_ptr(), accum.data_ptr(), _lib.ptr(out["means3D"]),
                                          _lib.ptr(out["means2D"]), _lib.ptr(out["opacities"]), _lib.ptr(out["scales"]),
                                          _lib.ptr(out["rotations"]), _lib.ptr(out["cov3D"]), sums.data_ptr(),
-                                         _lib.ptr(packed_out), stream)
+                                         _lib.ptr(packed_out), st.views.wh, stats.offsets, stream)
     _lib.check(rc, "sks_backward_fused_loss")
     return out, sums

@@ -400,6 +400,9 @@ def test_loop_with_mixed_image_sizes(device):
                                  torch.tensor(a.poses_2d[v:v + 1], device=device), [cams[v]])[0] for v in range(4)]
         loop = MultiViewLoop(gm, cams, hms, dataset="h36m", sparse=sparse)
         assert len(loop.size_groups) == 2
+        if sparse:   # one launch sequence for all four views: per-view sizes + offsets into one flat heat-map buffer
+            assert loop.views_all.mixed and loop.views_all.V == 4 and loop.fused_tail
+            assert loop.stats_all.offsets is not None and loop.stats_all.gt.numel() == 17 * 128 * (160 + 162) * 2
         loop.run(24)
         outs.append(gm._xyz.detach().cpu().clone())
     # literal reference loop on the CPU oracle
@@ -635,3 +638,170 @@ def test_knn_grid_equals_allpairs(device, P, kind):
     assert torch.equal(a, b)
     if P > 2048:
         assert torch.equal(distCUDA2(pts), b)
+
+
+# ------------------------------------------------------------------------------------------ view-sharded exchange
+@pytest.fixture
+def rccl_world1(device):
+    """A torch.distributed process group of ONE rank on RCCL: MultiViewLoop then takes the exchange branch -- padded
+    shard, all_gather_into_tensor, rank-major sks_loop_adam_step -- that 2..8 GPUs take."""
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(29600 + os.getpid() % 1000)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+    try:
+        yield dist
+    finally:
+        torch.cuda.synchronize()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["sparse", "dense", "sparse-hipgraph", "mixed-sizes"])
+def test_exchange_branch_on_rccl_equals_unsharded_loop(device, rccl_world1, mode):
+    """The production path of N > 1 GPUs at world size 1: the group runs geometry + fused backward into the padded shard,
+    ONE all_gather_into_tensor over RCCL, and the optimiser kernel on the gathered (rank-major) buffer.  Bit-identical
+    to the loop that never touches torch.distributed (shard_views=False)."""
+    from skelsplat_amd.loop import MultiViewLoop
+    from skelsplat_amd.heatmaps import generate_heatmaps
+    from skelsplat_amd.scene import SyntheticScene
+    sc, model = _make_loop_scene(device, seed=31)
+    cams = sc.cameras
+    if mode == "mixed-sizes":
+        b = SyntheticScene("h36m", n_views=4, seed=31, W=162, H=128, ring=2500.0, fx=1145.0 * 0.16 * 1.5, device=device)
+        cams = [b.cameras[0], sc.cameras[1], sc.cameras[2], b.cameras[3]]
+    res = []
+    for shard in (True, False):
+        gm = model(device)
+        with torch.no_grad():
+            gm._opacity.fill_(2.0)
+            gm._scaling.add_(0.2 * torch.randn(gm._scaling.shape, generator=torch.Generator().manual_seed(1)).to(device))
+        hms = [generate_heatmaps(gm._xyz.detach(), gm.get_scaling.detach(), gm._rotation.detach(),
+                                 torch.tensor(sc.poses_2d[v:v + 1], device=device), [cams[v]])[0] for v in range(4)]
+        hm = torch.stack(hms) if mode != "mixed-sizes" else hms
+        loop = MultiViewLoop(gm, cams, hm, dataset="h36m", sparse=mode != "dense", shard_views=shard,
+                             use_graph=mode == "sparse-hipgraph", graph_collectives=True, fused_tail=False)
+        assert loop.exchange == shard and loop.world == 1 and loop.device_tail
+        if shard:
+            assert loop._allg.shape == (4, 17, 11) and loop._shard.shape == (4, 17, 11)
+        assert loop.use_graph == (mode == "sparse-hipgraph")
+        loop.run(32)
+        S, N = loop.last_losses
+        res.append([x.detach().clone() for x in (gm._xyz, gm._scaling, gm._rotation, gm._opacity, loop.accumulated_grads, N)])
+    for k, (a, b_) in enumerate(zip(*res)):
+        assert torch.equal(a, b_), k
+    assert (res[0][0].cpu() - torch.tensor(sc.pose_3d_init).float()).norm(dim=1).mean() > 0.5
+
+
+def test_adam_step_reads_the_gathered_rank_major_layout(device):
+    """sks_loop_adam_step(shard_world = N) on the buffer all_gather_into_tensor leaves for N ranks (view v = row
+    (v % N) * ceil(V / N) + v // N, pad rows ignored) == the view-major call, for uneven shards (7 views over 2, 3, 4 and
+    8 ranks) and the many-view code path (31 views over 8)."""
+    import ctypes
+    from skelsplat_amd import _lib
+    lib = _lib.load()
+    stream = torch.cuda.current_stream(device).cuda_stream
+    g = torch.Generator(device=device).manual_seed(11)
+    sched = (ctypes.c_double * 5)(2.0, 0.02, 0.0, 0.0, 4000.0)
+    lrs = (ctypes.c_double * 3)(0.005, 0.001, 0.05)
+    adam = (ctypes.c_double * 3)(0.9, 0.999, 1e-15)
+    for V, P, worlds, limb in ((7, 17, (2, 3, 4, 8), (ctypes.c_int * 8)(12, 13, 15, 16, 5, 6, 2, 3)), (31, 19, (8,), None)):
+        grads = torch.randn((V, P, 11), device=device, generator=g)
+        init = [torch.randn(s, device=device, generator=g) for s in ((P, 3), (P, 3), (P, 4), (P, 1))]
+        slots0 = torch.randn((V, P, 3), device=device, generator=g)
+        mask, last = (1 << V) - 1 - 2, V - 2        # one view not rendered in this group: its slot keeps the old value
+
+        def run(buf, world):
+            prm = [x.clone() for x in init]
+            slots = slots0.clone()
+            m, vv = torch.zeros((P, 11), device=device), torch.zeros((P, 11), device=device)
+            cnt = torch.zeros(2, dtype=torch.int32, device=device)
+            for _ in range(3):
+                _lib.check(lib.sks_loop_adam_step(V, P, buf.data_ptr(), slots.data_ptr(), mask, last, prm[0].data_ptr(),
+                                                  prm[1].data_ptr(), prm[2].data_ptr(), prm[3].data_ptr(), m.data_ptr(),
+                                                  vv.data_ptr(), cnt.data_ptr(), V, sched, lrs, adam, 1e-3, limb, world, stream),
+                           "sks_loop_adam_step")
+            return prm + [slots, m, vv, cnt]
+
+        ref = run(grads, 1)
+        for world in worlds:
+            vmax = (V + world - 1) // world
+            buf = torch.full((world * vmax, P, 11), float("nan"), device=device)    # pad rows must never be read
+            for v in range(V):
+                buf[(v % world) * vmax + v // world] = grads[v]
+            for a, b in zip(ref, run(buf, world)):
+                assert torch.equal(a, b), (V, world)
+        assert not torch.equal(ref[0], init[0])
+
+
+def test_early_stopping_cuts_the_group_like_the_reference(device):
+    """training.early_stopping = opt_early_stopping (train.py:155, 182-233): the criterion sees every iteration's loss in
+    order; when it fires inside a group, only the views up to that iteration refresh their slots, that view's scaling /
+    rotation / opacity gradients win, the optimiser steps at once and the scene ends.  Against the literal per-iteration
+    loop on the oracle with the reference's own criterion class semantics."""
+    import copy
+    from skelsplat_amd.loop import MultiViewLoop, OptEarlyStopping
+    from skelsplat_amd.heatmaps import generate_heatmaps
+    from tests.ref_loop import view_grads_ref
+    sc, model = _make_loop_scene(device, seed=9)
+    gm = model(device)
+    hm = generate_heatmaps(gm._xyz.detach(), gm.get_scaling.detach(), gm._rotation.detach(),
+                           torch.tensor(sc.poses_2d, device=device), sc.cameras)
+    tol = 2e-3        # loose enough to fire within a few dozen iterations of this small scene, mid-group
+    loop = MultiViewLoop(gm, sc.cameras, hm, dataset="h36m", early_stopping=OptEarlyStopping(window_size=3, repeat_tolerance=tol))
+    assert loop._stopping and not loop.fused_tail and not loop.use_graph
+    with pytest.raises(ValueError):
+        MultiViewLoop(gm, sc.cameras, hm, dataset="h36m", early_stopping="opt_early_stopping", use_graph=True)
+    loop.run(400)
+    assert loop.stopped_at is not None and loop.iteration == loop.stopped_at < 400
+    # literal loop
+    gmr = model("cpu")
+    cams_cpu = [copy.copy(c).to("cpu") for c in sc.cameras]
+    hm_cpu = hm.cpu()
+    crit = OptEarlyStopping(window_size=3, repeat_tolerance=tol)
+    acc = torch.zeros(4, 17, 3)
+    stopped = None
+    for it in range(1, 401):
+        gmr.update_learning_rate(it)
+        idx = (it - 1) % 4
+        loss, (gx, gs, gr, go) = view_grads_ref(gmr, cams_cpu[idx], hm_cpu[idx], sc.W, sc.H, "h36m", 1e-5)
+        stop = crit(float(loss))
+        acc[idx] = gx
+        gmr._scaling.grad, gmr._rotation.grad, gmr._opacity.grad = gs, gr, go
+        if it % 4 == 0 or stop:
+            gmr._xyz.grad = acc.mean(0)
+            gmr.optimizer.step()
+            gmr.optimizer.zero_grad(set_to_none=True)
+        if stop:
+            stopped = it
+            break
+    assert stopped is not None
+    assert abs(stopped - loop.stopped_at) <= 4, (stopped, loop.stopped_at)   # fp32 loss rounding may move the trigger a view or two
+    if stopped == loop.stopped_at:
+        assert (gm._xyz.detach().cpu() - gmr._xyz.detach()).norm(dim=1).max().item() < 0.05
+
+
+def test_heatmap_dropout_zeroes_the_drawn_planes(device):
+    """training.dropout (general_utils.py:267-283): three cameras from randint(4) and three joints from randint(J) get no
+    impulse -> all-zero planes; the other planes are untouched and the fused totals see the zeros."""
+    from skelsplat_amd.heatmaps import generate_heatmaps, draw_dropout
+    sc, model = _make_loop_scene(device, seed=4)
+    gm = model(device)
+    p2d = torch.tensor(sc.poses_2d, device=device)
+    args = (gm._xyz.detach(), gm.get_scaling.detach(), gm._rotation.detach(), p2d, sc.cameras)
+    base = generate_heatmaps(*args)
+    torch.manual_seed(123)
+    cams = torch.randint(4, (3,))
+    joints = torch.randint(17, (3,))
+    torch.manual_seed(123)
+    mask = draw_dropout(4, 17)
+    want = torch.zeros(4, 17, dtype=torch.bool)
+    for c in cams.tolist():
+        want[c, joints] = True
+    assert torch.equal(mask, want) and mask.any()
+    totals = torch.zeros((4, 2), dtype=torch.float64, device=device)
+    hm = generate_heatmaps(*args, drop_mask=mask, totals=totals)
+    m = mask.to(device)
+    assert float(hm[m].abs().max()) == 0.0 and torch.equal(hm[~m], base[~m])
+    torch.testing.assert_close(totals[:, 0], (hm.double() ** 2).sum(dim=(1, 2, 3)), rtol=1e-9, atol=0)
+    assert torch.equal(totals[:, 1], (hm > 0).sum(dim=(1, 2, 3)).double())

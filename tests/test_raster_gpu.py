@@ -84,6 +84,171 @@ def test_forward_wide_images_row_aligned_fill(device, W, H, binned):
     assert covered > 200, "the splats should land inside the strip"
 
 
+@pytest.mark.parametrize("W,H", [(1002, 48), (1002, 40), (1002, 33), (998, 24), (1006, 18), (70, 36)], ids=lambda v: str(v))
+@pytest.mark.parametrize("binned", [False, True], ids=["small", "binned"])
+def test_forward_h36m_1002_wide_sensor(device, W, H, binned):
+    """H36M's 1002-wide cameras (scene/dataset_readers.py:68-80): W % 4 == 2.  With an even H every band of every plane
+    is still 16-byte aligned and is filled with 16-byte stores whose two pixel pairs are masked separately (a float4 may
+    straddle a row end or a tile-column boundary in its middle); an odd H falls back to 4-byte stores.  Full sensor
+    width x a strip of rows, the forced-linear tuning flag included: bit-exact against the oracle, debug planes too."""
+    c = util.make_case(seed=61, W=W, H=H, n_views=3, scale_log=4.3, fxmul=0.2 * 1000.0 / W, ring=2500.0)
+    outs = []
+    for tune in (0, 1 << 21, 16):   # default / forced linear / plain (cached) stores -> the 4-byte path
+        color, inv, radii, st, final_T, n_contrib = run_forward(c, device, force_binned=binned, tune_flags=tune)
+        outs.append((color, inv, final_T, n_contrib))
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert torch.equal(a, b)
+    color, inv, final_T, n_contrib = outs[0]
+    covered = 0
+    for v in range(len(c.cams)):
+        o = util.oracle_forward(c, v)
+        covered += int((o["n_contrib"] > 0).sum())
+        assert np.array_equal(color[v].cpu().numpy(), o["color"])
+        assert np.array_equal(inv[v].cpu().numpy(), o["invdepth"])
+        assert np.array_equal(final_T[v].cpu().numpy(), o["final_T"])
+        assert np.array_equal(n_contrib[v].cpu().numpy().astype(np.uint32), o["n_contrib"])
+    assert covered > 200, "the splats should land inside the strip"
+    # the clamp-folding store path and a poisoned output buffer: every element is written exactly once
+    views = R.ViewBatch.from_cameras([cam.to(device) for cam in c.cams])
+    ws = R.Workspace()
+    args = (t(c.means, device), t(c.feat, device), t(c.opac, device), t(c.scales, device), t(c.quats, device), None)
+    for k in range(2):
+        for tt in ws._t.values():
+            if tt.dtype == torch.float32:
+                tt.fill_(float("nan"))
+        col2, inv2, _, _ = R.forward_views(views, *args, force_binned=binned, workspace=ws)
+        assert torch.equal(col2, color) and torch.equal(inv2, inv)
+
+
+def test_full_size_h36m_1002(device):
+    """BASELINE config 2 at the real sensor mix: 1002x1000 views at full size.  No oracle at this size (minutes of CPU):
+    the 16-byte half-masked fill equals the 4-byte path bit for bit, every element is written (NaN-poisoned buffer), and the
+    image is supported exactly on the tiles the rects cover."""
+    from skelsplat_amd.scene import SyntheticScene, GaussianModel
+    sc = SyntheticScene("h36m", n_views=4, seed=0, device=device, W=1002, H=1000)
+    gm = GaussianModel().create_from_points(sc.pose_3d_init, sc.spatial_lr_scale, 17, device=device)
+    views = R.ViewBatch.from_cameras(sc.cameras)
+    with torch.no_grad():
+        args = (gm.get_xyz.detach(), gm.get_features.reshape(17, 17).contiguous(), gm.get_opacity.detach(),
+                gm.get_scaling.detach(), gm.get_rotation.detach(), None)
+    ws = R.Workspace()
+    R.forward_views(views, *args, workspace=ws)
+    for tt in ws._t.values():
+        if tt.dtype == torch.float32:
+            tt.fill_(float("nan"))
+    color, inv, radii, st = R.forward_views(views, *args, workspace=ws)
+    assert torch.isfinite(color).all() and torch.isfinite(inv).all()
+    c2, i2, r2, _ = R.forward_views(views, *args, tune_flags=16)     # plain stores: the 4-byte path
+    assert torch.equal(color, c2) and torch.equal(inv, i2) and torch.equal(radii, r2)
+    c3, i3, _, _ = R.forward_views(views, *args, force_binned=True)
+    assert torch.equal(color, c3) and torch.equal(inv, i3)
+    rect = R.decode_geom(st)["rect"].cpu().numpy()
+    for v in range(4):
+        mask = np.zeros((63, 63), bool)
+        for x0, y0, x1, y1 in rect[v]:
+            mask[y0:y1, x0:x1] = True
+        nz = (color[v] != 0).any(0).cpu().numpy()
+        ty, tx = np.nonzero(nz)
+        assert mask[ty // 16, tx // 16].all()
+        assert nz.sum() > 1000
+
+
+def test_full_size_config3_panoptic(device):
+    """BASELINE config 3 at full size: P = C = 19, 31 views @ 1920x1080 on one GPU.  Oracle parity on two of the views over
+    a 160-row strip at full width (same cameras, principal point shifted with the crop), and size-independent properties
+    of the whole 31-view launch: small path == binned path bit for bit, linearity of the backward in dL, clamp range,
+    support on the covered tiles, every element written."""
+    import copy
+    import math
+    from skelsplat_amd.scene import SyntheticScene, GaussianModel, Camera
+    V, W, H, C = 31, 1920, 1080, 19
+    sc = SyntheticScene("panoptic", n_views=V, seed=0, device=device)
+    gm = GaussianModel().create_from_points(sc.pose_3d_init, sc.spatial_lr_scale, C, scene_type="panoptic", device=device)
+    views = R.ViewBatch.from_cameras(sc.cameras)
+    with torch.no_grad():
+        args = (gm.get_xyz.detach(), gm.get_features.reshape(C, C).contiguous(), gm.get_opacity.detach(),
+                gm.get_scaling.detach(), gm.get_rotation.detach(), None)
+    ws = R.Workspace()
+    R.forward_views(views, *args, clamp01=True, workspace=ws)
+    for tt in ws._t.values():
+        if tt.dtype == torch.float32:
+            tt.fill_(float("nan"))
+    color, inv, radii, st = R.forward_views(views, *args, clamp01=True, workspace=ws)
+    assert torch.isfinite(color).all() and torch.isfinite(inv).all()
+    assert float(color.min()) >= 0.0 and float(color.max()) <= 1.0 and float(color.max()) > 0.5
+    assert int((radii > 0).sum()) == V * C                      # every joint visible in every view of the ring
+    rect = R.decode_geom(st)["rect"].cpu().numpy()
+    for v in (0, 13, 30):
+        mask = np.zeros((68, 120), bool)
+        for x0, y0, x1, y1 in rect[v]:
+            mask[y0:y1, x0:x1] = True
+        nz = (color[v] != 0).any(0).cpu().numpy()
+        ty, tx = np.nonzero(nz)
+        assert mask[ty // 16, tx // 16].all() and nz.sum() > 1000
+    cb, ib, rb, stb = R.forward_views(views, *args, clamp01=True, force_binned=True)
+    assert torch.equal(cb, color) and torch.equal(ib, inv) and torch.equal(rb, radii)
+    del cb, ib
+    # backward: linear in dL, small path vs binned path within the atomics tolerance
+    g = torch.Generator(device=device).manual_seed(3)
+    dA = torch.randn((V, C, H, W), device=device, generator=g)
+    ga = {k: x.clone() for k, x in R.backward_views(st, *args, dA).items() if x is not None}
+    gb = R.backward_views(stb, *args, dA)
+    for k in ("means3D", "scales", "rotations", "opacities"):
+        util.assert_close("binned-vs-small " + k, gb[k].cpu(), ga[k].cpu(), rtol=2e-3, atol_scale=1e-5)
+    dA.mul_(-2.5)
+    g2 = R.backward_views(st, *args, dA)
+    for k in ("means3D", "scales", "rotations", "opacities"):
+        util.assert_close("linearity " + k, g2[k].cpu(), (-2.5 * ga[k]).cpu(), rtol=1e-5, atol_scale=1e-6)
+    del dA
+    # oracle parity on views 5 and 22: full width, rows [y0, y0 + 160) around the skeleton -- a crop is the same camera
+    # with cy shifted (the projection of graphics_utils.py:74-95 is built from K, W, H)
+    for v in (5, 22):
+        cam = sc.cameras[v]
+        ys = R.decode_geom(st)["xy"][v, :, 1].cpu().numpy()
+        y0 = int(max(0, min(H - 160, (np.median(ys) - 80) // 16 * 16)))
+        K = cam.K.copy()
+        K[1, 2] -= y0
+        crop = Camera(cam.uid, cam.R, cam.T, K, W, 160, device=device)
+        # (FoVy changes with H; focal_y = H / (2 tan(FoVy / 2)) stays fy)
+        vb = R.ViewBatch.from_cameras([crop])
+        cc, ci, cr, cst, cT, cn = R.forward_views(vb, *args, want_aux=True)
+        ocam = orc.Cam(W, 160, math.tan(crop.FoVx * 0.5), math.tan(crop.FoVy * 0.5), crop.world_view_transform.cpu().numpy(),
+                       crop.full_proj_transform.cpu().numpy())
+        o = orc.forward(*[a.cpu().numpy() for a in args[:5]], None, ocam)
+        assert np.array_equal(cr[0].cpu().numpy(), o["radii"])
+        assert np.array_equal(cc[0].cpu().numpy(), o["color"])
+        assert np.array_equal(ci[0].cpu().numpy(), o["invdepth"])
+        assert np.array_equal(cn[0].cpu().numpy().astype(np.uint32), o["n_contrib"])
+        assert (o["n_contrib"] > 0).sum() > 2000
+        # the crop of the full render agrees with the strip render wherever the strip holds the whole splat: compare rows
+        full = color[v, :, y0:y0 + 160].cpu().numpy()
+        inside = (o["n_contrib"] > 0)
+        rows = np.nonzero(inside.any(1))[0]
+        if rows.min() > 16 and rows.max() < 160 - 16:   # no splat cut by the strip's border tiles
+            np.testing.assert_allclose(full, np.clip(o["color"], 0, 1), rtol=0, atol=2e-6)
+
+
+def test_mark_visible_culls_like_the_oracle(device):
+    """GaussianRasterizer.markVisible == checkFrustum (rasterizer_impl.cu:54-66, auxiliary.h:151-176): points behind the
+    camera or closer than 0.2 are culled, the rest -- inside the image or not -- are present."""
+    c = util.make_case(seed=7, W=160, H=128)
+    cam = c.cams[0].to(device)
+    rs = R.GaussianRasterizationSettings(128, 160, 0.5, 0.5, torch.zeros(3, device=device), 1.0, cam.world_view_transform,
+                                         cam.full_proj_transform, 0, cam.camera_center, False, False, False)
+    rng = np.random.default_rng(5)
+    center = cam.camera_center.cpu().numpy()
+    fwd = cam.world_view_transform.cpu().numpy()[:3, 2]          # world-space viewing direction (column-major view matrix)
+    depth = np.concatenate([rng.uniform(-3000, 3000, 200), [0.19, 0.2, 0.2000001, 0.21, -0.0, 1e-3]])
+    lateral = rng.normal(0, 4000, (depth.size, 3))
+    lateral -= np.outer(lateral @ fwd, fwd)                      # depth along the axis is exactly `depth` up to fp32
+    pts = (center[None] + depth[:, None] * fwd[None] + lateral).astype(np.float32)
+    got = R.GaussianRasterizer(rs).markVisible(torch.tensor(pts, device=device)).cpu().numpy()
+    want = orc.mark_visible(pts, c.ocams[0])
+    assert got.dtype == np.bool_ and np.array_equal(got, want.astype(bool))
+    assert 20 < got.sum() < got.size - 20                        # both outcomes are exercised
+
+
 @pytest.mark.parametrize("kw", CASES, ids=lambda k: f"seed{k['seed']}")
 @pytest.mark.parametrize("binned", [False, True], ids=["small", "binned"])
 @pytest.mark.parametrize("aa", [False, True], ids=["noaa", "aa"])
