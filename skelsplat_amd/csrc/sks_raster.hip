@@ -68,7 +68,9 @@ inline bool fill_half_mode(const FwdArgs& a) { return a.W % 4 == 2 && a.H % 2 ==
 inline void fill_geometry(const FwdArgs& a, bool have_cover, bool binned, int& fsplit, int& pb)
 {
     const int ppt = (a.W % 4 == 0 || fill_half_mode(a)) ? 4 : 1;
-    const int passes = (TILE * a.W + 256 * ppt - 1) / (256 * ppt);
+    // (+31: a band that does not start on a 128-byte line begins with a short pass, fwd_fill_role's `shift`)
+    const int lead = ((long long)a.H * a.W % 32 == 0 && TILE * a.W % 32 == 0) ? 0 : 31;
+    const int passes = (TILE * a.W + lead + 256 * ppt - 1) / (256 * ppt);
     const int tune = (int)((a.flags >> 8) & 0xff);                    // tuning knob: passes (or rows) per fill block
     const int chunks = (a.W + 1023) / 1024;
     const bool rowmode = ((ppt == 4 && a.W % 4 == 0 && have_cover && a.W % 32 == 0 && (long long)a.W * 10 >= (long long)chunks * 1024 * 9) ||

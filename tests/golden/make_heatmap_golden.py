@@ -61,6 +61,11 @@ def main():
         cov3 = general_utils.unpack_covariance(six)
         g = types.SimpleNamespace(get_xyz=gm._xyz.detach())
         ref = general_utils.generate_heatmaps(g, p2d, sc.cameras, cov3, False, "data/h36m", 2)
+        # training.dropout = True (general_utils.py:267-283): the same call with the reference's two randint draws from a
+        # seeded default generator; the planes it leaves without an impulse come out all zero, everything else unchanged
+        drop_seed = 9
+        torch.manual_seed(drop_seed)
+        ref_drop = general_utils.generate_heatmaps(g, p2d, sc.cameras, cov3, True, "data/h36m", 2)
     finally:
         for k, f in real.items():
             setattr(torch, k, f)
@@ -69,6 +74,12 @@ def main():
                world_view_transform=np.stack([c.world_view_transform.numpy() for c in sc.cameras]),
                fov=np.array([[c.FoVx, c.FoVy] for c in sc.cameras], dtype=np.float64),
                heatmaps=np.stack([ref[str(v)].numpy() for v in range(2)]).astype(np.float32))
+    full = np.stack([ref[str(v)].numpy() for v in range(2)])
+    drop = np.stack([ref_drop[str(v)].numpy() for v in range(2)])
+    mask = np.abs(drop).reshape(2, 17, -1).max(-1) == 0
+    assert mask.any() and not mask.all(), "choose a seed that drops planes of cameras 0 / 1"
+    assert np.array_equal(drop[~mask], full[~mask]) and not np.abs(full[mask]).reshape(mask.sum(), -1).max(-1).min() == 0
+    out.update(dropout_seed=np.int64(drop_seed), dropout_mask=mask)
     path = os.path.join(HERE, "reference_heatmaps.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes", {k: np.asarray(v).shape for k, v in out.items()})

@@ -419,6 +419,11 @@ def test_heatmaps_against_reference_generate_heatmaps_golden():
     assert hm.shape == want.shape == (2, 17, H, W)
     assert float(want.max()) == 1.0 and float((want > 0.5).float().mean()) > 1e-4
     torch.testing.assert_close(hm, want, rtol=0, atol=2e-6)
+    # training.dropout: the planes the reference's own seeded run left empty (general_utils.py:267-283) are the ones
+    # draw_dropout draws from the same generator state
+    from skelsplat_amd.heatmaps import draw_dropout
+    torch.manual_seed(int(g["dropout_seed"]))
+    assert np.array_equal(draw_dropout(2, 17).numpy(), g["dropout_mask"]) and g["dropout_mask"].any()
 
 
 def test_camera_and_model_against_reference_classes_golden():
@@ -457,3 +462,119 @@ def test_camera_and_model_against_reference_classes_golden():
         assert np.array_equal(np.array([gm.update_learning_rate(it) for it in (1, 4, 100, 500)]), g[pre + "xyz_lr_at"])
         c = gm.opt_cfg   # what the device-side optimiser step receives
         assert (c["lr_scaling"], c["lr_rotation"], c["lr_opacity"], c["eps"], tuple(c["betas"])) == (0.005, 0.001, 0.0, 1e-15, (0.9, 0.999))
+
+
+# ------------------------------------------------------------------- "next" rows pinned by the reference's own code
+NEXT = os.path.join(os.path.dirname(__file__), "golden", "reference_next.npz")
+
+
+def test_triangulation_against_reference_golden():
+    """skelsplat_amd.triangulation vs the outputs of the reference's own create_projection_matrix / triangulate_poses
+    (triangulation.py:111-150, run by tests/golden/make_golden_next.py): 4 noisy H36M views, 8 Panoptic views, 2 views."""
+    from skelsplat_amd import triangulation
+    from skelsplat_amd.scene import Camera
+    G = np.load(NEXT)
+    for tag in ("h36m4", "pan8", "two"):
+        K, Rw2c, t, P, x2d, X = (G[f"tri_{tag}_{k}"] for k in ("K", "R", "t", "P", "x2d", "X"))
+        cams = [Camera(i, Rw2c[i].T, t[i], K[i], 1000, 1000) for i in range(K.shape[0])]     # Camera.R is camera-to-world
+        Pm = triangulation.projection_matrices(cams)
+        assert np.allclose(Pm, P, rtol=1e-12, atol=1e-9)
+        got = triangulation.triangulate_poses(P, x2d)
+        assert got.shape == X.shape and np.allclose(got[:, 3], 1.0)
+        assert np.allclose(got, X, rtol=1e-8, atol=1e-6), np.abs(got - X).max()
+        assert np.linalg.norm(got[:, :3] - G[f"tri_{tag}_pts"], axis=1).mean() < (1e-6 if tag == "two" else 40.0)
+
+
+def test_early_stopping_against_reference_golden():
+    """loop.OptEarlyStopping / EarlyStopping / NotStopping give the reference classes' decisions (general_utils.py:449-498)
+    on every golden loss sequence, call by call."""
+    from skelsplat_amd.loop import OptEarlyStopping, EarlyStopping, NotStopping, early_stopping_strategy
+    G = np.load(NEXT)
+    assert set(early_stopping_strategy) == {"opt_early_stopping", "no_stopping"}
+    fired = 0
+    for name in ("plateau", "period4", "period4_drift", "edge", "noise", "short"):
+        seq = [float(x) for x in G[f"es_{name}_loss"]]
+        a, b, c = OptEarlyStopping(), OptEarlyStopping(window_size=3, repeat_tolerance=1e-3), EarlyStopping(patience=5, min_delta=1e-3)
+        assert [bool(a(x)) for x in seq] == G[f"es_{name}_opt"].tolist(), name
+        assert [bool(b(x)) for x in seq] == G[f"es_{name}_opt_w3"].tolist(), name
+        assert [bool(c(x)) for x in seq] == G[f"es_{name}_patience"].tolist(), name
+        assert not any(NotStopping()(x) for x in seq)
+        fired += int(G[f"es_{name}_opt"].any()) + int(G[f"es_{name}_opt_w3"].any())
+    assert fired >= 3      # the goldens exercise both outcomes
+
+
+def test_save_ply_against_reference_golden(tmp_path):
+    """io.save_ply writes the vertex element the reference's save_ply hands to plyfile (gaussian_model.py:250-281):
+    same property names in the same order, same float32 bytes; and read_ply_xyz reads the positions back."""
+    from skelsplat_amd import io
+    G = np.load(NEXT)
+    for key in ("h36m", "panoptic", "occlusion-person"):
+        pre = f"ply_{key}_"
+        gm = type("GM", (), {})()
+        for f in ("xyz", "features_dc", "features_rest", "scaling", "rotation", "opacity"):
+            setattr(gm, "_" + f, torch.tensor(G[pre + f]))
+        path = str(tmp_path / "point_cloud" / "iteration_500" / f"S1_Directions_{key}.ply")
+        io.save_ply(path, gm)
+        raw = open(path, "rb").read()
+        head, body = raw.split(b"end_header\n", 1)
+        lines = head.decode("ascii").strip().split("\n")
+        assert lines[0] == "ply" and lines[1] == "format binary_little_endian 1.0"
+        assert lines[2] == f"element {str(G[pre + 'element'])} {G[pre + 'xyz'].shape[0]}"
+        props = [ln.split() for ln in lines[3:]]
+        assert [p[2] for p in props] == G[pre + "names"].tolist() == G[pre + "attributes"].tolist()
+        assert all(p[:2] == ["property", "float"] for p in props) and set(G[pre + "formats"].tolist()) == {"<f4"}
+        assert body == G[pre + "bytes"].tobytes()
+        assert np.array_equal(io.read_ply_xyz(path).astype(np.float32), G[pre + "xyz"])
+
+
+def test_evaluate_against_reference_golden(tmp_path):
+    """io.evaluate == the reference's evaluate() (eval.py:91-171) on the same files: directory walk and sort order, the S9
+    exclusions of the absolute metric, [start_id, end_id) handling, absolute / root-relative MPJPE, per-activity means."""
+    from skelsplat_amd import io
+    G = np.load(NEXT)
+
+    def write(root, names, gt, pred, dataset, C):
+        ply_dir = tmp_path / root / "out" / "point_cloud" / "iteration_500"
+        seqs = {}
+        for n, g, p in zip(names, gt, pred):
+            n = str(n)
+            gm = type("GM", (), {})()
+            gm._xyz = torch.tensor(p, dtype=torch.float32)
+            gm._features_dc = torch.zeros(p.shape[0], 1, C)
+            gm._features_rest = torch.zeros(p.shape[0], 0, C)
+            gm._opacity = torch.zeros(p.shape[0], 1)
+            gm._scaling = torch.zeros(p.shape[0], 3)
+            gm._rotation = torch.zeros(p.shape[0], 4)
+            io.save_ply(str(ply_dir / n), gm)
+            stem = n[:-4]
+            if dataset == "h36m":
+                subj, act, frame = stem.split("_")
+            else:
+                subj, a, b, frame = stem.split("_")
+                act = a + "_" + b
+            seqs.setdefault((subj, act), {})[int(frame)] = g
+        gt_root = tmp_path / root / "data" / dataset
+        for (subj, act), frames in seqs.items():
+            d = gt_root / subj / act
+            d.mkdir(parents=True)
+            if dataset == "h36m":
+                arr = np.zeros((max(frames) + 1, 17, 3))
+                for f, g in frames.items():
+                    arr[f] = g                       # every 64th frame is a scene (eval.py:68)
+                np.savez(str(d / "poses.npz"), poses=arr)
+            else:
+                np.savez(str(d / "poses_filtered_4.npz"), poses=np.stack([frames[f] for f in sorted(frames)]))
+        return str(gt_root), str(tmp_path / root / "out")
+
+    gt_root, outp = write("h", G["eval_h36m_names"], G["eval_h36m_gt"], G["eval_h36m_pred"], "h36m", 17)
+    r = io.evaluate(gt_root, outp, 500, 0, 10 ** 6)
+    # positions went through float32 ply files: tolerance of a float32 round trip on ~1e3 mm coordinates
+    assert abs(r["abs"] - float(G["eval_h36m_abs"])) < 1e-3 and abs(r["rel"] - float(G["eval_h36m_rel"])) < 1e-3
+    for k in ("abs_activities", "rel_activities"):
+        want = G["eval_h36m_" + k]
+        assert np.array_equal(np.isnan(r[k]), np.isnan(want)) and np.nanmax(np.abs(r[k] - want)) < 1e-3
+        assert (~np.isnan(want)).sum() >= 5
+    gt_root, outp = write("p", G["eval_pan_names"], G["eval_pan_gt"], G["eval_pan_pred"], "panoptic", 19)
+    lo, hi = (int(x) for x in G["eval_pan_range"])
+    r = io.evaluate(gt_root, outp, 500, lo, hi)
+    assert abs(r["abs"] - float(G["eval_pan_abs"])) < 1e-3 and abs(r["rel"] - float(G["eval_pan_rel"])) < 1e-3

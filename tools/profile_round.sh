@@ -4,15 +4,15 @@
 # --kernel-trace).  Run on the GPU box from the repo root:  bash tools/profile_round.sh r01
 # Outputs land in gpurun_out/prof/; tools/make_profiles.py turns them into profiles/<round>_*.
 set -u
-R=${1:-r01}
+R=${1:-r02}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for WL in h36m panoptic; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${WL}_stats" -o stats -- python3 "$ROOT/bench.py" --workload $WL --steps 50 --warmup 5 --no-cpu-baseline --no-dropin > "$OUT/${WL}_bench_under_rocprof.json" 2> "$OUT/${WL}_stats.log"
-  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/${WL}_w" -o w -- python3 "$ROOT/bench.py" --workload $WL --steps 20 --warmup 3 --no-cpu-baseline --no-prof --no-dropin > /dev/null 2> "$OUT/${WL}_w.log"
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/${WL}_f" -o f -- python3 "$ROOT/bench.py" --workload $WL --steps 20 --warmup 3 --no-cpu-baseline --no-prof --no-dropin > /dev/null 2> "$OUT/${WL}_f.log"
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${WL}_stats" -o stats -- python3 "$ROOT/bench.py" --workload $WL --steps 50 --warmup 5 --no-cpu-baseline --no-extras > "$OUT/${WL}_bench_under_rocprof.json" 2> "$OUT/${WL}_stats.log"
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/${WL}_w" -o w -- python3 "$ROOT/bench.py" --workload $WL --steps 20 --warmup 3 --no-cpu-baseline --no-prof --no-extras > /dev/null 2> "$OUT/${WL}_w.log"
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/${WL}_f" -o f -- python3 "$ROOT/bench.py" --workload $WL --steps 20 --warmup 3 --no-cpu-baseline --no-prof --no-extras > /dev/null 2> "$OUT/${WL}_f.log"
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stress_stats" -o stats -- python3 "$ROOT/tools/bench_stress.py" > "$OUT/stress.log" 2>&1
 cd "$ROOT"
