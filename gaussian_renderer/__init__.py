@@ -19,18 +19,54 @@ from diff_gaussian_rasterization_op import GaussianRasterizer as GaussianRasteri
 
 
 class RenderPackage(dict):
-    """dict with the reference's keys; `visibility_filter` is materialised lazily (it needs a host sync)."""
+    """dict with the reference's keys (gaussian_renderer/__init__.py:131-138).  `visibility_filter` =
+    (radii > 0).nonzero() forces a host sync, so it is materialised on first use -- through ANY accessor: [], get, in,
+    keys / values / items, iteration, len, copy, dict(pkg), ** unpacking all see the five keys of the reference's dict."""
+    _LAZY = "visibility_filter"
+
+    def _materialise(self):
+        if not dict.__contains__(self, self._LAZY):
+            dict.__setitem__(self, self._LAZY, (dict.__getitem__(self, "radii") > 0).nonzero())
 
     def __getitem__(self, key):
-        if key == "visibility_filter" and not dict.__contains__(self, key):
-            dict.__setitem__(self, key, (dict.__getitem__(self, "radii") > 0).nonzero())
+        if key == self._LAZY:
+            self._materialise()
         return dict.__getitem__(self, key)
 
+    def get(self, key, default=None):
+        if key == self._LAZY:
+            self._materialise()
+        return dict.get(self, key, default)
+
     def __contains__(self, key):
-        return key == "visibility_filter" or dict.__contains__(self, key)
+        return key == self._LAZY or dict.__contains__(self, key)
+
+    def __iter__(self):
+        self._materialise()
+        return dict.__iter__(self)
+
+    def __len__(self):
+        return dict.__len__(self) + (0 if dict.__contains__(self, self._LAZY) else 1)
 
     def keys(self):
-        return list(dict.keys(self)) + ([] if dict.__contains__(self, "visibility_filter") else ["visibility_filter"])
+        self._materialise()
+        return dict.keys(self)
+
+    def values(self):
+        self._materialise()
+        return dict.values(self)
+
+    def items(self):
+        self._materialise()
+        return dict.items(self)
+
+    def copy(self):
+        self._materialise()
+        return dict(dict.items(self))
+
+    def __repr__(self):
+        self._materialise()
+        return dict.__repr__(self)
 
 
 def _render(Settings, Rasterizer, viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, separate_sh=False,
@@ -71,8 +107,13 @@ def _render(Settings, Rasterizer, viewpoint_camera, pc, pipe, bg_color, scaling_
     shs = colors_precomp = None
     if override_color is None:
         if pipe.convert_SHs_python:
-            raise NotImplementedError("convert_SHs_python: the skeleton features are not RGB SH (every shipped "
-                                      "config sets it to false, configs/h36m.yaml:46)")
+            # Refused, not stubbed (INTEGRATION.md "Switches that are refused"): the reference's branch
+            # (gaussian_renderer/__init__.py:85-90) views the (J,1,J) features as (-1, 3, (deg+1)^2) RGB SH -- a shape error for
+            # J = 17 / 19 (J*J is not a multiple of 3) and a (75,3) colour table for J = 15 -- and then calls the rasterizer
+            # with shs=None, whose kernels read the features from the `sh` pointer (quirk Q1): a null dereference.
+            raise RuntimeError("pipe.convert_SHs_python=True cannot work with skeleton features (P,1,J): the reference's "
+                               "own branch fails on them (see INTEGRATION.md); every shipped config sets it to false "
+                               "(configs/h36m.yaml:46)")
         shs = pc.get_features  # with separate_sh the reference passes dc + empty rest; same (P,1,C) features
     else:
         colors_precomp = override_color

@@ -31,17 +31,41 @@ def hipcc():
     raise RuntimeError("hipcc not found (set HIPCC)")
 
 
+STAMP = LIB + ".flags"     # the flag set the library was built with (a change of FLAGS / SOURCES is a rebuild)
+
+
+def _flags_stamp():
+    import hashlib
+    return hashlib.sha256(repr((FLAGS, sorted(SOURCES.items()))).encode()).hexdigest()
+
+
 def _stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "skelsplat_hip.h")]
-    return any(os.path.getmtime(d) > t for d in deps if os.path.isfile(d))
+    if any(os.path.getmtime(d) > t for d in deps if os.path.isfile(d)):
+        return True
+    # a library shipped without its stamp (the snapshot on the GPU box carries both) is taken as it is
+    return os.path.exists(STAMP) and open(STAMP).read().strip() != _flags_stamp()
 
 
 def build(force=False, verbose=False):
-    if not force and not _stale():
-        return LIB
+    """One builder at a time (every rank of a torchrun job calls this through _lib.load()): an exclusive flock around
+    check-compile-link-rename; the link target is a process-unique temporary renamed into place, so a rank never maps a
+    half-written file."""
+    import fcntl
+    with open(LIB + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not _stale():      # another rank built it while this one waited for the lock
+                return LIB
+            return _build_locked(verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(verbose):
     cc = hipcc()
     with tempfile.TemporaryDirectory(prefix="sks_build_") as tmp:
         def compile_one(item):
@@ -55,11 +79,14 @@ def build(force=False, verbose=False):
 
         with ThreadPoolExecutor(max_workers=4) as pool:   # one translation unit per source, compiled side by side
             objs = list(pool.map(compile_one, SOURCES.items()))
-        cmd = [cc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB + ".tmp"] + objs
+        out = f"{LIB}.{os.getpid()}.tmp"
+        cmd = [cc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", out] + objs
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
-    os.replace(LIB + ".tmp", LIB)
+    os.replace(out, LIB)
+    with open(STAMP, "w") as f:
+        f.write(_flags_stamp() + "\n")
     return LIB
 
 

@@ -124,8 +124,17 @@ def _ssim_scratch(dev, stream):
     key = (dev.index, stream)
     buf = _SSIM_SCRATCH.get(key)
     if buf is None:
-        buf = _SSIM_SCRATCH[key] = torch.zeros(_lib.SKS_SSIM_SCRATCH_BYTES // 8, dtype=torch.float64, device=dev)
+        buf = torch.zeros(_lib.SKS_SSIM_SCRATCH_BYTES // 8, dtype=torch.float64, device=dev)
+        # allocated during a hipGraph capture it lives in that graph's private pool (and its zero fill is part of the graph):
+        # never shared with other graphs or eager code
+        if not torch.cuda.is_current_stream_capturing():
+            _SSIM_SCRATCH[key] = buf
     return buf
+
+
+def reset_ssim_scratch():
+    """Forget the cached reduction scratch: a call that failed half-way may have left partial sums in it."""
+    _SSIM_SCRATCH.clear()
 
 
 class FusedSSIMMean(torch.autograd.Function):
@@ -149,6 +158,8 @@ class FusedSSIMMean(torch.autograd.Function):
             rc = _lib.load().sks_fused_ssim_mean(B, CH, H, W, float(C1), float(C2), img1c.data_ptr(), img2c.data_ptr(), crop,
                                                  _lib.ptr(parts[0]), _lib.ptr(parts[1]), _lib.ptr(parts[2]),
                                                  _ssim_scratch(dev, stream).data_ptr(), mean.data_ptr(), stream)
+        if rc != 0:
+            reset_ssim_scratch()
         _lib.check(rc, "sks_fused_ssim_mean")
         emp = torch.empty(0, device=dev)
         ctx.save_for_backward(img1c.detach(), img2c, *(p if p is not None else emp for p in parts))

@@ -807,5 +807,5 @@ def test_heatmap_dropout_zeroes_the_drawn_planes(device):
     hm = generate_heatmaps(*args, drop_mask=mask, totals=totals)
     m = mask.to(device)
     assert float(hm[m].abs().max()) == 0.0 and torch.equal(hm[~m], base[~m])
-    torch.testing.assert_close(totals[:, 0], (hm.double() ** 2).sum(dim=(1, 2, 3)), rtol=1e-9, atol=0)
+    torch.testing.assert_close(totals[:, 0], (hm.double() ** 2).sum(dim=(1, 2, 3)), rtol=1e-6, atol=0)   # (fp32 partial sums per thread)
     assert torch.equal(totals[:, 1], (hm > 0).sum(dim=(1, 2, 3)).double())

@@ -215,18 +215,17 @@ def test_full_size_config3_panoptic(device):
         cc, ci, cr, cst, cT, cn = R.forward_views(vb, *args, want_aux=True)
         ocam = orc.Cam(W, 160, math.tan(crop.FoVx * 0.5), math.tan(crop.FoVy * 0.5), crop.world_view_transform.cpu().numpy(),
                        crop.full_proj_transform.cpu().numpy())
-        o = orc.forward(*[a.cpu().numpy() for a in args[:5]], None, ocam)
+        o = orc.forward(*[a.detach().cpu().numpy() for a in args[:5]], None, ocam)
         assert np.array_equal(cr[0].cpu().numpy(), o["radii"])
         assert np.array_equal(cc[0].cpu().numpy(), o["color"])
         assert np.array_equal(ci[0].cpu().numpy(), o["invdepth"])
         assert np.array_equal(cn[0].cpu().numpy().astype(np.uint32), o["n_contrib"])
         assert (o["n_contrib"] > 0).sum() > 2000
         # the crop of the full render agrees with the strip render wherever the strip holds the whole splat: compare rows
+        # the strip of the full render: same tiles, same lists; the pixel centres differ by the rounding of two different
+        # ndc -> pixel maps (H = 1080 vs 160), hence a tolerance
         full = color[v, :, y0:y0 + 160].cpu().numpy()
-        inside = (o["n_contrib"] > 0)
-        rows = np.nonzero(inside.any(1))[0]
-        if rows.min() > 16 and rows.max() < 160 - 16:   # no splat cut by the strip's border tiles
-            np.testing.assert_allclose(full, np.clip(o["color"], 0, 1), rtol=0, atol=2e-6)
+        np.testing.assert_allclose(full, np.clip(o["color"], 0, 1), rtol=0, atol=5e-5)
 
 
 def test_mark_visible_culls_like_the_oracle(device):
@@ -788,3 +787,46 @@ def test_backward_variants_agree_on_random_scenes(device):
             worst = max(worst, err)
             assert err < 1e-4, (it, k, W, H, err)
     assert worst > 0.0   # (different summation orders: the two really are different computations)
+
+
+def test_workspace_replay_follows_the_inputs(device):
+    """forward_views / backward_views with a Workspace record the validated C-ABI call and replay it while the SAME tensors
+    come back (a training loop's case); the recorded call must never outlive its assumptions: new contents in the same
+    storage are seen, other tensors / switches / non-contiguous views take the validating path again."""
+    c = util.make_case(seed=2, W=96, H=96, scale_log=5.0, rand_rot=False, opac=1.0)
+    views = R.ViewBatch.from_cameras([cam.to(device) for cam in c.cams])
+    P = c.P
+    means, feat, opac, scales, quats = (t(a, device) for a in (c.means, c.feat, c.opac, c.scales, c.quats))
+    dL = t(c.dL_color, device)
+    ws = R.Workspace()
+
+    def both(ws_, *a, **kw):
+        col, inv, rad, st = R.forward_views(views, *a, None, workspace=ws_, **kw)
+        g = R.backward_views(st, *a, None, dL, workspace=ws_)
+        return [x.clone() for x in (col, inv, rad, g["means3D"], g["scales"], g["rotations"], g["opacities"])]
+
+    ref = both(None, means, feat, opac, scales, quats)
+    for _ in range(3):     # 1st: validating path + record, then replays
+        got = both(ws, means, feat, opac, scales, quats)
+        assert all(torch.equal(a, b) for a, b in zip(ref, got))
+    assert "fwd" in ws._plans and "bwd" in ws._plans
+    # new contents in the same storage
+    with torch.no_grad():
+        means.add_(7.0)
+        scales.mul_(1.1)
+    ref2 = both(None, means, feat, opac, scales, quats)
+    got2 = both(ws, means, feat, opac, scales, quats)
+    assert all(torch.equal(a, b) for a, b in zip(ref2, got2)) and not torch.equal(ref2[0], ref[0])
+    # other tensors with the same values elsewhere, a switch, then a non-contiguous view of a wider tensor
+    m2 = means.clone()
+    got3 = both(ws, m2, feat, opac, scales, quats)
+    assert all(torch.equal(a, b) for a, b in zip(ref2, got3))
+    ref4 = both(None, m2, feat, opac, scales, quats, clamp01=True)
+    got4 = both(ws, m2, feat, opac, scales, quats, clamp01=True)
+    assert all(torch.equal(a, b) for a, b in zip(ref4, got4)) and float(got4[0].max()) <= 1.0
+    wide = torch.zeros((P, 4), device=device)
+    wide[:, :3] = m2
+    got5 = both(ws, wide[:, :3], feat, opac, scales, quats)      # same values, strided: must not be read as contiguous
+    assert all(torch.equal(a, b) for a, b in zip(ref2, got5))
+    got6 = both(ws, wide[:, :3], feat, opac, scales, quats)
+    assert all(torch.equal(a, b) for a, b in zip(ref2, got6))
