@@ -162,9 +162,11 @@ class ForwardState:
 
 def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotations, cov3D_precomp,
                   scale_modifier=1.0, antialiasing=False, clamp01=False, debug=False, force_binned=False,
-                  bin_capacity=None, want_aux=False, tune_flags=0, check_capacity=True, workspace=None):
+                  bin_capacity=None, want_aux=False, tune_flags=0, check_capacity="auto", workspace=None):
     """Raw batched forward.  Returns (color (V,C,H,W), invdepth (V,1,H,W), radii (V,P) int32, state[, final_T, n_contrib]).
-    `workspace`: a Workspace whose tensors receive the outputs (see there)."""
+    `workspace`: a Workspace whose tensors receive the outputs (see there).  `check_capacity` (binned path, P > 256):
+    True = read the pair count back every call (one host sync, like the reference), "lazy" = never synchronise, detect an
+    overflowed arena at the next call, "auto" = True for the first call of a shape, lazy afterwards, False = no check."""
     lib = _lib.load()
     key = None
     if workspace is not None and not want_aux:
@@ -175,9 +177,16 @@ def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotati
         if plan is not None and plan[0] == key:
             _, _views, args, dev_index, result, cap_check = plan
             _lib.check(_replay(lib.sks_forward, args, dev_index), "sks_forward")
-            if cap_check is None or int(cap_check[0].max().item()) <= cap_check[1]:
+            if cap_check is None:
                 return result
-            del workspace._plans["fwd"]     # the binning arena overflowed: the validating path below grows it and redoes
+            nr, pcap, ckey = cap_check
+            if check_capacity is True:
+                if int(nr.max().item()) <= pcap:
+                    return result
+                del workspace._plans["fwd"]     # the binning arena overflowed: the validating path below grows it and redoes
+            else:
+                _lazy_probe(ckey, nr, pcap, args[0])
+                return result
     if views.mixed:
         raise RuntimeError("the dense forward writes one (V,C,H,W) tensor: all views of the batch must share the image size")
     if means3D is None or means3D.dim() != 2 or means3D.shape[1] != 3:
@@ -207,7 +216,7 @@ def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotati
             (_lib.SKS_DEBUG_SYNC if debug else 0) | (_lib.SKS_FORCE_BINNED if force_binned else 0) | int(tune_flags) | _ENV_TUNE
     binned = force_binned or P > _lib.SKS_SMALL_P
     if binned and bin_capacity is None:
-        bin_capacity = max(4096, 16 * P)
+        bin_capacity = _BIN_CAP_HINT.get((means3D.device.index, views.V, P, C, views.W, views.H), max(4096, 16 * P))
     cap = int(bin_capacity or 0)
     gbytes, bbytes, _ = _scratch_bytes_cached(V, max(P, 1), C, W, H, cap)
     def new(name, shape, dtype):
@@ -230,13 +239,25 @@ def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotati
             _lib.ptr(binning), cap, _lib.ptr(nrend), _lib.ptr(final_T), _lib.ptr(n_contrib), None]
     _lib.check(_replay(lib.sks_forward, args, dev.index), "sks_forward")
     if binned and check_capacity:
-        # like the reference (rasterizer_impl.cu:283-288) the binned path needs the pair count on the host to size its
-        # buffers: one D2H read; grow and redo when the arena was too small (entries beyond it were dropped)
-        need = int(nrend[:V].max().item())
-        if need > cap:
-            return forward_views(views, means3D, features, opacities, scales, rotations, cov3D_precomp, scale_modifier,
-                                 antialiasing, clamp01, debug, force_binned, int(need * 1.25) + 1024, want_aux, tune_flags,
-                                 check_capacity, workspace)
+        # The reference reads the pair count back on EVERY forward to size its buffers (rasterizer_impl.cu:283-288: a
+        # blocking D2H copy between the scan and the duplication).  Here the arena is persistent and the count stays on
+        # the device: check_capacity=True reads it back (exact: grow and redo when the arena was too small -- entries
+        # beyond it were dropped); "lazy" (what "auto" does after it has sized the arena once per shape with a
+        # synchronous first call) leaves an asynchronous copy + event behind and looks at it when the NEXT call for the
+        # shape comes in -- no host synchronisation on the fast path; an overflow found that way grows the arena for the
+        # calls to come and raises, because the image that call produced was missing entries.
+        cap_key = (dev.index, V, P, C, W, H)
+        lazy = check_capacity == "lazy" or (check_capacity == "auto" and cap_key in _BIN_CAP_SEEN)
+        if lazy:
+            _lazy_probe(cap_key, nrend[:V], cap, V)
+        elif not lazy:
+            need = int(nrend[:V].max().item())
+            _BIN_CAP_SEEN.add(cap_key)
+            if need > cap:
+                _BIN_CAP_HINT[cap_key] = int(need * 1.25) + 1024
+                return forward_views(views, means3D, features, opacities, scales, rotations, cov3D_precomp, scale_modifier,
+                                     antialiasing, clamp01, debug, force_binned, int(need * 1.25) + 1024, want_aux, tune_flags,
+                                     check_capacity, workspace)
     st = ForwardState()
     st.views, st.P, st.C, st.flags, st.scale_modifier = views, P, C, flags, float(scale_modifier)
     st.geom, st.binning, st.bin_capacity, st.radii, st.num_rendered_dev = geom, binning, cap, radii, nrend
@@ -246,11 +267,36 @@ def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotati
         # (the tensors the pointers belong to stay alive in `keep`; the views object is held so that its id stays its own)
         keep = (means3D, feat2, opacities, scales, rotations, cov3D_precomp)
         workspace._plans["fwd"] = (key, (views, keep), args, dev.index, (color, invdepth, radii, st),
-                                   (nrend[:V], cap) if binned and check_capacity else None)
+                                   (nrend[:V], cap, (dev.index, V, P, C, W, H)) if binned and check_capacity else None)
     return color, invdepth, radii, st
 
 
 _SCRATCH_BYTES = {}
+_BIN_CAP_HINT = {}     # (device, V, P, C, W, H) -> arena capacity learned from an overflow
+_BIN_CAP_SEEN = set()  # shapes whose arena a synchronous call has sized already ("auto" goes lazy after that)
+_BIN_PROBE = {}        # shape -> (pinned host counts, event, capacity) of the last lazy call
+
+
+def _lazy_probe(cap_key, nrend, cap, V):
+    """Look at the previous lazy call's pair counts (see forward_views) and leave this call's behind."""
+    if torch.cuda.is_current_stream_capturing():
+        return
+    prev = _BIN_PROBE.pop(cap_key, None)
+    if prev is not None:
+        host, ev, pcap = prev
+        if not ev.query():
+            ev.synchronize()
+        pneed = int(host.max())
+        if pneed > pcap:
+            _BIN_CAP_HINT[cap_key] = int(pneed * 1.25) + 1024
+            raise RuntimeError(f"skelsplat_amd: a previous binned forward of this shape needed {pneed} (Gaussian, tile) pairs "
+                               f"per view but its arena held {pcap}: that image missed entries.  The arena has been grown; "
+                               "call again (check_capacity=True checks every call synchronously).")
+    host = torch.empty(nrend.shape[0], dtype=torch.int32, pin_memory=True)
+    host.copy_(nrend, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(nrend.device))
+    _BIN_PROBE[cap_key] = (host, ev, cap)
 
 
 def _scratch_bytes_cached(V, P, C, W, H, cap):
