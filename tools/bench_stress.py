@@ -30,7 +30,11 @@ for name, fn in (("forward", lambda: R.forward_views(views, *args, bin_capacity=
     alg = 4.0 * H * W * (C + 1) * V * (2 if name == "fwd+bwd" else 1)
     print(f"{name}: {dt*1e3:.3f} ms per {V}-view call, {V/dt:.0f} views/s, algorithmic {alg/dt/1e9:.0f} GB/s")
 
-# dispatch floor of the tile-per-block kernels: every Gaussian culled -> every tile empty
+# dispatch floor of the tile-per-block kernels: every Gaussian culled -> every tile empty.  Only on request: under
+# rocprofv3 these launches would be averaged into the same kernel names as the real ones (round 1's kernel-stats file
+# showed k_render_bwd_binned "43 .. 337 us" for exactly that reason: 43 = all tiles empty, 337 = the stress scene)
+if "--floor" not in sys.argv:
+    sys.exit(0)
 far = (torch.tensor([[0.0, 0.0, 1e9]], device=dev).repeat(big.P, 1),) + args[1:]
 c2, i2, r2, st2 = R.forward_views(views, *far, force_binned=True, bin_capacity=400000)
 for name, fn in (("forward, all tiles empty", lambda: R.forward_views(views, *far, force_binned=True, bin_capacity=400000)),

@@ -16,7 +16,7 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
 DST = os.path.join(ROOT, "profiles")
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
 NAMES = {"h36m": "h36m_4view_1000x1000_P17_C17", "panoptic": "panoptic_31view_1920x1080_P19_C19"}
 
 
@@ -70,7 +70,7 @@ for wl, tag in (("h36m", ""), ("panoptic", "_panoptic"), ("stress", "_stress")):
         if "roofline" in line:
             line["roofline"]["traffic"] = entry["fwd_bytes_per_launch"]
             json.dump(line, open(bj, "w"))
-for name in ("bench_ssim.txt", "ssim_pmc_fwd.txt", "ssim_pmc_train.txt"):   # fused-SSIM timings and SQ counter passes
+for name in ("bench_ssim.txt", "ssim_pmc_fwd.txt", "ssim_pmc_train.txt", "sharded_world1_bench.json", "width_sweep.txt"):   # fused-SSIM timings and SQ counter passes
     src = os.path.join(SRC, name)
     if os.path.exists(src) and os.path.getsize(src):
         shutil.copy(src, os.path.join(DST, f"{rnd}_{name}"))

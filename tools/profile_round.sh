@@ -22,4 +22,7 @@ bash tools/pmc_ssim.sh train 4,17,1000,1000 > "$OUT/ssim_pmc_train.txt" 2>&1
 cd "$ROOT"
 python3 bench.py > "$OUT/h36m_bench.json" 2> "$OUT/h36m_bench.log"
 python3 bench.py --workload panoptic --steps 50 --warmup 5 > "$OUT/panoptic_bench.json" 2> "$OUT/panoptic_bench.log"
+# the sharded path at world size 1 (RCCL all_gather included, the group also replayed as a hipGraph)
+SKS_BENCH_FORCE_DIST=1 SKS_GRAPH_COLLECTIVES=1 python3 bench.py --steps 50 --warmup 5 > "$OUT/sharded_world1_bench.json" 2> "$OUT/sharded_world1_bench.log"
+python3 tools/width_sweep2.py 1000,1002,1024,1920 0 > "$OUT/width_sweep.txt" 2>&1
 find "$OUT" -name "*.csv" | head -40
