@@ -89,8 +89,9 @@ def cpu_baseline(scene, params, n_views):
 
 
 class ApiStep:
-    """One step through the C ABI: sks_forward + sks_backward of this process's views (dL resident), [all_gather of the
-    per-view joint gradients,] mean over the V views (train.py:175, 215-217)."""
+    """One step through the C ABI: sks_forward + sks_backward of this process's views (dL resident) and the mean of the
+    per-view joint gradients over the V views (train.py:175, 215-217) -- on one GPU formed by sks_backward itself
+    (dL_dmeans3D_mean), sharded: all_gather of the per-view gradients, then the mean."""
 
     def __init__(self, views, params, dL, V_total=None, exchange=None):
         import torch
@@ -113,7 +114,9 @@ class ApiStep:
         gx = None
         if self.views is not None:
             color, inv, radii, st = R.forward_views(self.views, *self.params, None, workspace=self.ws)
-            g = R.backward_views(st, *self.params, None, self.dL, workspace=self.ws)
+            g = R.backward_views(st, *self.params, None, self.dL, workspace=self.ws, want_mean=self.exchange is None)
+            if self.exchange is None:
+                return g["means3D_mean"]     # the mean over the views comes out of the backward's own last launch
             gx = g["means3D"]
         if self.exchange is not None:
             if gx is not None:
@@ -221,7 +224,8 @@ def run_single(args, torch, dev, wl):
         "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": wl["name"], "views_per_step": V, "P": P, "C": C, "W": W, "H": H, "parallelism": "single GPU",
-                   "path": "C ABI sks_forward + sks_backward, eager launches, outputs in a reused workspace"},
+                   "path": "C ABI sks_forward + sks_backward (incl. the mean over the views), eager launches, outputs in a "
+                           "reused workspace"},
     }
     if pf and pf[1]:
         res["roofline"] = roofline_entry(4.0 * H * W * (C + 1) * V, pf, wl["name"], args.steps)

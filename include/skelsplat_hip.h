@@ -98,6 +98,9 @@ int sks_backward(int V, int P, int C, int W, int H,
                  void* accum,
                  float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dopacity,
                  float* dL_dscales, float* dL_drotations, float* dL_dcov3D, float* dL_dfeatures,
+                 float* dL_dmeans3D_mean /* optional (P,3): the mean of dL_dmeans3D over the V views, summed in view order --
+                 what the reference's loop forms right after the backward (xyz.grad = accumulated_grads.mean(dim=0),
+                 train.py:215-217); for V * P <= 256 it comes out of the same launch as the geometry backward */,
                  void* stream);
 
 /* Replaces _C.mark_visible (DGR/rasterize_points.cu:225-244; checkFrustum rasterizer_impl.cu:54-66).

@@ -31,7 +31,7 @@ SIGNATURES = {
     "sks_forward": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _u,
                          _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
     "sks_backward": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _u,
-                          _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+                          _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sks_mark_visible": (_i, [_i, _vp, _vp, _vp, _vp, _vp]),
     "sks_export_lists": (_i, [_i, _i, _i, _vp, _sz, _vp, _vp, _vp]),
     "sks_masked_l2": (_i, [_i, _sz, _vp, _vp, _vp, _vp, _vp]),

@@ -166,7 +166,7 @@ void sks_set_error_(const char* msg)  // used by the other translation units of 
 {
     snprintf(g_err, sizeof(g_err), "%s", msg);
 }
-int sks_version(void) { return 2; }
+int sks_version(void) { return 3; }
 
 int sks_scratch_bytes(int V, int P, int C, int W, int H, size_t bin_capacity, size_t* geom, size_t* binning, size_t* accum)
 {
@@ -258,7 +258,7 @@ int sks_backward(int V, int P, int C, int W, int H, const float* viewmatrix, con
                  const float* cov3D_precomp, float scale_modifier, unsigned flags, const int* radii, const void* geom,
                  const void* binning, size_t bin_capacity, const float* dL_dout_color, const float* dL_dout_invdepth,
                  void* accum, float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dopacity, float* dL_dscales,
-                 float* dL_drotations, float* dL_dcov3D, float* dL_dfeatures, void* stream)
+                 float* dL_drotations, float* dL_dcov3D, float* dL_dfeatures, float* dL_dmeans3D_mean, void* stream)
 {
     if (int rc = check_common(V, P, C, W, H)) return rc;
     if (P == 0) return 0;
@@ -299,7 +299,13 @@ int sks_backward(int V, int P, int C, int W, int H, const float* viewmatrix, con
     GeomBwdArgs ga{ P, C, W, H, flags, viewmatrix, projmatrix, means3D, opacities, scales, rotations, cov3D_precomp,
                     scale_modifier, radii, (const float*)accum, small ? BWD_SPLITS : 1, nullptr, nullptr, nullptr, dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dscales,
                     dL_drotations, dL_dcov3D, dL_dfeatures };
-    hipLaunchKernelGGL(k_geom_bwd, dim3((P + 255) / 256, V), dim3(256), 0, st, ga, vt);
+    if (dL_dmeans3D_mean && V * P <= 256) {
+        hipLaunchKernelGGL(k_geom_bwd_all, dim3(1), dim3(256), 0, st, ga, vt, V, dL_dmeans3D_mean);
+    } else {
+        hipLaunchKernelGGL(k_geom_bwd, dim3((P + 255) / 256, V), dim3(256), 0, st, ga, vt);
+        if (dL_dmeans3D_mean)
+            hipLaunchKernelGGL(k_mean_views, dim3((3 * P + 255) / 256), dim3(256), 0, st, V, P, dL_dmeans3D, dL_dmeans3D_mean);
+    }
     STAGE_CHECK("geometry-backward");
     return 0;
 }

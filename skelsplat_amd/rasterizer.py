@@ -336,13 +336,15 @@ def _bg_channels(bg, C, dev):
 
 
 def backward_views(st: ForwardState, means3D, features, opacities, scales, rotations, cov3D_precomp, dL_dcolor,
-                   dL_dinvdepth=None, bg=None, want_dfeatures=False, tune_flags=0, workspace=None):
-    """Raw batched backward: per-view gradients, dict of (V,P,...) tensors (`workspace`: see Workspace)."""
+                   dL_dinvdepth=None, bg=None, want_dfeatures=False, tune_flags=0, workspace=None, want_mean=False):
+    """Raw batched backward: per-view gradients, dict of (V,P,...) tensors (`workspace`: see Workspace).  `want_mean`: also
+    "means3D_mean" (P,3), the mean of the joint gradients over the views (train.py:215-217), formed inside the library."""
     lib = _lib.load()
     key = None
     if workspace is not None and st.P:
         key = (id(st), _sig(means3D), _sig(features), _sig(opacities), _sig(scales), _sig(rotations), _sig(cov3D_precomp),
                _sig(dL_dcolor), _sig(dL_dinvdepth), None if bg is None else (id(bg), bg._version), want_dfeatures, tune_flags,
+               want_mean,
                torch._C._cuda_getCurrentRawStream(st.geom.device.index))   # (the partial-sum scratch is per stream)
         plan = workspace._plans.get("bwd")
         if plan is not None and plan[0] == key:
@@ -356,8 +358,11 @@ def backward_views(st: ForwardState, means3D, features, opacities, scales, rotat
     if st.P == 0:
         dev, V, C = means3D.device, st.views.V, st.C
         z = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
-        return dict(means3D=z(V, 0, 3), means2D=z(V, 0, 3), opacities=z(V, 0, 1), cov3D=z(V, 0, 6), scales=z(V, 0, 3),
-                    rotations=z(V, 0, 4), features=z(V, 0, C) if want_dfeatures else None)
+        empty = dict(means3D=z(V, 0, 3), means2D=z(V, 0, 3), opacities=z(V, 0, 1), cov3D=z(V, 0, 6), scales=z(V, 0, 3),
+                     rotations=z(V, 0, 4), features=z(V, 0, C) if want_dfeatures else None)
+        if want_mean:
+            empty["means3D_mean"] = z(0, 3)
+        return empty
     means3D = _f32c(means3D, "means3D")
     dev = means3D.device
     V, P, C = st.views.V, st.P, st.C
@@ -378,6 +383,8 @@ def backward_views(st: ForwardState, means3D, features, opacities, scales, rotat
                scales=e("sc", V, P, 3) if scales is not None else None,
                rotations=e("rot", V, P, 4) if rotations is not None else None,
                features=e("feat", V, P, C) if want_dfeatures else None)
+    if want_mean:
+        out["means3D_mean"] = e("m3mean", P, 3)
     stream = torch._C._cuda_getCurrentRawStream(dev.index)
     accum = _accum(dev, stream, V, P, C)
     args = [V, P, C, W, H, st.views.viewmatrix.data_ptr(), st.views.projmatrix.data_ptr(),
@@ -387,7 +394,7 @@ def backward_views(st: ForwardState, means3D, features, opacities, scales, rotat
             st.bin_capacity, dL_dcolor.data_ptr(), _lib.ptr(dL_dinvdepth), accum.data_ptr(),
             _lib.ptr(out["means3D"]), _lib.ptr(out["means2D"]), _lib.ptr(out["opacities"]),
             _lib.ptr(out["scales"]), _lib.ptr(out["rotations"]), _lib.ptr(out["cov3D"]),
-            _lib.ptr(out["features"]), None]
+            _lib.ptr(out["features"]), _lib.ptr(out.get("means3D_mean")), None]
     rc = _replay(lib.sks_backward, args, dev.index)
     if rc != 0:
         reset_scratch()

@@ -859,3 +859,30 @@ def test_workspace_replay_follows_the_inputs(device):
     assert all(torch.equal(a, b) for a, b in zip(ref2, got5))
     got6 = both(ws, wide[:, :3], feat, opac, scales, quats)
     assert all(torch.equal(a, b) for a, b in zip(ref2, got6))
+
+
+@pytest.mark.parametrize("n_views,dataset", [(4, "h36m"), (20, "panoptic")], ids=["one-launch", "mean-kernel"])
+def test_backward_mean_over_views(device, n_views, dataset):
+    """sks_backward's optional dL_dmeans3D_mean = the mean of the per-view joint gradients in view order (what the loop forms
+    right after the backward, train.py:215-217): from the geometry backward's own launch when V * P <= 256, else from a
+    small kernel behind it; the per-view outputs are unchanged either way."""
+    c = util.make_case(seed=12, W=96, H=80, n_views=n_views, scale_log=4.2, dataset=dataset)
+    views = R.ViewBatch.from_cameras([cam.to(device) for cam in c.cams])
+    args = (t(c.means, device), t(c.feat, device), t(c.opac, device), t(c.scales, device), t(c.quats, device), None)
+    dL = t(c.dL_color, device)
+    assert (n_views * c.P <= 256) == (dataset == "h36m")
+    _, _, _, st = R.forward_views(views, *args)
+    ref = R.backward_views(st, *args, dL)
+    got = R.backward_views(st, *args, dL, want_mean=True)
+    for k in ("means3D", "means2D", "opacities", "scales", "rotations", "cov3D"):
+        assert torch.equal(ref[k], got[k]), k
+    want = ref["means3D"][0].clone()
+    for v in range(1, n_views):
+        want += ref["means3D"][v]
+    want /= float(n_views)
+    assert torch.equal(got["means3D_mean"], want)
+    ws = R.Workspace()
+    for _ in range(2):
+        _, _, _, st2 = R.forward_views(views, *args, workspace=ws)
+        g2 = R.backward_views(st2, *args, dL, workspace=ws, want_mean=True)
+        assert torch.equal(g2["means3D_mean"], want)
