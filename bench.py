@@ -104,26 +104,22 @@ class ApiStep:
             vmax = (V_total + world - 1) // world
             self.shard = torch.zeros((vmax, P, 3), device=dev)      # pad rows stay zero
             self.allg = torch.empty((world * vmax, P, 3), device=dev)
-            # view v = row (v % world) * vmax + v // world of the gathered buffer: one precomputed index
-            self.rows = torch.tensor([(v % world) * vmax + v // world for v in range(V_total)], dtype=torch.long, device=dev)
+            self.mean_out = torch.empty((P, 3), device=dev)
+            self.V_total = V_total
         self.ws = R.Workspace()
 
     def __call__(self):
         import torch.distributed as dist
         R = self.R
-        gx = None
-        if self.views is not None:
+        if self.exchange is None:
             color, inv, radii, st = R.forward_views(self.views, *self.params, None, workspace=self.ws)
-            g = R.backward_views(st, *self.params, None, self.dL, workspace=self.ws, want_mean=self.exchange is None)
-            if self.exchange is None:
-                return g["means3D_mean"]     # the mean over the views comes out of the backward's own last launch
-            gx = g["means3D"]
-        if self.exchange is not None:
-            if gx is not None:
-                self.shard[:gx.shape[0]].copy_(gx)
-            dist.all_gather_into_tensor(self.allg, self.shard, group=self.exchange[2])
-            gx = self.allg.index_select(0, self.rows)
-        return gx.mean(dim=0)
+            g = R.backward_views(st, *self.params, None, self.dL, workspace=self.ws, want_mean=True)
+            return g["means3D_mean"]     # the mean over the views comes out of the backward's own last launch
+        if self.views is not None:       # this rank's views; their joint gradients land in its rows of the shard
+            color, inv, radii, st = R.forward_views(self.views, *self.params, None, workspace=self.ws)
+            R.backward_views(st, *self.params, None, self.dL, workspace=self.ws, out_means3D=self.shard[:self.views.V])
+        dist.all_gather_into_tensor(self.allg, self.shard, group=self.exchange[2])
+        return R.mean_views(self.allg, self.V_total, self.exchange[0], out=self.mean_out)   # reads the gathered rows in place
 
 
 def timed(fn, steps, warmup, sync):

@@ -103,6 +103,12 @@ int sks_backward(int V, int P, int C, int W, int H,
                  train.py:215-217); for V * P <= 256 it comes out of the same launch as the geometry backward */,
                  void* stream);
 
+/* xyz.grad = accumulated_grads.mean(dim=0) (train.py:215-217) on its own: mean over the V views of (V,P,3) joint gradients,
+ * summed in view order.  shard_world = N > 1: the rows are where all_gather_into_tensor leaves them when view v is local view
+ * v / N of rank v % N and every rank contributes ceil(V / N) rows (see sks_loop_adam_step) -- the exchange step of a
+ * view-sharded caller is then all_gather + this one launch, with no re-ordering pass in between. */
+int sks_mean_views(int V, int P, const float* dL_dmeans3D, int shard_world, float* mean_out /* (P,3) */, void* stream);
+
 /* Replaces _C.mark_visible (DGR/rasterize_points.cu:225-244; checkFrustum rasterizer_impl.cu:54-66).
  * present: P bytes (bool). */
 int sks_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,

@@ -33,6 +33,7 @@ SIGNATURES = {
     "sks_backward": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _u,
                           _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sks_mark_visible": (_i, [_i, _vp, _vp, _vp, _vp, _vp]),
+    "sks_mean_views": (_i, [_i, _i, _vp, _i, _vp, _vp]),
     "sks_export_lists": (_i, [_i, _i, _i, _vp, _sz, _vp, _vp, _vp]),
     "sks_masked_l2": (_i, [_i, _sz, _vp, _vp, _vp, _vp, _vp]),
     "sks_fused_ssim_fwd": (_i, [_i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

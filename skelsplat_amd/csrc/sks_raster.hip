@@ -310,6 +310,16 @@ int sks_backward(int V, int P, int C, int W, int H, const float* viewmatrix, con
     return 0;
 }
 
+int sks_mean_views(int V, int P, const float* dL_dmeans3D, int shard_world, float* mean_out, void* stream)
+{
+    if (V < 1 || P < 1 || shard_world < 1) return fail(-1, "mean_views: bad shape");
+    if (!dL_dmeans3D || !mean_out) return fail(-2, "mean_views: missing pointer");
+    hipLaunchKernelGGL(k_mean_views, dim3((3 * P + 255) / 256), dim3(256), 0, (hipStream_t)stream, V, P, dL_dmeans3D, mean_out,
+                       shard_world);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int sks_gt_tile_stats(int V, int C, int W, int H, const float* gt, float* tile_S, float* tile_N, double* totals, void* stream)
 {
     if (int rc = check_common(V, 1, C, W, H)) return rc;

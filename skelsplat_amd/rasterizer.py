@@ -336,15 +336,18 @@ def _bg_channels(bg, C, dev):
 
 
 def backward_views(st: ForwardState, means3D, features, opacities, scales, rotations, cov3D_precomp, dL_dcolor,
-                   dL_dinvdepth=None, bg=None, want_dfeatures=False, tune_flags=0, workspace=None, want_mean=False):
+                   dL_dinvdepth=None, bg=None, want_dfeatures=False, tune_flags=0, workspace=None, want_mean=False,
+                   out_means3D=None):
     """Raw batched backward: per-view gradients, dict of (V,P,...) tensors (`workspace`: see Workspace).  `want_mean`: also
-    "means3D_mean" (P,3), the mean of the joint gradients over the views (train.py:215-217), formed inside the library."""
+    "means3D_mean" (P,3), the mean of the joint gradients over the views (train.py:215-217), formed inside the library.
+    `out_means3D`: a contiguous fp32 (V,P,3) tensor to receive "means3D" (a view-sharded caller passes the rows of its
+    all_gather shard: no copy between the backward and the exchange)."""
     lib = _lib.load()
     key = None
     if workspace is not None and st.P:
         key = (id(st), _sig(means3D), _sig(features), _sig(opacities), _sig(scales), _sig(rotations), _sig(cov3D_precomp),
                _sig(dL_dcolor), _sig(dL_dinvdepth), None if bg is None else (id(bg), bg._version), want_dfeatures, tune_flags,
-               want_mean,
+               want_mean, None if out_means3D is None else out_means3D.data_ptr(),
                torch._C._cuda_getCurrentRawStream(st.geom.device.index))   # (the partial-sum scratch is per stream)
         plan = workspace._plans.get("bwd")
         if plan is not None and plan[0] == key:
@@ -385,6 +388,11 @@ def backward_views(st: ForwardState, means3D, features, opacities, scales, rotat
                features=e("feat", V, P, C) if want_dfeatures else None)
     if want_mean:
         out["means3D_mean"] = e("m3mean", P, 3)
+    if out_means3D is not None:
+        if tuple(out_means3D.shape) != (V, P, 3) or out_means3D.dtype != torch.float32 or not out_means3D.is_contiguous() \
+                or out_means3D.device != dev:
+            raise ValueError(f"out_means3D must be a contiguous fp32 (V,P,3) = {(V, P, 3)} tensor on {dev}")
+        out["means3D"] = out_means3D
     stream = torch._C._cuda_getCurrentRawStream(dev.index)
     accum = _accum(dev, stream, V, P, C)
     args = [V, P, C, W, H, st.views.viewmatrix.data_ptr(), st.views.projmatrix.data_ptr(),
@@ -402,6 +410,23 @@ def backward_views(st: ForwardState, means3D, features, opacities, scales, rotat
     if key is not None and all(sg is not False for sg in key[1:9]) and not torch.cuda.is_current_stream_capturing():
         keep = (st, means3D, feat2, opacities, scales, rotations, cov3D_precomp, dL_dcolor, dL_dinvdepth, bg, bgC, accum)
         workspace._plans["bwd"] = (key, keep, args, dev.index, out)
+    return out
+
+
+def mean_views(grads, V, world=1, out=None):
+    """Mean over the V views of (rows,P,3) joint gradients, summed in view order (train.py:215-217).  world > 1: `grads` is
+    what all_gather_into_tensor left for a view-sharded group (world * ceil(V / world) rows, rank-major)."""
+    vmax = (V + world - 1) // world
+    P = grads.shape[1]
+    if grads.dtype != torch.float32 or not grads.is_contiguous() or grads.shape[0] < (V if world == 1 else world * vmax) \
+            or grads.shape[2] != 3:
+        raise ValueError("mean_views: grads must be a contiguous fp32 (rows,P,3) tensor with a row for every view")
+    _need_gpu(grads, "grads")
+    if out is None:
+        out = torch.empty((P, 3), dtype=torch.float32, device=grads.device)
+    rc = _lib.load().sks_mean_views(V, P, grads.data_ptr(), world, out.data_ptr(),
+                                    torch._C._cuda_getCurrentRawStream(grads.device.index))
+    _lib.check(rc, "sks_mean_views")
     return out
 
 

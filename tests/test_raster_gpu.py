@@ -889,3 +889,29 @@ def test_backward_mean_over_views(device, n_views, dataset):
         _, _, _, st2 = R.forward_views(views, *args, workspace=ws)
         g2 = R.backward_views(st2, *args, dL, workspace=ws, want_mean=True)
         assert torch.equal(g2["means3D_mean"], got["means3D_mean"])
+
+
+def test_mean_views_on_gathered_rows_and_backward_into_a_shard(device):
+    """The exchange step of a view-sharded caller of the rasterizer API: sks_backward writes its views' joint gradients
+    straight into the rows of the all_gather shard (out_means3D), and sks_mean_views reads the gathered rank-major buffer
+    in place (view v = row (v % N) * ceil(V / N) + v // N; NaN pad rows must never be read)."""
+    c = util.make_case(seed=14, W=96, H=80, n_views=7, scale_log=4.2)
+    views = R.ViewBatch.from_cameras([cam.to(device) for cam in c.cams])
+    args = (t(c.means, device), t(c.feat, device), t(c.opac, device), t(c.scales, device), t(c.quats, device), None)
+    dL = t(c.dL_color, device)
+    _, _, _, st = R.forward_views(views, *args)
+    ref = R.backward_views(st, *args, dL, want_mean=True)
+    V, P = 7, c.P
+    shard = torch.full((9, P, 3), float("nan"), device=device)
+    got = R.backward_views(st, *args, dL, out_means3D=shard[:V])
+    assert got["means3D"].data_ptr() == shard.data_ptr() and torch.equal(shard[:V], ref["means3D"])
+    assert torch.isnan(shard[V:]).all()
+    assert torch.equal(R.mean_views(ref["means3D"], V), ref["means3D_mean"])
+    for world in (2, 3, 4, 8):
+        vmax = (V + world - 1) // world
+        buf = torch.full((world * vmax, P, 3), float("nan"), device=device)
+        for v in range(V):
+            buf[(v % world) * vmax + v // world] = ref["means3D"][v]
+        assert torch.equal(R.mean_views(buf, V, world), ref["means3D_mean"]), world
+    with pytest.raises(ValueError):
+        R.backward_views(st, *args, dL, out_means3D=shard[:V, :, :2])
