@@ -260,7 +260,7 @@ int sks_loop_fused_step(int V, int P, int C, int W, int H, const float* viewmatr
                         const int* view_wh /*HOST V x {W,H} or NULL*/, const size_t* gt_offsets /*HOST V or NULL*/,
                         void* stream);
 
-/* Measurement hook used by bench.py (no reference counterpart): while enabled, the dominant kernel of sks_forward
+/* Measurement hook used by bench.py (no reference counterpart; state per HOST THREAD, like the error text): while enabled, the dominant kernel of sks_forward
  * (kind 0: forward compositor) and of sks_backward (kind 1: backward compositor) is bracketed by hipEvents recorded
  * on the caller's stream.  on = 1: every launch; on = n > 1: every n-th launch of each kind (an event pair costs ~3 us of
  * queue time, so sampling keeps the measured loop undisturbed).  sks_prof_read waits for the recorded events, returns

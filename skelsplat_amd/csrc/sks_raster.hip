@@ -446,16 +446,21 @@ int sks_loop_fused_step(int V, int P, int C, int W, int H, const float* viewmatr
 
 int sks_prof_enable(int on)
 {
-    g_prof_on = on != 0;
-    g_prof_every = on > 1 ? on : 1;
-    g_prof_seen[0] = g_prof_seen[1] = 0;
+    if (!tl_prof) {
+        if (!on) return 0;
+        tl_prof = new ProfState();
+    }
+    tl_prof->on = on != 0;
+    tl_prof->every = on > 1 ? on : 1;
+    tl_prof->seen[0] = tl_prof->seen[1] = 0;
     return 0;
 }
 
 int sks_prof_read(int kind, double* total_ms, long long* launches)
 {
     if (kind < 0 || kind > 1 || !total_ms || !launches) return fail(-2, "bad profile query");
-    ProfKind& p = g_prof[kind];
+    if (!tl_prof) { *total_ms = 0.0; *launches = 0; return 0; }
+    ProfKind& p = tl_prof->kind[kind];
     double tot = 0;
     for (int i = 0; i < p.n; i++) {
         HIP_TRY(hipEventSynchronize(p.e[i]));
@@ -472,7 +477,8 @@ int sks_prof_read(int kind, double* total_ms, long long* launches)
 int sks_prof_read_quantiles(int kind, double* q_ms /* 3: p10, p50, p90 */, double* total_ms, long long* launches)
 {
     if (kind < 0 || kind > 1 || !q_ms || !total_ms || !launches) return fail(-2, "bad profile query");
-    ProfKind& p = g_prof[kind];
+    if (!tl_prof) { q_ms[0] = q_ms[1] = q_ms[2] = 0.0; *total_ms = 0.0; *launches = 0; return 0; }
+    ProfKind& p = tl_prof->kind[kind];
     static thread_local float t[PROF_MAX];
     double tot = 0;
     for (int i = 0; i < p.n; i++) {
