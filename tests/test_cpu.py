@@ -578,3 +578,30 @@ def test_evaluate_against_reference_golden(tmp_path):
     lo, hi = (int(x) for x in G["eval_pan_range"])
     r = io.evaluate(gt_root, outp, 500, lo, hi)
     assert abs(r["abs"] - float(G["eval_pan_abs"])) < 1e-3 and abs(r["rel"] - float(G["eval_pan_rel"])) < 1e-3
+
+
+def test_bench_starts_its_own_launcher_for_n_gpus(monkeypatch):
+    """`python bench.py --gpus N` without a launcher around it must not fall back to one GPU silently: it starts
+    torch.distributed.run with one rank per GPU as a child process and hands its exit code through; under a launcher whose
+    WORLD_SIZE disagrees with --gpus it refuses."""
+    import subprocess
+    import sys
+    import types
+    sys.path.insert(0, ROOT)
+    import bench
+    seen = {}
+
+    def fake_run(cmd, **kw):
+        seen["cmd"] = cmd
+        return types.SimpleNamespace(returncode=7)
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "9", "--warmup", "2"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "9", "--warmup", "2"] and cmd[-7].endswith("bench.py")

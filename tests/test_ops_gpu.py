@@ -809,3 +809,35 @@ def test_heatmap_dropout_zeroes_the_drawn_planes(device):
     assert float(hm[m].abs().max()) == 0.0 and torch.equal(hm[~m], base[~m])
     torch.testing.assert_close(totals[:, 0], (hm.double() ** 2).sum(dim=(1, 2, 3)), rtol=1e-6, atol=0)   # (fp32 partial sums per thread)
     assert torch.equal(totals[:, 1], (hm > 0).sum(dim=(1, 2, 3)).double())
+
+
+@pytest.mark.parametrize("mixed", [False, True], ids=["4x1000", "1002-1000-1000-1002"])
+def test_full_size_h36m_loop_sparse_equals_dense(device, mixed):
+    """BASELINE config 2 at full size, through the loop: 40 iterations of the sparse fused step (two launches per group,
+    hipGraphs) end where the dense device path (full images, sks_masked_l2, dense backward) ends -- with four equal sensors
+    and with H36M's real mix of 1002- and 1000-wide ones (one launch sequence in the sparse path, two in the dense one)."""
+    from skelsplat_amd.loop import MultiViewLoop
+    from skelsplat_amd.heatmaps import generate_heatmaps
+    from skelsplat_amd.scene import SyntheticScene, GaussianModel
+    a = SyntheticScene("h36m", n_views=4, seed=0, device=device, W=1000, H=1000)
+    b = SyntheticScene("h36m", n_views=4, seed=0, device=device, W=1002, H=1000)
+    cams = [b.cameras[0], a.cameras[1], a.cameras[2], b.cameras[3]] if mixed else a.cameras
+    res = []
+    for kw in (dict(sparse=True, use_graph=True), dict(sparse=False)):
+        gm = GaussianModel().create_from_points(a.pose_3d_init, a.spatial_lr_scale, 17, device=device)
+        gm.training_setup()
+        hms = [generate_heatmaps(gm._xyz.detach(), gm.get_scaling.detach(), gm._rotation.detach(),
+                                 torch.tensor(a.poses_2d[v:v + 1], device=device), [cams[v]])[0] for v in range(4)]
+        loop = MultiViewLoop(gm, cams, hms if mixed else torch.stack(hms), dataset="h36m", **kw)
+        assert (len(loop.size_groups) == 2) == mixed
+        if kw["sparse"]:
+            assert loop.fused_tail and (loop.views_all.mixed == mixed)
+        loop.run(40)
+        S, N = loop.last_losses
+        res.append([x.detach().clone() for x in (gm._xyz, gm._scaling, gm._rotation, N, S)])
+    moved = (res[0][0].cpu() - torch.tensor(a.pose_3d_init).float()).norm(dim=1).mean().item()
+    assert moved > 0.5
+    assert (res[0][0] - res[1][0]).norm(dim=1).max().item() < 2e-3 * moved
+    util.assert_close("scaling", res[0][1].cpu(), res[1][1].cpu(), rtol=1e-4, atol_scale=1e-4)
+    assert torch.equal(res[0][3], res[1][3])                                  # mask counts: integers, exact
+    assert ((res[0][4] - res[1][4]).abs() <= 1e-5 * res[1][4].abs()).all()
