@@ -622,6 +622,11 @@ def main():
                          f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device (no CPU fallback)")
+    # SKS_BENCH_ONE_DEVICE=1 (tests): every rank on GPU 0 over gloo -- RCCL refuses two ranks on one device; this checks
+    # the sharded logic at world > 1 on a single-GPU box, its timings mean nothing
+    one_device = os.environ.get("SKS_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or os.environ.get("SKS_BENCH_FORCE_DIST") == "1"   # the env switch runs the sharded path at world 1
@@ -630,7 +635,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        if one_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     wl = WORKLOADS[args.workload or ("panoptic" if use_dist else "h36m")]
     if use_dist:

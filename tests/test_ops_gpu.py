@@ -841,3 +841,66 @@ def test_full_size_h36m_loop_sparse_equals_dense(device, mixed):
     util.assert_close("scaling", res[0][1].cpu(), res[1][1].cpu(), rtol=1e-4, atol_scale=1e-4)
     assert torch.equal(res[0][3], res[1][3])                                  # mask counts: integers, exact
     assert ((res[0][4] - res[1][4]).abs() <= 1e-5 * res[1][4].abs()).all()
+
+
+# ------------------------------------------------------------------ two ranks, one GPU (gloo): the sharded branch at world 2
+def _two_rank_worker(rank, world, port, mode, ret):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)   # RCCL refuses two ranks on one device
+    from skelsplat_amd.loop import MultiViewLoop
+    from skelsplat_amd.heatmaps import generate_heatmaps
+    from skelsplat_amd.scene import SyntheticScene
+    sc, model = _make_loop_scene(dev, V=5, seed=41)          # 5 views over 2 ranks: shards of 3 and 2, one pad row
+    cams = sc.cameras
+    if mode == "mixed":
+        b = SyntheticScene("h36m", n_views=5, seed=41, W=162, H=128, ring=2500.0, fx=1145.0 * 0.16 * 1.5, device=dev)
+        cams = [b.cameras[0], sc.cameras[1], sc.cameras[2], b.cameras[3], sc.cameras[4]]
+    gm = model(dev)
+    with torch.no_grad():
+        gm._opacity.fill_(2.0)
+    hms = [generate_heatmaps(gm._xyz.detach(), gm.get_scaling.detach(), gm._rotation.detach(),
+                             torch.tensor(sc.poses_2d[v:v + 1], device=dev), [cams[v]])[0] for v in range(5)]
+    loop = MultiViewLoop(gm, cams, hms, dataset="h36m", accumulation_steps=5, sparse=mode != "dense", fused_tail=False)
+    assert loop.world == world and loop.exchange == (world > 1) and loop.device_tail
+    if world > 1:
+        assert loop.local_ids == [v for v in range(5) if v % 2 == rank] and tuple(loop._allg.shape) == (6, 17, 11)
+    loop.run(30)
+    torch.cuda.synchronize()
+    if rank == 0:
+        ret.put([x.detach().cpu().numpy() for x in (gm._xyz, gm._scaling, gm._rotation, gm._opacity, loop.accumulated_grads)])
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["sparse", "dense", "mixed"])
+def test_two_ranks_on_one_gpu_equal_one_rank(device, mode):
+    """The view-sharded device path at world size 2 -- uneven shards (3 + 2 views, one zero pad row), all_gather, the
+    rank-major optimiser kernel, every rank stepping identically -- as two processes sharing this GPU over gloo (RCCL
+    does not allow two ranks on one device; the collective's transport is not what is under test).  Bit-identical to
+    one process."""
+    import os
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = 29700 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, mode, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    two = ret.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    one_p = ctx.Process(target=_two_rank_worker, args=(0, 1, port + 1, mode, ret))
+    one_p.start()
+    one = ret.get(timeout=300)
+    one_p.join(timeout=120)
+    assert one_p.exitcode == 0
+    for k, (a, b) in enumerate(zip(two, one)):
+        assert np.array_equal(a, b), k
