@@ -52,6 +52,9 @@ extern "C" {
 #define SKS_FILL_ROWS (1u << 22)    /* tuning/tests: row-aligned fill blocks whenever W % 4 == 0 */
 /* bits 26..29: tuning, composite blocks per (view, Gaussian) of the small-path forward (0 = default 4) */
 #define SKS_BWD_LDS_LIST (1u << 20) /* tests: use the LDS-list backward even when P <= 64 (default: wave-resident) */
+/* bits 23..25: tuning/tests, workgroups per (view, Gaussian) of the wave-resident backward = 16 >> (value - 1)
+   (0 = automatic: 16 for a few views, fewer and longer ones when V x P is large; the results do not depend on it) */
+#define SKS_BWD_WG_SHIFT 23
 
 const char* sks_last_error(void);
 int sks_version(void);
@@ -145,7 +148,9 @@ int sks_heatmaps(int V, int J, int W, int H, const float* row, const float* col,
  * tanfovx/tanfovy HOST arrays of V. */
 int sks_heatmap_factors(int V, int J, int W, int H, const float* means3D, const float* scales, const float* rotations,
                         float scale_modifier, const float* poses_2d, const float* viewmatrix, const float* tanfovx,
-                        const float* tanfovy, float* row, float* col, float* cmin, float* den, void* stream);
+                        const float* tanfovy, float* row, float* col, float* cmin, float* den,
+                        int frames /* 1; > 1: V = frames x Vf views, parameters stacked (frames,J,..), see sks_loop_fused_step */,
+                        void* stream);
 
 /* Replaces fusedssim (submodules/fused-ssim/ssim.cu:368-404, binding ext.cpp): img1, img2, ssim_map and the three
  * optional partial-derivative maps (train == true) are (B,CH,H,W) fp32; "same" zero padding. */
@@ -205,7 +210,8 @@ int sks_geometry(int V, int P, int C, int W, int H, const float* viewmatrix, con
                  const float* tanfovx /*HOST V*/, const float* tanfovy /*HOST V*/, const float* means3D,
                  const float* opacities, const float* scales, const float* rotations, const float* cov3D_precomp,
                  float scale_modifier, unsigned flags, int* radii, void* geom,
-                 const int* view_wh /*HOST V x {W,H} or NULL: see below*/, void* stream);
+                 const int* view_wh /*HOST V x {W,H} or NULL: see below*/, int frames /* 1, or see sks_loop_fused_step */,
+                 void* stream);
 int sks_backward_fused_loss(int V, int P, int C, int W, int H, const float* viewmatrix, const float* projmatrix,
                             const float* tanfovx /*HOST V*/, const float* tanfovy /*HOST V*/, const float* bg,
                             const float* means3D, const float* features, const float* opacities, const float* scales,
@@ -248,7 +254,15 @@ int sks_loop_adam_step(int V, int P, const float* grads, float* slots, unsigned 
  * Precondition: `geom` / `radii` hold the geometry of the current parameters (sks_geometry with SKS_RAW_PARAMS, or the
  * previous sks_loop_fused_step); on return they hold the geometry of the updated ones.  xyz / scaling / rotation / opacity
  * are the RAW leaf parameters (updated in place); packed: (V,P,11) scratch (the group's raw-parameter gradients on
- * return); loss_sums: out, V x {S, N}.  P <= 64.  Results are bit-identical to the separate calls. */
+ * return); loss_sums: out, V x {S, N}.  P <= 64.  Results are bit-identical to the separate calls.
+ *
+ * frames > 1 batches INDEPENDENT frames (the reference optimises one frame after the other, train.py:74-99, and a
+ * 17-Gaussian skeleton leaves most of the chip idle): V = frames x Vf views, view f*Vf + j is frame f's j-th view (the
+ * camera rows are repeated per frame), and every frame owns a slice of the stacked tensors -- xyz/scaling (frames,P,3),
+ * rotation (frames,P,4), opacity (frames,P), exp_avg/exp_avg_sq (frames,P,11), slots (frames,Vf,P,3), counters
+ * (frames,2).  group_mask (bit j = view j of EVERY frame) and last_view are per frame (0 <= last_view < Vf); features,
+ * the optimiser's hyper-parameters and the limb pairs are shared.  Each frame's results are bit-identical to running
+ * it alone with frames = 1. */
 int sks_loop_fused_step(int V, int P, int C, int W, int H, const float* viewmatrix, const float* projmatrix,
                         const float* tanfovx /*HOST V*/, const float* tanfovy /*HOST V*/, const float* features,
                         float scale_modifier, unsigned flags, int* radii, void* geom, const float* gt,
@@ -258,7 +272,7 @@ int sks_loop_fused_step(int V, int P, int C, int W, int H, const float* viewmatr
                         const double* lr_sched /*HOST 5*/, const double* lrs /*HOST 3*/, const double* adam /*HOST 3*/,
                         float lambda_consistency, const int* limb /*HOST 8 or NULL*/,
                         const int* view_wh /*HOST V x {W,H} or NULL*/, const size_t* gt_offsets /*HOST V or NULL*/,
-                        void* stream);
+                        int frames, void* stream);
 
 /* Measurement hook used by bench.py (no reference counterpart; state per HOST THREAD, like the error text): while enabled, the dominant kernel of sks_forward
  * (kind 0: forward compositor) and of sks_backward (kind 1: backward compositor) is bracketed by hipEvents recorded

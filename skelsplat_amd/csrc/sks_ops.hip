@@ -401,11 +401,15 @@ __global__ __launch_bounds__(256) void k_heatmap_factors(int J, int W, int H, co
                                                           float scale_modifier, const float* __restrict__ poses_2d,
                                                           const float* __restrict__ viewmatrix, HmTan tan,
                                                           float* __restrict__ row, float* __restrict__ col,
-                                                          float* __restrict__ cmin, float* __restrict__ den)
+                                                          float* __restrict__ cmin, float* __restrict__ den, int vf)
 {
     __shared__ double s_red[4];
     __shared__ float s_redf[4];
     const int j = blockIdx.x, v = blockIdx.y, vj = v * J + j;
+    if (vf > 0) {   // frames batched: view v belongs to frame v / vf, whose J Gaussians sit frame-th in the stacked tensors
+        const size_t fr = (size_t)(v / vf);
+        means += fr * J * 3; scales += fr * J * 3; rots += fr * J * 4;
+    }
     // ---- lambda1, lambda2 (every thread the same scalars) ----
     const float q0 = rots[4 * j], q1 = rots[4 * j + 1], q2 = rots[4 * j + 2], q3 = rots[4 * j + 3];
     const float qn = sqrtf(((q0 * q0 + q1 * q1) + q2 * q2) + q3 * q3);
@@ -528,15 +532,16 @@ int sks_heatmaps(int V, int J, int W, int H, const float* row, const float* col,
 
 int sks_heatmap_factors(int V, int J, int W, int H, const float* means3D, const float* scales, const float* rotations,
                         float scale_modifier, const float* poses_2d, const float* viewmatrix, const float* tanfovx,
-                        const float* tanfovy, float* row, float* col, float* cmin, float* den, void* stream)
+                        const float* tanfovy, float* row, float* col, float* cmin, float* den, int frames, void* stream)
 {
     if (V < 1 || V > SKS_MAX_VIEWS || J < 1 || W < 1 || H < 1) return fail2(-1, "heatmap factors: bad shape");
+    if (frames < 1 || V % frames) return fail2(-1, "heatmap factors: frames must divide the number of views");
     if (!means3D || !scales || !rotations || !poses_2d || !viewmatrix || !tanfovx || !tanfovy || !row || !col || !cmin || !den)
         return fail2(-2, "heatmap factors: missing pointer");
     HmTan tan;
     for (int v = 0; v < V; v++) { tan.x[v] = tanfovx[v]; tan.y[v] = tanfovy[v]; }
     hipLaunchKernelGGL(k_heatmap_factors, dim3(J, V), dim3(256), 0, (hipStream_t)stream, J, W, H, means3D, scales, rotations,
-                       scale_modifier, poses_2d, viewmatrix, tan, row, col, cmin, den);
+                       scale_modifier, poses_2d, viewmatrix, tan, row, col, cmin, den, frames > 1 ? V / frames : 0);
     HIP_TRY2(hipGetLastError());
     return 0;
 }

@@ -23,6 +23,7 @@
 // followed here by the launchers and the extern "C" entry points of include/skelsplat_hip.h.
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -133,6 +134,17 @@ void launch_fwd_binned(const FwdArgs& a, const BinView& bv, int V, int gx, int g
     }
 }
 
+// workgroups per (view, Gaussian) of k_render_bwd_wave (they share the BWD_SPLITS partial-sum slots; see the kernel)
+inline int bwd_wave_groups(int V, int P, unsigned flags)
+{
+    unsigned t = (flags >> SKS_BWD_WG_SHIFT) & 7u;
+    static const int env = [] { const char* e = getenv("SKS_BWD_WG"); return e ? atoi(e) : 0; }();   // tuning sweeps only
+    if (!t && env > 0) t = (unsigned)env;
+    if (t) return t > 5 ? 1 : (BWD_SPLITS >> (t - 1));
+    const int pairs = V * P;
+    return pairs <= BWD_WG_PAIRS16 ? 16 : (pairs <= BWD_WG_PAIRS8 ? 8 : 4);
+}
+
 template <int CG>
 void launch_bwd_small(const BwdArgs& a, const ViewTan& vt, const ViewOff& vo, int V, int gy, bool dfeat, hipStream_t st)
 {
@@ -140,12 +152,13 @@ void launch_bwd_small(const BwdArgs& a, const ViewTan& vt, const ViewOff& vo, in
     // slot index slowest: a (view, Gaussian) only has work for its first ceil(pixels / 256) slots, so the idle workgroups
     // (half of them on the skeleton scenes) come last in dispatch order instead of holding wave slots the working ones
     // wait for (the fused-loss kernel fits 3 workgroups per CU: 768 of H36M's 1 088 at once)
-    dim3 grid(a.P, V, BWD_SPLITS);
     if (a.P <= 64 && !(a.flags & (1u << 20))) {  // wave-resident variant (bit 20: force the LDS variant, tests)
+        dim3 grid(a.P, V, bwd_wave_groups(V, a.P, a.flags));
         if (dfeat) hipLaunchKernelGGL((k_render_bwd_wave<CG, true, false>), grid, dim3(256), 0, st, a, vt, vo);
         else hipLaunchKernelGGL((k_render_bwd_wave<CG, false, false>), grid, dim3(256), 0, st, a, vt, vo);
         return;
     }
+    dim3 grid(a.P, V, BWD_SPLITS);
     const size_t lds = GatherLds<CG>::bytes((a.P + 15) & ~15, CG, a.C);
     if (lds > 48 * 1024) {  // gfx950 has 160 KB of LDS per CU; raise the per-kernel dynamic limit when P is large
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render_bwd_gather<CG, true>),
@@ -166,7 +179,7 @@ void sks_set_error_(const char* msg)  // used by the other translation units of 
 {
     snprintf(g_err, sizeof(g_err), "%s", msg);
 }
-int sks_version(void) { return 3; }
+int sks_version(void) { return 4; }
 
 int sks_scratch_bytes(int V, int P, int C, int W, int H, size_t bin_capacity, size_t* geom, size_t* binning, size_t* accum)
 {
@@ -205,7 +218,7 @@ int sks_forward(int V, int P, int C, int W, int H, const float* viewmatrix, cons
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE, NT = gx * gy;
 
     hipLaunchKernelGGL(k_geom_fwd, dim3((P + 255) / 256, V), dim3(256), 0, st, P, W, H, vt, viewmatrix, projmatrix,
-                       means3D, opacities, scales, rotations, cov3D_precomp, scale_modifier, flags, g, radii);
+                       means3D, opacities, scales, rotations, cov3D_precomp, scale_modifier, flags, g, radii, 0);
     STAGE_CHECK("geometry");
 
     FwdArgs a{ P, C, W, H, flags, g, features, out_color, out_invdepth, final_T, n_contrib, composite_slots(flags, V, P),
@@ -356,7 +369,7 @@ int sks_backward_fused_loss(int V, int P, int C, int W, int H, const float* view
     if ((view_wh != nullptr) != (gt_offsets != nullptr)) return fail(-2, "view_wh and gt_offsets go together");
     Geom g = geom_from(const_cast<void*>(geom), V, P, W, H);
     BwdArgs a{ P, C, W, H, flags | SKS_CLAMP01, g, features, bg, gt, nullptr, (float*)accum, tile_S, tile_N };
-    dim3 grid(P, V, BWD_SPLITS);   // see launch_bwd_small
+    dim3 grid(P, V, bwd_wave_groups(V, P, flags));   // see launch_bwd_small
     {
         ProfScope prof(1, st);
         switch (pick_cg(C)) {
@@ -378,10 +391,11 @@ int sks_backward_fused_loss(int V, int P, int C, int W, int H, const float* view
 int sks_geometry(int V, int P, int C, int W, int H, const float* viewmatrix, const float* projmatrix, const float* tanfovx,
                  const float* tanfovy, const float* means3D, const float* opacities, const float* scales,
                  const float* rotations, const float* cov3D_precomp, float scale_modifier, unsigned flags, int* radii,
-                 void* geom, const int* view_wh, void* stream)
+                 void* geom, const int* view_wh, int frames, void* stream)
 {
     if (int rc = check_common(V, P, C, W, H)) return rc;
     if (P < 1) return fail(-1, "P must be positive");
+    if (frames < 1 || V % frames) return fail(-1, "frames must divide the number of views (V = %d, frames = %d)", V, frames);
     if (!viewmatrix || !projmatrix || !tanfovx || !tanfovy || !means3D || !opacities || !radii || !geom)
         return fail(-2, "missing required pointer");
     if (!cov3D_precomp && (!scales || !rotations)) return fail(-2, "need scales+rotations or cov3D_precomp");
@@ -392,7 +406,8 @@ int sks_geometry(int V, int P, int C, int W, int H, const float* viewmatrix, con
     Geom g = geom_from(geom, V, P, W, H);
     if (view_wh) g.cover = nullptr;   // the cover rows serve the dense forward, which needs one image size
     hipLaunchKernelGGL(k_geom_fwd, dim3((P + 255) / 256, V), dim3(256), 0, st, P, W, H, vt, viewmatrix, projmatrix,
-                       means3D, opacities, scales, rotations, cov3D_precomp, scale_modifier, flags, g, radii);
+                       means3D, opacities, scales, rotations, cov3D_precomp, scale_modifier, flags, g, radii,
+                       frames > 1 ? V / frames : 0);
     STAGE_CHECK("geometry");
     return 0;
 }
@@ -403,10 +418,13 @@ int sks_loop_fused_step(int V, int P, int C, int W, int H, const float* viewmatr
                         double* loss_sums, float* packed, float* slots, unsigned long long group_mask, int last_view,
                         float* xyz, float* scaling, float* rotation, float* opacity, float* exp_avg, float* exp_avg_sq,
                         int* counters, int acc_steps, const double* lr_sched, const double* lrs, const double* adam,
-                        float lambda_consistency, const int* limb, const int* view_wh, const size_t* gt_offsets, void* stream)
+                        float lambda_consistency, const int* limb, const int* view_wh, const size_t* gt_offsets, int frames,
+                        void* stream)
 {
     if (int rc = check_common(V, P, C, W, H)) return rc;
     if (P < 1 || P > 64) return fail(-1, "fused step needs 1 <= P <= 64 (got %d)", P);
+    if (frames < 1 || V % frames) return fail(-1, "frames must divide the number of views (V = %d, frames = %d)", V, frames);
+    const int Vf = V / frames;   // views of one frame: the optimiser's V (slots, group mask, last_view are per frame)
     if (!viewmatrix || !projmatrix || !tanfovx || !tanfovy || !features || !radii || !geom || !gt || !gt_totals || !accum ||
         !loss_sums || !packed)
         return fail(-2, "missing required pointer");
@@ -418,14 +436,14 @@ int sks_loop_fused_step(int V, int P, int C, int W, int H, const float* viewmatr
     if ((view_wh != nullptr) != (gt_offsets != nullptr)) return fail(-2, "view_wh and gt_offsets go together");
     flags |= SKS_RAW_PARAMS | SKS_CLAMP01;
     sksloop::AdamArgs aa;
-    if (const char* err = sksloop::fill_adam_args(aa, V, P, packed, slots, group_mask, last_view, xyz, scaling, rotation, opacity,
+    if (const char* err = sksloop::fill_adam_args(aa, Vf, P, packed, slots, group_mask, last_view, xyz, scaling, rotation, opacity,
                                                   exp_avg, exp_avg_sq, counters, acc_steps, lr_sched, lrs, adam,
                                                   lambda_consistency, limb))
         return fail(-2, "%s", err);
     Geom g = geom_from(geom, V, P, W, H);
     g.cover = nullptr;   // no forward render on this path
     BwdArgs a{ P, C, W, H, flags, g, features, nullptr, gt, nullptr, (float*)accum, nullptr, nullptr };
-    dim3 grid(P, V, BWD_SPLITS);   // see launch_bwd_small
+    dim3 grid(P, V, bwd_wave_groups(V, P, flags));   // see launch_bwd_small
     {
         ProfScope prof(1, st);
         switch (pick_cg(C)) {
@@ -439,7 +457,7 @@ int sks_loop_fused_step(int V, int P, int C, int W, int H, const float* viewmatr
     GeomBwdArgs ga{ P, C, W, H, flags, viewmatrix, projmatrix, xyz, opacity, scaling, rotation, nullptr, scale_modifier, radii,
                     (const float*)accum, BWD_SPLITS, gt_totals, loss_sums, packed, nullptr, nullptr, nullptr, nullptr, nullptr,
                     nullptr, nullptr };
-    hipLaunchKernelGGL(k_step_tail, dim3(1), dim3(256), 0, st, ga, vt, aa, V, g, radii);
+    hipLaunchKernelGGL(k_step_tail, dim3(frames), dim3(256), 0, st, ga, vt, aa, Vf, g, radii);
     STAGE_CHECK("step tail");
     return 0;
 }

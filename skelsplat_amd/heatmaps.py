@@ -23,19 +23,23 @@ def covariance_from_scaling_rotation(scaling, rotation_raw, modifier=1.0):
     return L @ L.transpose(1, 2)
 
 
-def heatmap_factors(means, scaling, rotation_raw, poses_2d, cameras, scaling_modifier=1.0, views=None):
+def heatmap_factors(means, scaling, rotation_raw, poses_2d, cameras, scaling_modifier=1.0, views=None, frames=1):
     """The separable description of the (V, J, H, W) heat-maps: row (V,J,H) = 255 * impulse response along y,
     col (V,J,W) = impulse response along x, cmin (V,J), den (V,J) with
     plane = (row[:, None] * col[None, :] - cmin) / den.
     The plane minimum / maximum are the products of the factor minima / maxima (everything is non-negative and fp32
     multiplication is monotone), so the min-max normalisation of normalize_heatmaps (:300-304) needs no image pass.
     One kernel launch (sks_heatmap_factors), no host synchronisation.  `views`: a rasterizer.ViewBatch of `cameras` to
-    reuse (scene streaming), else built here."""
+    reuse (scene streaming), else built here.  `frames` > 1: independent frames in one launch -- `cameras` / `views`
+    list frames x Vf views frame-major, the parameters are stacked (frames, J, ..) and poses_2d is (frames*Vf, J, 2)."""
     from . import _lib
     from .rasterizer import ViewBatch, _f32c
     dev = means.device
     W, H = int(cameras[0].image_width), int(cameras[0].image_height)
     V = len(cameras)
+    frames = int(frames)
+    if frames < 1 or V % frames or (frames > 1 and (means.dim() != 3 or means.shape[0] != frames)):
+        raise ValueError(f"frames = {frames}: needs frames x Vf cameras and parameters stacked (frames, J, ..)")
     for cam in cameras:
         if int(cam.image_width) != W or int(cam.image_height) != H:
             raise ValueError("generate_heatmaps: all cameras must share (W, H)")
@@ -43,7 +47,7 @@ def heatmap_factors(means, scaling, rotation_raw, poses_2d, cameras, scaling_mod
     poses_2d = torch.as_tensor(poses_2d, device=dev)
     if views is None:
         views = ViewBatch.from_cameras(cameras)
-    J = means.shape[0]
+    J = means.shape[-2]
     p2d = poses_2d.to(torch.float32).contiguous()
     if tuple(p2d.shape) != (V, J, 2):
         raise ValueError(f"poses_2d must be (V, J, 2) = {(V, J, 2)}, got {tuple(p2d.shape)}")
@@ -55,7 +59,8 @@ def heatmap_factors(means, scaling, rotation_raw, poses_2d, cameras, scaling_mod
         rc = _lib.load().sks_heatmap_factors(V, J, W, H, means.data_ptr(), scaling.data_ptr(), rotation_raw.data_ptr(),
                                              float(scaling_modifier), p2d.data_ptr(), views.viewmatrix.data_ptr(),
                                              views.tanfovx, views.tanfovy, row.data_ptr(), col.data_ptr(),
-                                             cmin.data_ptr(), den.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+                                             cmin.data_ptr(), den.data_ptr(), frames,
+                                             torch.cuda.current_stream(dev).cuda_stream)
     _lib.check(rc, "sks_heatmap_factors")
     return row, col, cmin, den
 
@@ -75,7 +80,7 @@ def draw_dropout(n_views, n_joints, generator=None):
 
 
 def generate_heatmaps(means, scaling, rotation_raw, poses_2d, cameras, scaling_modifier=1.0, out=None, views=None,
-                      totals=None, dropout=False, drop_mask=None):
+                      totals=None, dropout=False, drop_mask=None, frames=1):
     """(V, J, H, W) normalised heat-maps on the parameters' ROCm device; all cameras must share (W, H).  poses_2d:
     (V, J, 2) pixel (x, y).  general_utils.py:175-304 with dropout=False, as two launches (sks_heatmap_factors, then the
     planes by the streaming kernel sks_heatmaps).  `out`: optional (V,J,H,W) fp32 buffer to write into (scene
@@ -83,9 +88,10 @@ def generate_heatmaps(means, scaling, rotation_raw, poses_2d, cameras, scaling_m
     {sum gt^2, count gt > 0} (rasterizer.GtStats.totals) while the planes are written, instead of a separate pass.
     `dropout=True` draws the reference's dropped (camera, joint) planes (draw_dropout); `drop_mask` (V,J) bool gives them
     explicitly.  A dropped plane has no impulse: it is all zero before and after normalize_heatmaps (0 / 1e-8), which the
-    separable form states as row = 0, cmin = 0, den = 1."""
+    separable form states as row = 0, cmin = 0, den = 1.  `frames`: see heatmap_factors."""
     from . import _lib
-    row, col, cmin, den = heatmap_factors(means, scaling, rotation_raw, poses_2d, cameras, scaling_modifier, views=views)
+    row, col, cmin, den = heatmap_factors(means, scaling, rotation_raw, poses_2d, cameras, scaling_modifier, views=views,
+                                          frames=frames)
     if dropout and drop_mask is None:
         drop_mask = draw_dropout(row.shape[0], row.shape[1])
     if drop_mask is not None:

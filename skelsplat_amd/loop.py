@@ -14,6 +14,8 @@ on every rank, so the mean uses the reference's summation order and every rank t
 """
 import math
 
+import numpy as np
+
 import torch
 import torch.distributed as dist
 
@@ -562,6 +564,196 @@ class MultiViewLoop:
         while self.iteration < iterations and self.stopped_at is None:
             self.step_group()
         return self.gm._xyz.detach()
+
+
+class FrameBatchLoop:
+    """F independent frames seen by the SAME cameras, optimised side by side in the sparse fused step.
+
+    The reference optimises one frame after the other (train.py:74-99: a fresh GaussianModel and fresh heat-maps per
+    scene, nothing carried over), and one 17-Gaussian skeleton keeps only a fraction of an MI355X busy: the fused
+    render+loss+backward kernel of a 4-view group launches 4 x 17 x 16 workgroups for 256 CUs, and the single-workgroup
+    tail (geometry backward, Adam, next geometry) runs on ONE.  Frames being independent, F of them go through the same
+    two launches: `sks_loop_fused_step(frames=F)` renders F x V views and steps F optimisers, one workgroup per frame.
+    Every frame's trajectory is bit-identical to a MultiViewLoop running it alone (tests/test_ops_gpu.py).
+
+    `gaussians`: a GaussianModel of ONE frame after training_setup() -- the template for the initial scaling /
+    rotation / opacity, the one-hot features and the optimiser's configuration; its own tensors are not touched.
+    Parameters live stacked: xyz / scaling (F,P,3), rotation (F,P,4), opacity (F,P,1).  F x V <= 64 views per launch.
+    Early stopping (a per-frame host decision, one sync per group) is MultiViewLoop's business, not this class's."""
+
+    def __init__(self, gaussians, cameras, frames, dataset="h36m", accumulation_steps=4, lambda_consistency=1e-5,
+                 antialiasing=False, use_graph=False):
+        import ctypes
+        gm = gaussians
+        self.gm = gm
+        self.dataset = dataset
+        self.cameras = cameras
+        self.F, self.V = int(frames), len(cameras)
+        F, V = self.F, self.V
+        if F < 1 or F * V > R._lib.SKS_MAX_VIEWS:
+            raise ValueError(f"frames x views = {F} x {V} exceeds the {R._lib.SKS_MAX_VIEWS} views of one launch")
+        P = gm._xyz.shape[0]
+        if P > 64:
+            raise ValueError("frame batching runs the sparse fused step: P <= 64 Gaussians per frame")
+        self.P = P
+        dev = gm._xyz.device
+        self.device = dev
+        self.acc_steps = int(accumulation_steps)
+        self.lambda_consistency = float(lambda_consistency)
+        self.antialiasing = antialiasing
+        self.use_graph = bool(use_graph)
+        self.features = gm.get_features.detach().reshape(P, -1).contiguous()
+        self.C = self.features.shape[1]
+        init = gm._initial
+        self._init = (init[0].reshape(1, P, 3), init[1].reshape(1, P, 4), init[2].reshape(1, P, 1))
+        self.xyz = gm._xyz.detach().reshape(1, P, 3).repeat(F, 1, 1).contiguous()
+        self.scaling = self._init[0].repeat(F, 1, 1).contiguous()
+        self.rotation = self._init[1].repeat(F, 1, 1).contiguous()
+        self.opacity = self._init[2].repeat(F, 1, 1).contiguous()
+        self.exp_avg = torch.zeros((F, P, 11), device=dev)
+        self.exp_avg_sq = torch.zeros((F, P, 11), device=dev)
+        self.counters = torch.zeros((F, 2), dtype=torch.int32, device=dev)
+        self.accumulated_grads = torch.zeros((F, V, P, 3), device=dev)    # train.py:121, one V-slot buffer per frame
+        self._packed = torch.zeros((F * V, P, 11), device=dev)
+        self._sums = torch.zeros((F * V, 2), dtype=torch.float64, device=dev)
+        cfg = gm.opt_cfg
+        self._sched = (ctypes.c_double * 5)(cfg["lr_init"], cfg["lr_final"], cfg["lr_delay_mult"],
+                                            float(cfg["lr_delay_steps"]), float(cfg["lr_max_steps"]))
+        self._lrs = (ctypes.c_double * 3)(cfg["lr_scaling"], cfg["lr_rotation"], cfg["lr_opacity"])
+        self._adam = (ctypes.c_double * 3)(cfg["betas"][0], cfg["betas"][1], cfg["eps"])
+        limbs = [i for pair in DATASETS[dataset]["limbs"] for i in pair]
+        self._limb = (ctypes.c_int * 8)(*limbs) if self.lambda_consistency != 0.0 else None
+        # heat-maps of all F x V views (frame-major) in one flat buffer; views of one size adjacent (H36M: two sizes)
+        cams_all = [cameras[k % V] for k in range(F * V)]
+        sizes = [(int(c.image_width), int(c.image_height)) for c in cams_all]
+        self.hset = R.HeatmapSet(sizes, self.C, dev)
+        self.size_groups = []     # [slots (frame-major), ViewBatch of them, (Vg,C,H,W) planes, GtStats, slot index tensor]
+        for key, slots in self.hset.groups.items():
+            vb = R.ViewBatch.from_cameras([cams_all[k] for k in slots])
+            gt = self.hset.group(key)
+            gt.zero_()
+            self.size_groups.append([slots, vb, gt, R.gt_tile_stats(gt), torch.tensor(slots, dtype=torch.long, device=dev)])
+        if len(self.size_groups) == 1:
+            self.views_all, self.stats_all = self.size_groups[0][1], self.size_groups[0][3]
+        else:
+            self.views_all = R.ViewBatch.from_cameras(cams_all, allow_mixed=True)
+            st = R.GtStats()
+            st.gt, st.tile_S, st.tile_N = self.hset.flat, None, None
+            st.totals = torch.zeros((F * V, 2), dtype=torch.float64, device=dev)
+            st.offsets = self.hset.offsets
+            self.stats_all = st
+        with torch.no_grad():
+            self._fstate = R.geometry_views(self.views_all, self.xyz, self.C, self.opacity, self.scaling, self.rotation, None,
+                                            antialiasing=antialiasing, raw_params=True, frames=F)
+        self._geom_valid = False
+        self._graph = None
+        self._multi = None
+        self.iteration = 0
+        self.last_losses = None
+
+    def new_scenes(self, points, poses_2d=None, heatmaps=None, drop_masks=None):
+        """The next F frames: `points` (F,P,3) initial joints; either `poses_2d` (F,V,J,2) -- the heat-maps are generated
+        from the re-initialised Gaussians like general_utils.py:175-304, all frames in two launches per image size -- or
+        ready `heatmaps` (F,V,C,H,W) / a list of F lists of V (C,H_v,W_v) planes.  `drop_masks`: optional (F,V,J) bool of
+        dropped heat-map planes (heatmaps.draw_dropout per frame).  Everything is re-initialised in place, so captured
+        hipGraphs are replayed as they are."""
+        from .heatmaps import generate_heatmaps
+        F, V, P = self.F, self.V, self.P
+        with torch.no_grad():
+            pts = points if torch.is_tensor(points) else torch.as_tensor(np.asarray(points))
+            if tuple(pts.shape) != (F, P, 3):
+                raise ValueError(f"points must be (F,P,3) = {(F, P, 3)}, got {tuple(pts.shape)}")
+            self.xyz.copy_(pts.to(device=self.device, dtype=torch.float32))
+            self.scaling.copy_(self._init[0].expand(F, P, 3))
+            self.rotation.copy_(self._init[1].expand(F, P, 4))
+            self.opacity.copy_(self._init[2].expand(F, P, 1))
+            self.exp_avg.zero_(); self.exp_avg_sq.zero_(); self.counters.zero_(); self.accumulated_grads.zero_()
+            if poses_2d is not None:
+                p2d_all = torch.as_tensor(poses_2d, device=self.device).reshape(F * V, -1, 2)
+                drop_all = None if drop_masks is None else torch.as_tensor(drop_masks).reshape(F * V, -1)
+            elif heatmaps is None:
+                raise ValueError("new_scenes needs poses_2d or heatmaps")
+            for slots, vb, gt, stats, idx in self.size_groups:
+                if heatmaps is not None:
+                    for i, k in enumerate(slots):
+                        gt[i].copy_(heatmaps[k // V][k % V])
+                    R.gt_tile_stats(gt, out=stats)
+                else:
+                    generate_heatmaps(self.xyz, torch.exp(self.scaling), self.rotation, p2d_all[idx],
+                                      [self.cameras[k % V] for k in slots], out=gt, views=vb, totals=stats.totals,
+                                      drop_mask=None if drop_all is None else drop_all[idx.cpu()], frames=F)
+                if len(self.size_groups) > 1:
+                    self.stats_all.totals.index_copy_(0, idx, stats.totals)
+        self._geom_valid = False
+        self.iteration = 0
+        return self
+
+    def _device_group(self, group_mask, last_view, n_iters):
+        with torch.no_grad():
+            if not self._geom_valid:
+                self._fstate = R.geometry_views(self.views_all, self.xyz, self.C, self.opacity, self.scaling, self.rotation,
+                                                None, antialiasing=self.antialiasing, raw_params=True, out=self._fstate,
+                                                frames=self.F)
+                self._geom_valid = True
+            R.loop_fused_step(self._fstate, self.stats_all, self.features, self._packed, self._sums, self.accumulated_grads,
+                              group_mask, last_view, self.xyz, self.scaling, self.rotation, self.opacity, self.exp_avg,
+                              self.exp_avg_sq, self.counters, n_iters, self._sched, self._lrs, self._adam,
+                              self.lambda_consistency, self._limb)
+        s = self._sums.view(self.F, self.V, 2)
+        self.last_losses = (s[..., 0], s[..., 1])       # per (frame, view) {S, N}: loss = S / N
+
+    def step_group(self):
+        """Iterations self.iteration+1 .. the next optimiser step of EVERY frame (train.py:130-222; the frames share the
+        iteration counter, the view order and therefore the group's view mask)."""
+        it0 = self.iteration + 1
+        it1 = it0
+        while it1 % self.acc_steps != 0:
+            it1 += 1
+        view_of_iter = [(it - 1) % self.V for it in range(it0, it1 + 1)]
+        mask = 0
+        for v in view_of_iter:
+            mask |= 1 << v
+        key = (mask, view_of_iter[-1], it1 - it0 + 1)
+        if self.use_graph:
+            if self._graph is None or self._graph[0] != key:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    self._geom_valid = False
+                    self._device_group(*key)
+                self._graph = (key, graph)
+            self._graph[1].replay()
+        else:
+            self._geom_valid = False
+            self._device_group(*key)
+        self.iteration = it1
+        return it1
+
+    def run(self, iterations=500, groups_per_graph=25):
+        """All F frames up to `iterations`; returns the joints (F,P,3).  With use_graph, `groups_per_graph` groups are one
+        hipGraph, as in MultiViewLoop.run."""
+        if self.use_graph and self.acc_steps % self.V == 0 and self.iteration % self.acc_steps == 0:
+            key = ((1 << self.V) - 1, (self.acc_steps - 1) % self.V, self.acc_steps)
+            remaining = (iterations - self.iteration) // self.acc_steps
+            G = min(int(groups_per_graph), remaining)
+            if G > 1:
+                if self._multi is None or self._multi[0] != (key, G):
+                    self._geom_valid = False
+                    self._device_group(*key)
+                    self.iteration += self.acc_steps
+                    remaining -= 1
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        self._geom_valid = False
+                        for _ in range(G):
+                            self._device_group(*key)
+                    self._multi = ((key, G), graph)
+                while remaining >= G:
+                    self._multi[1].replay()
+                    self.iteration += G * self.acc_steps
+                    remaining -= G
+        while self.iteration < iterations:
+            self.step_group()
+        return self.xyz
 
 
 def mpjpe(pred, gt):

@@ -157,7 +157,10 @@ class ForwardState:
     """What backward needs (the reference keeps geomBuffer / binningBuffer / imgBuffer + num_rendered,
     DGR/diff_gaussian_rasterization_h36m/__init__.py:87-89)."""
     __slots__ = ("views", "P", "C", "flags", "scale_modifier", "geom", "binning", "bin_capacity", "radii",
-                 "num_rendered_dev")
+                 "num_rendered_dev", "frames")
+
+    def __init__(self):
+        self.frames = 1
 
 
 def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotations, cov3D_precomp,
@@ -681,19 +684,26 @@ def gt_tile_stats(gt, out=None, tiles=False):
 
 
 def geometry_views(views: ViewBatch, means3D, C, opacities, scales, rotations, cov3D_precomp, scale_modifier=1.0,
-                   antialiasing=False, raw_params=False, out=None):
+                   antialiasing=False, raw_params=False, out=None, frames=1):
     """Geometry stage only (no image): returns a ForwardState usable by backward_fused_loss.  raw_params: the three
-    tensors are the leaf parameters (_opacity, _scaling, _rotation); activations run in-kernel (SKS_RAW_PARAMS)."""
+    tensors are the leaf parameters (_opacity, _scaling, _rotation); activations run in-kernel (SKS_RAW_PARAMS).
+    frames > 1: `views` holds frames x Vf views (frame-major) and the parameter tensors are stacked (frames, P, ..):
+    view f*Vf + j renders frame f's Gaussians (see sks_loop_fused_step)."""
     lib = _lib.load()
     means3D = _f32c(means3D, "means3D")
     dev = means3D.device
-    P = means3D.shape[0]
+    frames = int(frames)
+    if frames < 1 or views.V % frames:
+        raise ValueError(f"frames = {frames} must divide the number of views ({views.V})")
+    if frames > 1 and (means3D.dim() != 3 or means3D.shape[0] != frames):
+        raise ValueError(f"frames = {frames} needs parameters stacked (frames, P, ..); means3D is {tuple(means3D.shape)}")
+    P = means3D.shape[-2]
     opacities = _f32c(opacities, "opacities")
     scales, rotations, cov3D_precomp = _f32c(scales, "scales"), _f32c(rotations, "rotations"), _f32c(cov3D_precomp, "cov3D_precomp")
     V, W, H = views.V, views.W, views.H
     flags = (_lib.SKS_ANTIALIASING if antialiasing else 0) | (_lib.SKS_RAW_PARAMS if raw_params else 0)
     gbytes, _, _ = _lib.scratch_bytes(V, max(P, 1), C, W, H, 0)
-    if out is not None and out.P == P and out.C == C and out.views is views and out.flags == flags:
+    if out is not None and out.P == P and out.C == C and out.views is views and out.flags == flags and out.frames == frames:
         radii, geom = out.radii, out.geom       # refill in place (persistent state of the fused loop step)
     else:
         radii = torch.empty((V, P), dtype=torch.int32, device=dev)
@@ -702,9 +712,10 @@ def geometry_views(views: ViewBatch, means3D, C, opacities, scales, rotations, c
         rc = lib.sks_geometry(V, P, C, W, H, views.viewmatrix.data_ptr(), views.projmatrix.data_ptr(), views.tanfovx,
                               views.tanfovy, _lib.ptr(means3D), _lib.ptr(opacities), _lib.ptr(scales), _lib.ptr(rotations),
                               _lib.ptr(cov3D_precomp), float(scale_modifier), flags, radii.data_ptr(), geom.data_ptr(),
-                              views.wh, torch.cuda.current_stream(dev).cuda_stream)
+                              views.wh, frames, torch.cuda.current_stream(dev).cuda_stream)
     _lib.check(rc, "sks_geometry")
     st = ForwardState()
+    st.frames = frames
     st.views, st.P, st.C, st.flags, st.scale_modifier = views, P, C, flags, float(scale_modifier)
     st.geom, st.binning, st.bin_capacity, st.radii, st.num_rendered_dev = geom, None, 0, radii, None
     return st
@@ -726,7 +737,8 @@ def loop_fused_step(st: ForwardState, stats: GtStats, features, packed, sums, sl
                     rotation, opacity, exp_avg, exp_avg_sq, counters, acc_steps, lr_sched, lrs, adam, lambda_consistency, limb):
     """sks_loop_fused_step: fused-loss compositing backward + (geometry backward, Adam step, geometry forward of the
     updated parameters) for one accumulation group; `st` must describe the current parameters and is left describing the
-    updated ones.  lr_sched / lrs / adam / limb: ctypes arrays as for sks_loop_adam_step."""
+    updated ones.  lr_sched / lrs / adam / limb: ctypes arrays as for sks_loop_adam_step.  A state made with
+    geometry_views(frames=F) steps F independent frames at once (stacked parameter / moment / slot / counter tensors)."""
     lib = _lib.load()
     dev = xyz.device
     V, P, C = st.views.V, st.P, st.C
@@ -742,7 +754,8 @@ def loop_fused_step(st: ForwardState, stats: GtStats, features, packed, sums, sl
                                      accum.data_ptr(), sums.data_ptr(), packed.data_ptr(), slots.data_ptr(), group_mask,
                                      last_view, xyz.data_ptr(), scaling.data_ptr(), rotation.data_ptr(), opacity.data_ptr(),
                                      exp_avg.data_ptr(), exp_avg_sq.data_ptr(), counters.data_ptr(), acc_steps, lr_sched, lrs,
-                                     adam, float(lambda_consistency), limb, st.views.wh, stats.offsets, stream)
+                                     adam, float(lambda_consistency), limb, st.views.wh, stats.offsets,
+                                     st.frames, stream)
     _lib.check(rc, "sks_loop_fused_step")
 
 

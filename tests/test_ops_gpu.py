@@ -843,6 +843,79 @@ def test_full_size_h36m_loop_sparse_equals_dense(device, mixed):
     assert ((res[0][4] - res[1][4]).abs() <= 1e-5 * res[1][4].abs()).all()
 
 
+
+# ------------------------------------------------------------------ frame batching: F frames in the two launches of one
+@pytest.mark.parametrize("mode", ["same", "mixed", "graph5"])
+def test_frame_batch_equals_separate_loops(device, mode):
+    """FrameBatchLoop steps F independent frames per launch (sks_loop_fused_step(frames=F), one tail workgroup per frame);
+    every frame must end EXACTLY where a MultiViewLoop running it alone ends: parameters, Adam moments, V-slot buffers,
+    per-view losses, and the heat-maps generated for it.  `mixed`: two image sizes (H36M's 1000/1002 sensors, scaled);
+    `graph5`: 5 views with 4-iteration groups (masks that rotate) inside hipGraphs."""
+    from skelsplat_amd.loop import MultiViewLoop, FrameBatchLoop
+    from skelsplat_amd.scene import SyntheticScene, GaussianModel
+    F = 3
+    V = 5 if mode == "graph5" else 4
+    sc, model = _make_loop_scene(device, V=V, seed=51)
+    cams = sc.cameras
+    if mode == "mixed":
+        b = SyntheticScene("h36m", n_views=V, seed=51, W=162, H=128, ring=2500.0, fx=1145.0 * 0.16 * 1.5, device=device)
+        cams = [b.cameras[0], sc.cameras[1], sc.cameras[2], b.cameras[3]]
+    rng = np.random.default_rng(5)
+    base3, base2 = np.asarray(sc.pose_3d_init, np.float32), np.asarray(sc.poses_2d, np.float32)
+    pts = np.stack([base3 + rng.normal(0, 30.0 * f, base3.shape) for f in range(F)]).astype(np.float32)
+    p2d = np.stack([base2 + rng.normal(0, 3.0 * f, base2.shape) for f in range(F)]).astype(np.float32)
+    drop = torch.zeros((F, V, sc.n_joints), dtype=torch.bool)
+    drop[1, 2, [3, 9]] = True          # frame 1 loses two planes of view 2 (training.dropout)
+    use_graph = mode == "graph5"
+    iters = 44
+    fb = FrameBatchLoop(model(device), cams, F, dataset="h36m", use_graph=use_graph)
+    fb.new_scenes(pts, poses_2d=p2d, drop_masks=drop)
+    out = fb.run(iters, groups_per_graph=4).clone()
+    assert tuple(out.shape) == (F, sc.n_joints, 3) and fb.iteration == iters
+    assert int(fb.counters[:, 0].min()) == int(fb.counters[:, 0].max()) > 0
+    for f in range(F):
+        gm = model(device)
+        hm0 = [torch.zeros((sc.n_joints, int(c.image_height), int(c.image_width)), device=device) for c in cams]
+        loop = MultiViewLoop(gm, cams, hm0 if mode == "mixed" else torch.stack(hm0), dataset="h36m", sparse=True,
+                             use_graph=use_graph)
+        assert loop.fused_tail
+        from skelsplat_amd.heatmaps import generate_heatmaps
+        # (new_scene draws its own dropout; give the planes explicitly instead)
+        gm.reset_from_points(pts[f])
+        for slots, vb, gt, stats, idx in loop.size_groups:
+            generate_heatmaps(gm._xyz.detach(), gm.get_scaling.detach(), gm._rotation.detach(),
+                              torch.tensor(p2d[f][slots], device=device), [cams[k] for k in slots], out=gt, views=vb,
+                              totals=stats.totals, drop_mask=drop[f][slots])
+        if len(loop.size_groups) > 1:
+            loop._merge_totals()
+        for v in range(V):                                       # the batched generator wrote the same planes
+            assert torch.equal(fb.hset.planes[f * V + v], loop.hset.planes[v]), (f, v)
+        loop.run(iters, groups_per_graph=4)
+        assert torch.equal(out[f], gm._xyz.detach()), f
+        assert torch.equal(fb.scaling[f], gm._scaling.detach()) and torch.equal(fb.rotation[f], gm._rotation.detach())
+        assert torch.equal(fb.opacity[f], gm._opacity.detach())
+        assert torch.equal(fb.exp_avg[f], loop.exp_avg) and torch.equal(fb.exp_avg_sq[f], loop.exp_avg_sq)
+        assert torch.equal(fb.accumulated_grads[f], loop.accumulated_grads)
+        assert torch.equal(fb.counters[f], loop.counters)
+        S, N = loop.last_losses
+        # N (a pixel count) is exact; S starts from the heat-map totals sks_heatmaps accumulates with fp64 atomics, whose
+        # order is not fixed: equal to the last few bits (nothing but the reported loss reads S)
+        assert torch.equal(fb.last_losses[1][f], N)
+        assert ((fb.last_losses[0][f] - S).abs() <= 1e-12 * S.abs()).all()
+    assert not torch.equal(out[0], out[1])
+
+
+def test_frame_batch_refuses_what_it_cannot_do(device):
+    from skelsplat_amd.loop import FrameBatchLoop
+    sc, model = _make_loop_scene(device, V=4, seed=3)
+    with pytest.raises(ValueError, match="exceeds"):
+        FrameBatchLoop(model(device), sc.cameras, 17)
+    fb = FrameBatchLoop(model(device), sc.cameras, 2)
+    with pytest.raises(ValueError, match="points must be"):
+        fb.new_scenes(np.zeros((3, 17, 3), np.float32), poses_2d=np.zeros((2, 4, 17, 2), np.float32))
+    with pytest.raises(ValueError, match="poses_2d or heatmaps"):
+        fb.new_scenes(np.zeros((2, 17, 3), np.float32))
+
 # ------------------------------------------------------------------ two ranks, one GPU (gloo): the sharded branch at world 2
 def _two_rank_worker(rank, world, port, mode, ret):
     import os
