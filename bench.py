@@ -282,6 +282,27 @@ def run_single(args, torch, dev, wl):
         sync()
         extras["frame_stream_ms"] = 1e3 * (time.perf_counter() - tf) / 5
         del loop, hm
+        torch.cuda.empty_cache()
+        # the same streamed frames, F at a time through the same two launches per group (loop.FrameBatchLoop: frames
+        # are independent, train.py:74-99; each one's trajectory is bit-identical to running it alone)
+        from skelsplat_amd.loop import FrameBatchLoop
+        F = max(1, min(16, 64 // V))
+        fb = FrameBatchLoop(fresh_model(scene, wl["dataset"], dev), scene.cameras, F, dataset=wl["dataset"],
+                            accumulation_steps=V, use_graph=True)
+        ptsF, p2dF = pts[None].repeat(F, 1, 1), p2d[None].repeat(F, 1, 1, 1)
+        fb.new_scenes(ptsF, poses_2d=p2dF)
+        fb.run(500)
+        sync()
+        tf = time.perf_counter()
+        for _ in range(3):
+            fb.new_scenes(ptsF, poses_2d=p2dF)
+            fb.run(500)
+        sync()
+        tb = (time.perf_counter() - tf) / 3
+        extras["frame_batch"] = {"frames_per_launch": F, "batch_ms": 1e3 * tb, "frames_per_s": F / tb,
+                                 "one_at_a_time_frames_per_s": 1e3 / extras["frame_stream_ms"]}
+        del fb
+        torch.cuda.empty_cache()
     except Exception as e:
         extras["loop_error"] = repr(e)[:300]
     # ---- the reference's own iteration with only the modules swapped (train.py:130-161) --------------------------
