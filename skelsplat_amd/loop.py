@@ -755,6 +755,24 @@ class FrameBatchLoop:
             self.step_group()
         return self.xyz
 
+    def optimize_sequence(self, points, poses_2d, iterations=500, groups_per_graph=25):
+        """The reference's outer loop over the frames of a sequence (train.py:74-99) F frames at a time: `points`
+        (N,P,3) initial joints and `poses_2d` (N,V,J,2) detections of N frames -> (N,P,3) optimised joints.  A last batch
+        with fewer than F frames is filled up by repeating its final frame (frames are independent: the filler changes
+        nothing and is dropped)."""
+        pts = points if torch.is_tensor(points) else torch.as_tensor(np.asarray(points))
+        p2d = poses_2d if torch.is_tensor(poses_2d) else torch.as_tensor(np.asarray(poses_2d))
+        N, F = pts.shape[0], self.F
+        if p2d.shape[0] != N:
+            raise ValueError(f"{N} frames of points, {p2d.shape[0]} of detections")
+        out = torch.empty((N, self.P, 3), dtype=torch.float32, device=self.device)
+        for b in range(0, N, F):
+            idx = [min(b + i, N - 1) for i in range(F)]
+            self.new_scenes(pts[idx], poses_2d=p2d[idx])
+            res = self.run(iterations, groups_per_graph)
+            out[b:min(b + F, N)] = res[:min(F, N - b)]
+        return out
+
 
 def mpjpe(pred, gt):
     """eval.py:123-124: mean Euclidean joint error (same units as the inputs, mm)."""

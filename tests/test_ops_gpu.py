@@ -845,16 +845,16 @@ def test_full_size_h36m_loop_sparse_equals_dense(device, mixed):
 
 
 # ------------------------------------------------------------------ frame batching: F frames in the two launches of one
-@pytest.mark.parametrize("mode", ["same", "mixed", "graph5"])
+@pytest.mark.parametrize("mode", ["same", "mixed", "graph5", "wide9"])
 def test_frame_batch_equals_separate_loops(device, mode):
     """FrameBatchLoop steps F independent frames per launch (sks_loop_fused_step(frames=F), one tail workgroup per frame);
     every frame must end EXACTLY where a MultiViewLoop running it alone ends: parameters, Adam moments, V-slot buffers,
     per-view losses, and the heat-maps generated for it.  `mixed`: two image sizes (H36M's 1000/1002 sensors, scaled);
-    `graph5`: 5 views with 4-iteration groups (masks that rotate) inside hipGraphs."""
+    `graph5`: 5 views with 4-iteration groups (masks that rotate) inside hipGraphs; `wide9`: 9 views per frame."""
     from skelsplat_amd.loop import MultiViewLoop, FrameBatchLoop
     from skelsplat_amd.scene import SyntheticScene, GaussianModel
     F = 3
-    V = 5 if mode == "graph5" else 4
+    V = {"graph5": 5, "wide9": 9}.get(mode, 4)   # wide9: more than 8 views, the optimiser's LDS-parked slot walk
     sc, model = _make_loop_scene(device, V=V, seed=51)
     cams = sc.cameras
     if mode == "mixed":
@@ -877,7 +877,7 @@ def test_frame_batch_equals_separate_loops(device, mode):
         gm = model(device)
         hm0 = [torch.zeros((sc.n_joints, int(c.image_height), int(c.image_width)), device=device) for c in cams]
         loop = MultiViewLoop(gm, cams, hm0 if mode == "mixed" else torch.stack(hm0), dataset="h36m", sparse=True,
-                             use_graph=use_graph)
+                             use_graph=use_graph, fused_tail=True)
         assert loop.fused_tail
         from skelsplat_amd.heatmaps import generate_heatmaps
         # (new_scene draws its own dropout; give the planes explicitly instead)
@@ -903,6 +903,22 @@ def test_frame_batch_equals_separate_loops(device, mode):
         assert torch.equal(fb.last_losses[1][f], N)
         assert ((fb.last_losses[0][f] - S).abs() <= 1e-12 * S.abs()).all()
     assert not torch.equal(out[0], out[1])
+
+
+def test_frame_batch_sequence_with_a_partial_last_batch(device):
+    """optimize_sequence: 5 frames through batches of 2 (the last one padded) == the same frames through a batch of 5."""
+    from skelsplat_amd.loop import FrameBatchLoop
+    sc, model = _make_loop_scene(device, V=4, seed=52)
+    rng = np.random.default_rng(6)
+    base3, base2 = np.asarray(sc.pose_3d_init, np.float32), np.asarray(sc.poses_2d, np.float32)
+    pts = np.stack([base3 + rng.normal(0, 20.0, base3.shape) for _ in range(5)]).astype(np.float32)
+    p2d = np.stack([base2 + rng.normal(0, 2.0, base2.shape) for _ in range(5)]).astype(np.float32)
+    a = FrameBatchLoop(model(device), sc.cameras, 2, dataset="h36m", use_graph=True).optimize_sequence(pts, p2d, iterations=24, groups_per_graph=3)
+    fb = FrameBatchLoop(model(device), sc.cameras, 5, dataset="h36m")
+    fb.new_scenes(pts, poses_2d=p2d)
+    b = fb.run(24)
+    assert tuple(a.shape) == (5, sc.n_joints, 3) and torch.equal(a, b)
+    assert (a.cpu() - torch.tensor(pts)).norm(dim=2).mean().item() > 0.05
 
 
 def test_frame_batch_refuses_what_it_cannot_do(device):
