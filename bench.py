@@ -303,6 +303,23 @@ def run_single(args, torch, dev, wl):
                                  "one_at_a_time_frames_per_s": 1e3 / extras["frame_stream_ms"]}
         del fb
         torch.cuda.empty_cache()
+        # ... and several such batches in flight on separate HIP streams (loop.FramePipeline): one batch's single-workgroup
+        # step tails run under the others' backward kernels
+        from skelsplat_amd.loop import FramePipeline
+        S = 4
+        pipe = FramePipeline(fresh_model(scene, wl["dataset"], dev), scene.cameras, frames=F, streams=S, dataset=wl["dataset"],
+                             accumulation_steps=V)
+        ptsN, p2dN = pts[None].repeat(S * F, 1, 1), p2d[None].repeat(S * F, 1, 1, 1)
+        pipe.optimize_sequence(ptsN, p2dN, iterations=500)
+        sync()
+        tf = time.perf_counter()
+        for _ in range(2):
+            pipe.optimize_sequence(ptsN, p2dN, iterations=500)
+        sync()
+        tp = (time.perf_counter() - tf) / 2
+        extras["frame_batch"].update({"pipeline_streams": S, "pipeline_frames_per_s": S * F / tp})
+        del pipe
+        torch.cuda.empty_cache()
     except Exception as e:
         extras["loop_error"] = repr(e)[:300]
     # ---- the reference's own iteration with only the modules swapped (train.py:130-161) --------------------------

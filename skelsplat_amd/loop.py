@@ -774,6 +774,55 @@ class FrameBatchLoop:
         return out
 
 
+class FramePipeline:
+    """A sequence of frames through `streams` FrameBatchLoops of `frames` frames each, one HIP stream per loop.
+
+    Inside one FrameBatchLoop a group is two dependent launches: the compositing backward of all its frames, then one
+    workgroup per frame for geometry backward + Adam + next geometry (~14 us during which the chip is nearly idle).  Several
+    loops on separate streams fill that hole with each other's backward kernels: on one MI355X (H36M, 4 views, 500
+    iterations per frame, heat-map generation included) 292 frames/s one frame at a time, 1 480 with 16 frames per launch,
+    1 900-2 100 with 2-4 such loops in flight (tools/bench_frames.py).  Results do not depend on `frames` / `streams`:
+    every frame's trajectory is bit-identical to a MultiViewLoop running it alone."""
+
+    def __init__(self, gaussians, cameras, frames=16, streams=2, **kw):
+        kw.setdefault("use_graph", True)
+        self.loops = [FrameBatchLoop(gaussians, cameras, frames, **kw) for _ in range(int(streams))]
+        self.device = self.loops[0].device
+        self.streams = [torch.cuda.Stream(self.device) for _ in self.loops]
+        self.F, self.P = self.loops[0].F, self.loops[0].P
+
+    def optimize_sequence(self, points, poses_2d, iterations=500, groups_per_graph=25, interleave=100):
+        """(N,P,3) initial joints + (N,V,J,2) detections -> (N,P,3) optimised joints (train.py:74-99 over the frames).
+        The loops' graph launches are issued round-robin, `interleave` iterations at a time, so that every stream always
+        has work queued; a last batch with fewer than `frames` frames is padded by repeating its final frame."""
+        pts = points if torch.is_tensor(points) else torch.as_tensor(np.asarray(points))
+        p2d = poses_2d if torch.is_tensor(poses_2d) else torch.as_tensor(np.asarray(poses_2d))
+        N, F, S = pts.shape[0], self.F, len(self.loops)
+        if p2d.shape[0] != N:
+            raise ValueError(f"{N} frames of points, {p2d.shape[0]} of detections")
+        out = torch.empty((N, self.P, 3), dtype=torch.float32, device=self.device)
+        cur = torch.cuda.current_stream(self.device)
+        starts = list(range(0, N, F))
+        for st in self.streams:
+            st.wait_stream(cur)                      # inputs and `out` were produced on the caller's stream
+        for w in range(0, len(starts), S):
+            active = list(zip(self.loops, self.streams, starts[w:w + S]))
+            for fb, st, b in active:
+                idx = [min(b + i, N - 1) for i in range(F)]
+                with torch.cuda.stream(st):
+                    fb.new_scenes(pts[idx], poses_2d=p2d[idx])
+            for k in range(0, iterations, max(int(interleave), 1)):
+                for fb, st, b in active:
+                    with torch.cuda.stream(st):
+                        fb.run(min(iterations, k + interleave), groups_per_graph)
+            for fb, st, b in active:
+                with torch.cuda.stream(st):
+                    out[b:min(b + F, N)] = fb.xyz[:min(F, N - b)]
+        for st in self.streams:
+            cur.wait_stream(st)
+        return out
+
+
 def mpjpe(pred, gt):
     """eval.py:123-124: mean Euclidean joint error (same units as the inputs, mm)."""
     return torch.norm(pred - gt, dim=1).mean()

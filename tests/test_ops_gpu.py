@@ -921,6 +921,26 @@ def test_frame_batch_sequence_with_a_partial_last_batch(device):
     assert (a.cpu() - torch.tensor(pts)).norm(dim=2).mean().item() > 0.05
 
 
+def test_frame_pipeline_on_streams_equals_one_batch(device):
+    """FramePipeline: 7 frames through 2 loops of 2 frames on 2 HIP streams (two rounds, the last batch padded) == the same
+    7 frames in one 7-frame batch -- bit for bit, whatever the interleaving of the streams' graph launches."""
+    from skelsplat_amd.loop import FrameBatchLoop, FramePipeline
+    sc, model = _make_loop_scene(device, V=4, seed=53)
+    rng = np.random.default_rng(7)
+    base3, base2 = np.asarray(sc.pose_3d_init, np.float32), np.asarray(sc.poses_2d, np.float32)
+    pts = np.stack([base3 + rng.normal(0, 20.0, base3.shape) for _ in range(7)]).astype(np.float32)
+    p2d = np.stack([base2 + rng.normal(0, 2.0, base2.shape) for _ in range(7)]).astype(np.float32)
+    pipe = FramePipeline(model(device), sc.cameras, frames=2, streams=2, dataset="h36m")
+    a = pipe.optimize_sequence(pts, p2d, iterations=32, groups_per_graph=3, interleave=8)
+    torch.cuda.synchronize()
+    fb = FrameBatchLoop(model(device), sc.cameras, 7, dataset="h36m")
+    fb.new_scenes(pts, poses_2d=p2d)
+    b = fb.run(32)
+    assert tuple(a.shape) == (7, sc.n_joints, 3) and torch.equal(a, b)
+    a2 = pipe.optimize_sequence(pts, p2d, iterations=32, groups_per_graph=3, interleave=8)   # graphs reused
+    assert torch.equal(a2, b)
+
+
 def test_frame_batch_refuses_what_it_cannot_do(device):
     from skelsplat_amd.loop import FrameBatchLoop
     sc, model = _make_loop_scene(device, V=4, seed=3)

@@ -57,3 +57,27 @@ for F in Fs:
           f"{(t2-t1)*1e6/(ITERS/4):.1f} us per group), {1/dt:.0f} frames/s, x{(base or dt)/dt:.2f}")
     del fb
     torch.cuda.empty_cache()
+
+# several batches on as many streams: one's single-workgroup tails run under the others' backward kernels
+for spec in os.environ.get("STREAMS", "2x8,2x16,4x8,4x16").split(","):
+    if not spec:
+        continue
+    ns, h = (int(x) for x in spec.split("x"))
+    F = ns * h
+    loops = [FrameBatchLoop(model(), sc.cameras, h, dataset="h36m", use_graph=True) for _ in range(ns)]
+    streams = [torch.cuda.Stream() for _ in range(ns)]
+    pts, p2d = frames(F)
+    for rep in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for i, (fb, st) in enumerate(zip(loops, streams)):
+            with torch.cuda.stream(st):
+                fb.new_scenes(pts[i * h:(i + 1) * h], poses_2d=p2d[i * h:(i + 1) * h])
+        for k in range(0, ITERS, 100):      # interleave the graph launches of the streams
+            for fb, st in zip(loops, streams):
+                with torch.cuda.stream(st):
+                    fb.run(min(ITERS, k + 100))
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+    dt = (t2 - t0) / F
+    print(f"{ns} streams x {h:2d} frames: {(t2-t0)*1e3:.3f} ms per {F} frames, {1/dt:.0f} frames/s")
+    del loops
+    torch.cuda.empty_cache()
