@@ -614,6 +614,21 @@ def run_sharded(args, torch, dist, dev, wl, world, rank):
             tf = max_over_ranks((time.perf_counter() - t0) / 3)
             res["frame_sharded"] = {"frame_ms": 1e3 * tf, "frames_per_s_all_ranks": world / tf,
                                     "note": "500 iterations per frame incl. heat-map generation; zero communication"}
+            del fl
+            if V <= 8:   # few-view rigs: every rank also batches its frames (loop.FramePipeline)
+                from skelsplat_amd.loop import FramePipeline
+                F, S = min(16, 64 // V), 2
+                pipe = FramePipeline(fresh_model(scene, wl["dataset"], dev), scene.cameras, frames=F, streams=S,
+                                     dataset=wl["dataset"], accumulation_steps=V)
+                ptsN, p2dN = pts[None].repeat(S * F, 1, 1), p2d[None].repeat(S * F, 1, 1, 1)
+                pipe.optimize_sequence(ptsN, p2dN, iterations=500)
+                sync()
+                t0 = time.perf_counter()
+                pipe.optimize_sequence(ptsN, p2dN, iterations=500)
+                sync()
+                tp = max_over_ranks(time.perf_counter() - t0)
+                res["frame_sharded"]["pipeline_frames_per_s_all_ranks"] = world * S * F / tp
+                del pipe
         except Exception as e:
             res["loop_error"] = repr(e)[:300]
     res["strong_scaling"] = strong
