@@ -150,7 +150,13 @@ int sks_heatmap_factors(int V, int J, int W, int H, const float* means3D, const 
                         float scale_modifier, const float* poses_2d, const float* viewmatrix, const float* tanfovx,
                         const float* tanfovy, float* row, float* col, float* cmin, float* den,
                         int frames /* 1; > 1: V = frames x Vf views, parameters stacked (frames,J,..), see sks_loop_fused_step */,
+                        const int* view_wh /* HOST V x {W,H} or NULL: per-view sizes; row / col keep the strides H / W */,
                         void* stream);
+/* {sum gt^2, count gt > 0} per view (gt_totals, V x 2 fp64) of heat-maps that are NEVER WRITTEN: computed from the
+ * separable factors alone (strides H / W, per-view sizes view_wh or NULL).  Together with hm_factors of
+ * sks_backward_fused_loss / sks_loop_fused_step this replaces sks_heatmaps + the (V,J,H,W) planes on the sparse path. */
+int sks_heatmap_totals(int V, int J, int W, int H, const float* row, const float* col, const float* cmin, const float* den,
+                       const int* view_wh, double* gt_totals, void* stream);
 
 /* Replaces fusedssim (submodules/fused-ssim/ssim.cu:368-404, binding ext.cpp): img1, img2, ssim_map and the three
  * optional partial-derivative maps (train == true) are (B,CH,H,W) fp32; "same" zero padding. */
@@ -222,7 +228,11 @@ int sks_backward_fused_loss(int V, int P, int C, int W, int H, const float* view
                             double* loss_sums, float* packed_raw_grads /* optional (V,P,11), see sks_loop_pack_grads:
                             with SKS_RAW_PARAMS the activation Jacobians and the 1/N_v scale are applied here */,
                             const int* view_wh /*HOST V x {W,H} or NULL*/, const size_t* gt_offsets /*HOST V or NULL*/,
-                            void* stream);
+                            const float* const* hm_factors /*HOST 4 device pointers or NULL, see below*/, void* stream);
+/* hm_factors = {row (V,C,H), col (V,C,W), cmin (V,C), den (V,C)} (sks_heatmap_factors' outputs, strides H / W = this
+ * call's W, H): the pseudo-GT is evaluated where it is needed, gt(v,c,y,x) = (row[y] * col[x] - cmin) / den -- the value
+ * sks_heatmaps would have stored, bit for bit -- and `gt` / `gt_offsets` are not read (may be NULL); gt_totals then comes
+ * from sks_heatmap_totals.  No heat-map plane exists anywhere on that path. */
 
 /* Device-side tail of the multi-view loop (train.py:160-222), so that one accumulation group is a fixed launch
  * sequence with no host state (capturable into a hipGraph):
@@ -272,7 +282,8 @@ int sks_loop_fused_step(int V, int P, int C, int W, int H, const float* viewmatr
                         const double* lr_sched /*HOST 5*/, const double* lrs /*HOST 3*/, const double* adam /*HOST 3*/,
                         float lambda_consistency, const int* limb /*HOST 8 or NULL*/,
                         const int* view_wh /*HOST V x {W,H} or NULL*/, const size_t* gt_offsets /*HOST V or NULL*/,
-                        int frames, void* stream);
+                        int frames, const float* const* hm_factors /*HOST 4 or NULL, as for sks_backward_fused_loss*/,
+                        void* stream);
 
 /* Measurement hook used by bench.py (no reference counterpart; state per HOST THREAD, like the error text): while enabled, the dominant kernel of sks_forward
  * (kind 0: forward compositor) and of sks_backward (kind 1: backward compositor) is bracketed by hipEvents recorded

@@ -341,6 +341,7 @@ __global__ __launch_bounds__(256) void k_heatmaps(int W, int H, int J, const flo
 // ------------------------------------------------------------------------------------------------------------
 struct HmTan {
     float x[SKS_MAX_VIEWS], y[SKS_MAX_VIEWS];
+    int w[SKS_MAX_VIEWS], h[SKS_MAX_VIEWS];   // per-view image size (<= the W, H strides of row / col)
 };
 
 __device__ __forceinline__ double block_sum_d(double v, double* s_red)
@@ -406,6 +407,8 @@ __global__ __launch_bounds__(256) void k_heatmap_factors(int J, int W, int H, co
     __shared__ double s_red[4];
     __shared__ float s_redf[4];
     const int j = blockIdx.x, v = blockIdx.y, vj = v * J + j;
+    const int Ws = W, Hs = H;        // strides of col / row: the largest view
+    W = tan.w[v]; H = tan.h[v];      // this view's own size (focal lengths, clamps, reflections)
     if (vf > 0) {   // frames batched: view v belongs to frame v / vf, whose J Gaussians sit frame-th in the stacked tensors
         const size_t fr = (size_t)(v / vf);
         means += fr * J * 3; scales += fr * J * 3; rots += fr * J * 4;
@@ -447,8 +450,8 @@ __global__ __launch_bounds__(256) void k_heatmap_factors(int J, int W, int H, co
     // ---- responses: sigma1 filters rows (axis 0), sigma2 columns; the impulse sits at the truncated 2D detection ----
     const int xs = min(max((int)poses_2d[2 * vj], 0), W - 1), ys = min(max((int)poses_2d[2 * vj + 1], 0), H - 1);
     float rmin, rmax, kmin, kmax;
-    impulse_response(H, ys, sqrtf(l1), 255.0f, row + (size_t)vj * H, s_red, rmin, rmax);
-    impulse_response(W, xs, sqrtf(l2), 1.0f, col + (size_t)vj * W, s_red, kmin, kmax);
+    impulse_response(H, ys, sqrtf(l1), 255.0f, row + (size_t)vj * Hs, s_red, rmin, rmax);
+    impulse_response(W, xs, sqrtf(l2), 1.0f, col + (size_t)vj * Ws, s_red, kmin, kmax);
     rmin = block_minmax(rmin, false, s_redf);
     rmax = block_minmax(rmax, true, s_redf);
     kmin = block_minmax(kmin, false, s_redf);
@@ -457,6 +460,52 @@ __global__ __launch_bounds__(256) void k_heatmap_factors(int J, int W, int H, co
         const float lo = rmin * kmin, hi = rmax * kmax;
         cmin[vj] = lo;
         den[vj] = (hi - lo) + 1e-8f;
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
+// Per-view loss constants of heat-maps that are never written: sum of gt^2 and count of gt > 0 over the J planes of a
+// view, from the separable factors alone (gt = (row[y] * col[x] - cmin) / den, the very expression k_heatmaps stores).
+// Outside the impulse response's 4-sigma support the factors are exactly zero, and then so is cmin and the pixel: only
+// the rows with a non-zero factor are walked (a few dozen of a thousand).  grid (row bands of 16, J, V); the counts are
+// integers (exact in any order), the sums are accumulated in fp64 like k_heatmaps' own.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_heatmap_totals(int J, int Ws, int Hs, HmTan sz, const float* __restrict__ row,
+                                                         const float* __restrict__ col, const float* __restrict__ cmin,
+                                                         const float* __restrict__ den, double* __restrict__ totals)
+{
+    __shared__ double s_t[2][4];
+    const int j = blockIdx.y, v = blockIdx.z, vj = v * J + j, y0 = blockIdx.x * 16;
+    const int W = sz.w[v], H = sz.h[v];
+    if (y0 >= H) return;
+    const float lo = cmin[vj], d = den[vj];
+    const float* r = row + (size_t)vj * Hs;
+    const float* c = col + (size_t)vj * Ws;
+    const int rows = min(16, H - y0);
+    bool any = lo != 0.0f;
+    for (int i = 0; i < rows && !any; i++) any = r[y0 + i] != 0.0f;   // (uniform)
+    if (!any) return;
+    double S = 0.0, N = 0.0;
+    for (int x = threadIdx.x; x < W; x += 256) {
+        const float k = c[x];
+        if (k == 0.0f && lo == 0.0f) continue;
+        float s = 0.0f, n = 0.0f;
+        for (int i = 0; i < rows; i++) {
+            const float g = (r[y0 + i] * k - lo) / d;
+            s += g * g;
+            n += g > 0.0f ? 1.0f : 0.0f;
+        }
+        S += (double)s;
+        N += (double)n;
+    }
+    S = wave_sum_d(S);
+    N = wave_sum_d(N);
+    if ((threadIdx.x & 63) == 0) { s_t[0][threadIdx.x >> 6] = S; s_t[1][threadIdx.x >> 6] = N; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&totals[2 * v], (s_t[0][0] + s_t[0][1]) + (s_t[0][2] + s_t[0][3]));
+        atomicAdd(&totals[2 * v + 1], (s_t[1][0] + s_t[1][1]) + (s_t[1][2] + s_t[1][3]));
     }
 }
 
@@ -532,16 +581,41 @@ int sks_heatmaps(int V, int J, int W, int H, const float* row, const float* col,
 
 int sks_heatmap_factors(int V, int J, int W, int H, const float* means3D, const float* scales, const float* rotations,
                         float scale_modifier, const float* poses_2d, const float* viewmatrix, const float* tanfovx,
-                        const float* tanfovy, float* row, float* col, float* cmin, float* den, int frames, void* stream)
+                        const float* tanfovy, float* row, float* col, float* cmin, float* den, int frames,
+                        const int* view_wh, void* stream)
 {
     if (V < 1 || V > SKS_MAX_VIEWS || J < 1 || W < 1 || H < 1) return fail2(-1, "heatmap factors: bad shape");
     if (frames < 1 || V % frames) return fail2(-1, "heatmap factors: frames must divide the number of views");
     if (!means3D || !scales || !rotations || !poses_2d || !viewmatrix || !tanfovx || !tanfovy || !row || !col || !cmin || !den)
         return fail2(-2, "heatmap factors: missing pointer");
     HmTan tan;
-    for (int v = 0; v < V; v++) { tan.x[v] = tanfovx[v]; tan.y[v] = tanfovy[v]; }
+    for (int v = 0; v < V; v++) {
+        tan.x[v] = tanfovx[v]; tan.y[v] = tanfovy[v];
+        tan.w[v] = view_wh ? view_wh[2 * v] : W; tan.h[v] = view_wh ? view_wh[2 * v + 1] : H;
+        if (tan.w[v] < 1 || tan.w[v] > W || tan.h[v] < 1 || tan.h[v] > H)
+            return fail2(-1, "heatmap factors: every view's size must be within [1, W] x [1, H]");
+    }
     hipLaunchKernelGGL(k_heatmap_factors, dim3(J, V), dim3(256), 0, (hipStream_t)stream, J, W, H, means3D, scales, rotations,
                        scale_modifier, poses_2d, viewmatrix, tan, row, col, cmin, den, frames > 1 ? V / frames : 0);
+    HIP_TRY2(hipGetLastError());
+    return 0;
+}
+
+int sks_heatmap_totals(int V, int J, int W, int H, const float* row, const float* col, const float* cmin, const float* den,
+                       const int* view_wh, double* gt_totals, void* stream)
+{
+    if (V < 1 || V > SKS_MAX_VIEWS || J < 1 || W < 1 || H < 1) return fail2(-1, "heatmap totals: bad shape");
+    if (!row || !col || !cmin || !den || !gt_totals) return fail2(-2, "heatmap totals: missing pointer");
+    HmTan sz;
+    for (int v = 0; v < V; v++) {
+        sz.x[v] = sz.y[v] = 0.0f;
+        sz.w[v] = view_wh ? view_wh[2 * v] : W; sz.h[v] = view_wh ? view_wh[2 * v + 1] : H;
+        if (sz.w[v] < 1 || sz.w[v] > W || sz.h[v] < 1 || sz.h[v] > H)
+            return fail2(-1, "heatmap totals: every view's size must be within [1, W] x [1, H]");
+    }
+    HIP_TRY2(hipMemsetAsync(gt_totals, 0, (size_t)V * 2 * sizeof(double), (hipStream_t)stream));
+    hipLaunchKernelGGL(k_heatmap_totals, dim3((H + 15) / 16, J, V), dim3(256), 0, (hipStream_t)stream, J, W, H, sz, row, col, cmin,
+                       den, gt_totals);
     HIP_TRY2(hipGetLastError());
     return 0;
 }

@@ -145,6 +145,26 @@ inline int bwd_wave_groups(int V, int P, unsigned flags)
     return pairs <= BWD_WG_PAIRS16 ? 16 : (pairs <= BWD_WG_PAIRS8 ? 8 : 4);
 }
 
+// the fused-loss variant of the wave-resident backward: heat-maps as planes or (a.hm_row) as separable factors
+inline void launch_bwd_loss(const BwdArgs& a, const ViewTan& vt, const ViewOff& vo, dim3 grid, int cg, hipStream_t st)
+{
+    if (a.hm_row) {
+        switch (cg) {
+            case 4: hipLaunchKernelGGL((k_render_bwd_wave<4, false, true, true>), grid, dim3(256), 0, st, a, vt, vo); break;
+            case 16: hipLaunchKernelGGL((k_render_bwd_wave<16, false, true, true>), grid, dim3(256), 0, st, a, vt, vo); break;
+            case 20: hipLaunchKernelGGL((k_render_bwd_wave<20, false, true, true>), grid, dim3(256), 0, st, a, vt, vo); break;
+            default: hipLaunchKernelGGL((k_render_bwd_wave<32, false, true, true>), grid, dim3(256), 0, st, a, vt, vo); break;
+        }
+        return;
+    }
+    switch (cg) {
+        case 4: hipLaunchKernelGGL((k_render_bwd_wave<4, false, true>), grid, dim3(256), 0, st, a, vt, vo); break;
+        case 16: hipLaunchKernelGGL((k_render_bwd_wave<16, false, true>), grid, dim3(256), 0, st, a, vt, vo); break;
+        case 20: hipLaunchKernelGGL((k_render_bwd_wave<20, false, true>), grid, dim3(256), 0, st, a, vt, vo); break;
+        default: hipLaunchKernelGGL((k_render_bwd_wave<32, false, true>), grid, dim3(256), 0, st, a, vt, vo); break;
+    }
+}
+
 template <int CG>
 void launch_bwd_small(const BwdArgs& a, const ViewTan& vt, const ViewOff& vo, int V, int gy, bool dfeat, hipStream_t st)
 {
@@ -179,7 +199,7 @@ void sks_set_error_(const char* msg)  // used by the other translation units of 
 {
     snprintf(g_err, sizeof(g_err), "%s", msg);
 }
-int sks_version(void) { return 4; }
+int sks_version(void) { return 5; }
 
 int sks_scratch_bytes(int V, int P, int C, int W, int H, size_t bin_capacity, size_t* geom, size_t* binning, size_t* accum)
 {
@@ -353,31 +373,29 @@ int sks_backward_fused_loss(int V, int P, int C, int W, int H, const float* view
                             const double* gt_totals, void* accum, float* dL_dmeans3D, float* dL_dmeans2D,
                             float* dL_dopacity, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
                             double* loss_sums, float* packed_raw_grads, const int* view_wh, const size_t* gt_offsets,
-                            void* stream)
+                            const float* const* hm_factors, void* stream)
 {
     if (int rc = check_common(V, P, C, W, H)) return rc;
     if (P < 1 || P > 64) return fail(-1, "fused-loss backward needs 1 <= P <= 64 (got %d)", P);
     hipStream_t st = (hipStream_t)stream;
-    if (!viewmatrix || !projmatrix || !tanfovx || !tanfovy || !means3D || !features || !opacities || !radii || !geom || !gt ||
-        !gt_totals || !accum || !dL_dmeans3D || !dL_dmeans2D || !dL_dopacity || !loss_sums)
+    if (!viewmatrix || !projmatrix || !tanfovx || !tanfovy || !means3D || !features || !opacities || !radii || !geom ||
+        (!gt && !hm_factors) || !gt_totals || !accum || !dL_dmeans3D || !dL_dmeans2D || !dL_dopacity || !loss_sums)
         return fail(-2, "missing required pointer");
+    if (hm_factors && (!hm_factors[0] || !hm_factors[1] || !hm_factors[2] || !hm_factors[3]))
+        return fail(-2, "hm_factors: row, col, cmin, den must all be given");
     if (!cov3D_precomp && (!scales || !rotations)) return fail(-2, "need scales+rotations or cov3D_precomp");
     ViewTan vt;
     ViewOff vo;
     if (!fill_views(vt, &vo, V, C, W, H, tanfovx, tanfovy, view_wh, gt_offsets))
         return fail(-1, "view_wh: every view's size must be within [1, W] x [1, H] (pass the largest as W, H)");
-    if ((view_wh != nullptr) != (gt_offsets != nullptr)) return fail(-2, "view_wh and gt_offsets go together");
+    if (!hm_factors && (view_wh != nullptr) != (gt_offsets != nullptr)) return fail(-2, "view_wh and gt_offsets go together");
     Geom g = geom_from(const_cast<void*>(geom), V, P, W, H);
     BwdArgs a{ P, C, W, H, flags | SKS_CLAMP01, g, features, bg, gt, nullptr, (float*)accum, tile_S, tile_N };
+    if (hm_factors) { a.hm_row = hm_factors[0]; a.hm_col = hm_factors[1]; a.hm_cmin = hm_factors[2]; a.hm_den = hm_factors[3]; }
     dim3 grid(P, V, bwd_wave_groups(V, P, flags));   // see launch_bwd_small
     {
         ProfScope prof(1, st);
-        switch (pick_cg(C)) {
-            case 4: hipLaunchKernelGGL((k_render_bwd_wave<4, false, true>), grid, dim3(256), 0, st, a, vt, vo); break;
-            case 16: hipLaunchKernelGGL((k_render_bwd_wave<16, false, true>), grid, dim3(256), 0, st, a, vt, vo); break;
-            case 20: hipLaunchKernelGGL((k_render_bwd_wave<20, false, true>), grid, dim3(256), 0, st, a, vt, vo); break;
-            default: hipLaunchKernelGGL((k_render_bwd_wave<32, false, true>), grid, dim3(256), 0, st, a, vt, vo); break;
-        }
+        launch_bwd_loss(a, vt, vo, grid, pick_cg(C), st);
     }
     STAGE_CHECK("fused loss + render-backward");
     GeomBwdArgs ga{ P, C, W, H, flags, viewmatrix, projmatrix, means3D, opacities, scales, rotations, cov3D_precomp,
@@ -419,21 +437,23 @@ int sks_loop_fused_step(int V, int P, int C, int W, int H, const float* viewmatr
                         float* xyz, float* scaling, float* rotation, float* opacity, float* exp_avg, float* exp_avg_sq,
                         int* counters, int acc_steps, const double* lr_sched, const double* lrs, const double* adam,
                         float lambda_consistency, const int* limb, const int* view_wh, const size_t* gt_offsets, int frames,
-                        void* stream)
+                        const float* const* hm_factors, void* stream)
 {
     if (int rc = check_common(V, P, C, W, H)) return rc;
     if (P < 1 || P > 64) return fail(-1, "fused step needs 1 <= P <= 64 (got %d)", P);
     if (frames < 1 || V % frames) return fail(-1, "frames must divide the number of views (V = %d, frames = %d)", V, frames);
     const int Vf = V / frames;   // views of one frame: the optimiser's V (slots, group mask, last_view are per frame)
-    if (!viewmatrix || !projmatrix || !tanfovx || !tanfovy || !features || !radii || !geom || !gt || !gt_totals || !accum ||
-        !loss_sums || !packed)
+    if (!viewmatrix || !projmatrix || !tanfovx || !tanfovy || !features || !radii || !geom || (!gt && !hm_factors) || !gt_totals ||
+        !accum || !loss_sums || !packed)
         return fail(-2, "missing required pointer");
+    if (hm_factors && (!hm_factors[0] || !hm_factors[1] || !hm_factors[2] || !hm_factors[3]))
+        return fail(-2, "hm_factors: row, col, cmin, den must all be given");
     hipStream_t st = (hipStream_t)stream;
     ViewTan vt;
     ViewOff vo;
     if (!fill_views(vt, &vo, V, C, W, H, tanfovx, tanfovy, view_wh, gt_offsets))
         return fail(-1, "view_wh: every view's size must be within [1, W] x [1, H] (pass the largest as W, H)");
-    if ((view_wh != nullptr) != (gt_offsets != nullptr)) return fail(-2, "view_wh and gt_offsets go together");
+    if (!hm_factors && (view_wh != nullptr) != (gt_offsets != nullptr)) return fail(-2, "view_wh and gt_offsets go together");
     flags |= SKS_RAW_PARAMS | SKS_CLAMP01;
     sksloop::AdamArgs aa;
     if (const char* err = sksloop::fill_adam_args(aa, Vf, P, packed, slots, group_mask, last_view, xyz, scaling, rotation, opacity,
@@ -443,15 +463,11 @@ int sks_loop_fused_step(int V, int P, int C, int W, int H, const float* viewmatr
     Geom g = geom_from(geom, V, P, W, H);
     g.cover = nullptr;   // no forward render on this path
     BwdArgs a{ P, C, W, H, flags, g, features, nullptr, gt, nullptr, (float*)accum, nullptr, nullptr };
+    if (hm_factors) { a.hm_row = hm_factors[0]; a.hm_col = hm_factors[1]; a.hm_cmin = hm_factors[2]; a.hm_den = hm_factors[3]; }
     dim3 grid(P, V, bwd_wave_groups(V, P, flags));   // see launch_bwd_small
     {
         ProfScope prof(1, st);
-        switch (pick_cg(C)) {
-            case 4: hipLaunchKernelGGL((k_render_bwd_wave<4, false, true>), grid, dim3(256), 0, st, a, vt, vo); break;
-            case 16: hipLaunchKernelGGL((k_render_bwd_wave<16, false, true>), grid, dim3(256), 0, st, a, vt, vo); break;
-            case 20: hipLaunchKernelGGL((k_render_bwd_wave<20, false, true>), grid, dim3(256), 0, st, a, vt, vo); break;
-            default: hipLaunchKernelGGL((k_render_bwd_wave<32, false, true>), grid, dim3(256), 0, st, a, vt, vo); break;
-        }
+        launch_bwd_loss(a, vt, vo, grid, pick_cg(C), st);
     }
     STAGE_CHECK("render-backward(fused loss)");
     GeomBwdArgs ga{ P, C, W, H, flags, viewmatrix, projmatrix, xyz, opacity, scaling, rotation, nullptr, scale_modifier, radii,

@@ -23,7 +23,8 @@ def covariance_from_scaling_rotation(scaling, rotation_raw, modifier=1.0):
     return L @ L.transpose(1, 2)
 
 
-def heatmap_factors(means, scaling, rotation_raw, poses_2d, cameras, scaling_modifier=1.0, views=None, frames=1):
+def heatmap_factors(means, scaling, rotation_raw, poses_2d, cameras, scaling_modifier=1.0, views=None, frames=1, out=None,
+                    drop_mask=None):
     """The separable description of the (V, J, H, W) heat-maps: row (V,J,H) = 255 * impulse response along y,
     col (V,J,W) = impulse response along x, cmin (V,J), den (V,J) with
     plane = (row[:, None] * col[None, :] - cmin) / den.
@@ -31,37 +32,49 @@ def heatmap_factors(means, scaling, rotation_raw, poses_2d, cameras, scaling_mod
     multiplication is monotone), so the min-max normalisation of normalize_heatmaps (:300-304) needs no image pass.
     One kernel launch (sks_heatmap_factors), no host synchronisation.  `views`: a rasterizer.ViewBatch of `cameras` to
     reuse (scene streaming), else built here.  `frames` > 1: independent frames in one launch -- `cameras` / `views`
-    list frames x Vf views frame-major, the parameters are stacked (frames, J, ..) and poses_2d is (frames*Vf, J, 2)."""
+    list frames x Vf views frame-major, the parameters are stacked (frames, J, ..) and poses_2d is (frames*Vf, J, 2).
+    `out`: a rasterizer.HeatmapFactors to fill in place (the sparse fused step reads the factors themselves, no plane is
+    ever written); only then may the cameras differ in size (rows / columns keep the largest view's strides).
+    `drop_mask` (V,J) bool: planes without an impulse (see generate_heatmaps)."""
     from . import _lib
     from .rasterizer import ViewBatch, _f32c
     dev = means.device
-    W, H = int(cameras[0].image_width), int(cameras[0].image_height)
     V = len(cameras)
     frames = int(frames)
     if frames < 1 or V % frames or (frames > 1 and (means.dim() != 3 or means.shape[0] != frames)):
         raise ValueError(f"frames = {frames}: needs frames x Vf cameras and parameters stacked (frames, J, ..)")
-    for cam in cameras:
-        if int(cam.image_width) != W or int(cam.image_height) != H:
-            raise ValueError("generate_heatmaps: all cameras must share (W, H)")
+    if views is None:
+        views = ViewBatch.from_cameras(cameras, allow_mixed=out is not None)
+    W, H = views.W, views.H
+    if views.mixed and out is None:
+        raise ValueError("generate_heatmaps: all cameras must share (W, H)")
     means, scaling, rotation_raw = _f32c(means, "means"), _f32c(scaling, "scaling"), _f32c(rotation_raw, "rotation")
     poses_2d = torch.as_tensor(poses_2d, device=dev)
-    if views is None:
-        views = ViewBatch.from_cameras(cameras)
     J = means.shape[-2]
     p2d = poses_2d.to(torch.float32).contiguous()
     if tuple(p2d.shape) != (V, J, 2):
         raise ValueError(f"poses_2d must be (V, J, 2) = {(V, J, 2)}, got {tuple(p2d.shape)}")
-    row = torch.empty((V, J, H), dtype=torch.float32, device=dev)
-    col = torch.empty((V, J, W), dtype=torch.float32, device=dev)
-    cmin = torch.empty((V, J), dtype=torch.float32, device=dev)
-    den = torch.empty((V, J), dtype=torch.float32, device=dev)
+    if out is not None:
+        if (out.V, out.J, out.W, out.H) != (V, J, W, H) or out.row.device != dev:
+            raise ValueError(f"heatmap_factors: `out` is {(out.V, out.J, out.W, out.H)}, the views need {(V, J, W, H)}")
+        row, col, cmin, den = out.row, out.col, out.cmin, out.den
+    else:
+        row = torch.empty((V, J, H), dtype=torch.float32, device=dev)
+        col = torch.empty((V, J, W), dtype=torch.float32, device=dev)
+        cmin = torch.empty((V, J), dtype=torch.float32, device=dev)
+        den = torch.empty((V, J), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         rc = _lib.load().sks_heatmap_factors(V, J, W, H, means.data_ptr(), scaling.data_ptr(), rotation_raw.data_ptr(),
                                              float(scaling_modifier), p2d.data_ptr(), views.viewmatrix.data_ptr(),
                                              views.tanfovx, views.tanfovy, row.data_ptr(), col.data_ptr(),
-                                             cmin.data_ptr(), den.data_ptr(), frames,
+                                             cmin.data_ptr(), den.data_ptr(), frames, views.wh,
                                              torch.cuda.current_stream(dev).cuda_stream)
     _lib.check(rc, "sks_heatmap_factors")
+    if drop_mask is not None:
+        dm = torch.as_tensor(drop_mask, dtype=torch.bool).to(row.device)
+        row.masked_fill_(dm[:, :, None], 0.0)
+        cmin.masked_fill_(dm, 0.0)
+        den.masked_fill_(dm, 1.0)
     return row, col, cmin, den
 
 
@@ -90,15 +103,10 @@ def generate_heatmaps(means, scaling, rotation_raw, poses_2d, cameras, scaling_m
     explicitly.  A dropped plane has no impulse: it is all zero before and after normalize_heatmaps (0 / 1e-8), which the
     separable form states as row = 0, cmin = 0, den = 1.  `frames`: see heatmap_factors."""
     from . import _lib
-    row, col, cmin, den = heatmap_factors(means, scaling, rotation_raw, poses_2d, cameras, scaling_modifier, views=views,
-                                          frames=frames)
     if dropout and drop_mask is None:
-        drop_mask = draw_dropout(row.shape[0], row.shape[1])
-    if drop_mask is not None:
-        dm = torch.as_tensor(drop_mask, dtype=torch.bool).to(row.device)
-        row.masked_fill_(dm[:, :, None], 0.0)
-        cmin.masked_fill_(dm, 0.0)
-        den.masked_fill_(dm, 1.0)
+        drop_mask = draw_dropout(len(cameras), means.shape[-2])
+    row, col, cmin, den = heatmap_factors(means, scaling, rotation_raw, poses_2d, cameras, scaling_modifier, views=views,
+                                          frames=frames, drop_mask=drop_mask)
     V, J, H = row.shape
     W = col.shape[2]
     if out is None:

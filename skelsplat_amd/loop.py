@@ -582,7 +582,7 @@ class FrameBatchLoop:
     Early stopping (a per-frame host decision, one sync per group) is MultiViewLoop's business, not this class's."""
 
     def __init__(self, gaussians, cameras, frames, dataset="h36m", accumulation_steps=4, lambda_consistency=1e-5,
-                 antialiasing=False, use_graph=False):
+                 antialiasing=False, use_graph=False, factored=True):
         import ctypes
         gm = gaussians
         self.gm = gm
@@ -623,25 +623,40 @@ class FrameBatchLoop:
         self._adam = (ctypes.c_double * 3)(cfg["betas"][0], cfg["betas"][1], cfg["eps"])
         limbs = [i for pair in DATASETS[dataset]["limbs"] for i in pair]
         self._limb = (ctypes.c_int * 8)(*limbs) if self.lambda_consistency != 0.0 else None
-        # heat-maps of all F x V views (frame-major) in one flat buffer; views of one size adjacent (H36M: two sizes)
         cams_all = [cameras[k % V] for k in range(F * V)]
+        self._cams_all = cams_all
         sizes = [(int(c.image_width), int(c.image_height)) for c in cams_all]
-        self.hset = R.HeatmapSet(sizes, self.C, dev)
-        self.size_groups = []     # [slots (frame-major), ViewBatch of them, (Vg,C,H,W) planes, GtStats, slot index tensor]
-        for key, slots in self.hset.groups.items():
-            vb = R.ViewBatch.from_cameras([cams_all[k] for k in slots])
-            gt = self.hset.group(key)
-            gt.zero_()
-            self.size_groups.append([slots, vb, gt, R.gt_tile_stats(gt), torch.tensor(slots, dtype=torch.long, device=dev)])
-        if len(self.size_groups) == 1:
-            self.views_all, self.stats_all = self.size_groups[0][1], self.size_groups[0][3]
-        else:
+        # factored (default): the pseudo-GT stays in its separable form (rasterizer.HeatmapFactors) -- the fused step
+        # evaluates the pixels it needs, the per-view loss constants come from the factors (sks_heatmap_totals), and no
+        # heat-map plane is ever written: 68 MB per H36M view and a frame's largest memory pass are gone
+        self.factored = bool(factored)
+        self.hset, self.size_groups, self.factors = None, [], None
+        if self.factored:
             self.views_all = R.ViewBatch.from_cameras(cams_all, allow_mixed=True)
+            self.factors = R.HeatmapFactors(F * V, self.C, self.views_all.W, self.views_all.H, dev)
             st = R.GtStats()
-            st.gt, st.tile_S, st.tile_N = self.hset.flat, None, None
+            st.gt, st.tile_S, st.tile_N = None, None, None
             st.totals = torch.zeros((F * V, 2), dtype=torch.float64, device=dev)
-            st.offsets = self.hset.offsets
+            st.factors = self.factors
             self.stats_all = st
+        else:
+            # planes of all F x V views (frame-major) in one flat buffer; views of one size adjacent (H36M: two sizes)
+            self.hset = R.HeatmapSet(sizes, self.C, dev)
+            # [slots (frame-major), ViewBatch of them, (Vg,C,H,W) planes, GtStats, slot index tensor]
+            for key, slots in self.hset.groups.items():
+                vb = R.ViewBatch.from_cameras([cams_all[k] for k in slots])
+                gt = self.hset.group(key)
+                gt.zero_()
+                self.size_groups.append([slots, vb, gt, R.gt_tile_stats(gt), torch.tensor(slots, dtype=torch.long, device=dev)])
+            if len(self.size_groups) == 1:
+                self.views_all, self.stats_all = self.size_groups[0][1], self.size_groups[0][3]
+            else:
+                self.views_all = R.ViewBatch.from_cameras(cams_all, allow_mixed=True)
+                st = R.GtStats()
+                st.gt, st.tile_S, st.tile_N = self.hset.flat, None, None
+                st.totals = torch.zeros((F * V, 2), dtype=torch.float64, device=dev)
+                st.offsets = self.hset.offsets
+                self.stats_all = st
         with torch.no_grad():
             self._fstate = R.geometry_views(self.views_all, self.xyz, self.C, self.opacity, self.scaling, self.rotation, None,
                                             antialiasing=antialiasing, raw_params=True, frames=F)
@@ -657,8 +672,10 @@ class FrameBatchLoop:
         ready `heatmaps` (F,V,C,H,W) / a list of F lists of V (C,H_v,W_v) planes.  `drop_masks`: optional (F,V,J) bool of
         dropped heat-map planes (heatmaps.draw_dropout per frame).  Everything is re-initialised in place, so captured
         hipGraphs are replayed as they are."""
-        from .heatmaps import generate_heatmaps
+        from .heatmaps import generate_heatmaps, heatmap_factors
         F, V, P = self.F, self.V, self.P
+        if self.factored and heatmaps is not None:
+            raise ValueError("ready heat-map planes need FrameBatchLoop(..., factored=False)")
         with torch.no_grad():
             pts = points if torch.is_tensor(points) else torch.as_tensor(np.asarray(points))
             if tuple(pts.shape) != (F, P, 3):
@@ -673,6 +690,11 @@ class FrameBatchLoop:
                 drop_all = None if drop_masks is None else torch.as_tensor(drop_masks).reshape(F * V, -1)
             elif heatmaps is None:
                 raise ValueError("new_scenes needs poses_2d or heatmaps")
+            if self.factored:
+                # two small launches for all frames and image sizes: the factors, then the loss constants from them
+                heatmap_factors(self.xyz, torch.exp(self.scaling), self.rotation, p2d_all, self._cams_all,
+                                views=self.views_all, frames=F, out=self.factors, drop_mask=drop_all)
+                self.factors.totals(self.views_all, self.stats_all.totals)
             for slots, vb, gt, stats, idx in self.size_groups:
                 if heatmaps is not None:
                     for i, k in enumerate(slots):

@@ -604,10 +604,46 @@ class GtStats:
     """Per-scene statistics of the constant pseudo-GT heat-maps (V,C,H,W): what the masked-L2 loss sees wherever the
     render is zero.  `offsets` (HOST size_t array or None): views of different sizes -- `gt` is then a flat fp32 buffer
     and offsets[v] the start (in floats) of view v's (C,H_v,W_v) planes (HeatmapSet)."""
-    __slots__ = ("gt", "tile_S", "tile_N", "totals", "offsets")
+    __slots__ = ("gt", "tile_S", "tile_N", "totals", "offsets", "factors")
 
     def __init__(self):
         self.offsets = None
+        self.factors = None      # HeatmapFactors: the heat-maps in separable form, no planes (then gt is None)
+
+
+class HeatmapFactors:
+    """The pseudo-GT heat-maps of V views in SEPARABLE form -- plane(v, j) = (row[v,j][:, None] * col[v,j][None, :] -
+    cmin[v,j]) / den[v,j], what heatmaps.heatmap_factors computes -- for the sparse fused step, which evaluates the few
+    thousand pixels it needs from the factors (bit for bit the value sks_heatmaps would have stored) instead of reading
+    them back from (V,J,H,W) planes nobody else looks at: 68 MB per H36M view never written.  row (V,J,H), col (V,J,W) with
+    H, W the LARGEST view (views of different sizes use the leading part of their rows), cmin / den (V,J).
+    `totals()` fills a (V,2) fp64 table with each view's {sum gt^2, count gt > 0} (GtStats.totals)."""
+
+    def __init__(self, V, J, W, H, device):
+        import ctypes
+        self.V, self.J, self.W, self.H = int(V), int(J), int(W), int(H)
+        self.row = torch.zeros((V, J, H), dtype=torch.float32, device=device)
+        self.col = torch.zeros((V, J, W), dtype=torch.float32, device=device)
+        self.cmin = torch.zeros((V, J), dtype=torch.float32, device=device)
+        self.den = torch.ones((V, J), dtype=torch.float32, device=device)
+        self.ptrs = (ctypes.c_void_p * 4)(self.row.data_ptr(), self.col.data_ptr(), self.cmin.data_ptr(), self.den.data_ptr())
+
+    def totals(self, views, out):
+        lib = _lib.load()
+        if tuple(out.shape) != (self.V, 2) or out.dtype != torch.float64 or not out.is_contiguous():
+            raise ValueError("HeatmapFactors.totals: `out` must be a contiguous fp64 (V,2) tensor")
+        dev = self.row.device
+        with torch.cuda.device(dev):
+            rc = lib.sks_heatmap_totals(self.V, self.J, self.W, self.H, self.row.data_ptr(), self.col.data_ptr(),
+                                        self.cmin.data_ptr(), self.den.data_ptr(), views.wh, out.data_ptr(),
+                                        torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(rc, "sks_heatmap_totals")
+        return out
+
+    def planes(self, v, size=None):
+        """View v's (J,H_v,W_v) planes as tensor ops (tests, debugging): the same fp32 expression, same order."""
+        w, h = size or (self.W, self.H)
+        return (self.row[v, :, :h, None] * self.col[v, :, None, :w] - self.cmin[v, :, None, None]) / self.den[v, :, None, None]
 
 
 class HeatmapSet:
@@ -722,7 +758,13 @@ def geometry_views(views: ViewBatch, means3D, C, opacities, scales, rotations, c
 
 
 def _check_heatmaps(views, C, stats):
-    """The heat-maps must be what the views address: one (V,C,H,W) tensor, or (mixed sizes) a HeatmapSet's flat buffer."""
+    """The heat-maps must be what the views address: one (V,C,H,W) tensor, or (mixed sizes) a HeatmapSet's flat buffer,
+    or (factored) a HeatmapFactors of the views' largest size."""
+    if stats.factors is not None:
+        f = stats.factors
+        if (f.V, f.J, f.W, f.H) != (views.V, C, views.W, views.H):
+            raise RuntimeError(f"heat-map factors {(f.V, f.J, f.W, f.H)} do not match the views {(views.V, C, views.W, views.H)}")
+        return
     if views.mixed:
         if stats.offsets is None or len(stats.offsets) != views.V:
             raise RuntimeError("views of different sizes need heat-maps in one flat buffer with per-view offsets (HeatmapSet)")
@@ -750,12 +792,12 @@ def loop_fused_step(st: ForwardState, stats: GtStats, features, packed, sums, sl
     with torch.cuda.device(dev):
         rc = lib.sks_loop_fused_step(V, P, C, W, H, st.views.viewmatrix.data_ptr(), st.views.projmatrix.data_ptr(),
                                      st.views.tanfovx, st.views.tanfovy, feat2.data_ptr(), st.scale_modifier, st.flags,
-                                     st.radii.data_ptr(), st.geom.data_ptr(), stats.gt.data_ptr(), stats.totals.data_ptr(),
+                                     st.radii.data_ptr(), st.geom.data_ptr(), _lib.ptr(stats.gt), stats.totals.data_ptr(),
                                      accum.data_ptr(), sums.data_ptr(), packed.data_ptr(), slots.data_ptr(), group_mask,
                                      last_view, xyz.data_ptr(), scaling.data_ptr(), rotation.data_ptr(), opacity.data_ptr(),
                                      exp_avg.data_ptr(), exp_avg_sq.data_ptr(), counters.data_ptr(), acc_steps, lr_sched, lrs,
                                      adam, float(lambda_consistency), limb, st.views.wh, stats.offsets,
-                                     st.frames, stream)
+                                     st.frames, None if stats.factors is None else stats.factors.ptrs, stream)
     _lib.check(rc, "sks_loop_fused_step")
 
 
@@ -791,10 +833,11 @@ def backward_fused_loss(st: ForwardState, stats: GtStats, means3D, features, opa
                                          st.views.tanfovx, st.views.tanfovy, _lib.ptr(bgC), _lib.ptr(means3D), _lib.ptr(feat2),
                                          _lib.ptr(opacities), _lib.ptr(scales), _lib.ptr(rotations), _lib.ptr(cov3D_precomp),
                                          st.scale_modifier, st.flags, st.radii.data_ptr(), st.geom.data_ptr(),
-                                         stats.gt.data_ptr(), _lib.ptr(stats.tile_S), _lib.ptr(stats.tile_N),
+                                         _lib.ptr(stats.gt), _lib.ptr(stats.tile_S), _lib.ptr(stats.tile_N),
                                          stats.totals.data_ptr(), accum.data_ptr(), _lib.ptr(out["means3D"]),
                                          _lib.ptr(out["means2D"]), _lib.ptr(out["opacities"]), _lib.ptr(out["scales"]),
                                          _lib.ptr(out["rotations"]), _lib.ptr(out["cov3D"]), sums.data_ptr(),
-                                         _lib.ptr(packed_out), st.views.wh, stats.offsets, stream)
+                                         _lib.ptr(packed_out), st.views.wh, stats.offsets,
+                                         None if stats.factors is None else stats.factors.ptrs, stream)
     _lib.check(rc, "sks_backward_fused_loss")
     return out, sums

@@ -12,6 +12,7 @@ from skelsplat_amd.scene import SyntheticScene, GaussianModel
 dev = torch.device("cuda", 0)
 Fs = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8, 16]
 ITERS = int(os.environ.get("ITERS", "500"))
+FACTORED = os.environ.get("FACTORED", "1") == "1"   # heat-maps as separable factors (no planes) or as planes
 sc = SyntheticScene("h36m", n_views=4, seed=0, device=dev)
 rng = np.random.default_rng(1)
 base3, base2 = np.asarray(sc.pose_3d_init, np.float32), np.asarray(sc.poses_2d, np.float32)
@@ -44,7 +45,7 @@ if os.environ.get("ONLY_BATCH") != "1":
   print(f"one frame at a time: {dt*1e3:.3f} ms per frame, {1/dt:.0f} frames/s")
   base = dt
 for F in Fs:
-    fb = FrameBatchLoop(model(), sc.cameras, F, dataset="h36m", use_graph=True)
+    fb = FrameBatchLoop(model(), sc.cameras, F, dataset="h36m", use_graph=True, factored=FACTORED)
     pts, p2d = frames(F)
     for rep in range(3):
         torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -64,7 +65,7 @@ for spec in os.environ.get("STREAMS", "2x8,2x16,4x8,4x16").split(","):
         continue
     ns, h = (int(x) for x in spec.split("x"))
     F = ns * h
-    loops = [FrameBatchLoop(model(), sc.cameras, h, dataset="h36m", use_graph=True) for _ in range(ns)]
+    loops = [FrameBatchLoop(model(), sc.cameras, h, dataset="h36m", use_graph=True, factored=FACTORED) for _ in range(ns)]
     streams = [torch.cuda.Stream() for _ in range(ns)]
     pts, p2d = frames(F)
     for rep in range(3):
