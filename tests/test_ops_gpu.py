@@ -330,6 +330,23 @@ def test_sparse_fused_loss_backward_equals_dense_path(device, dataset):
     assert float(N.min()) > 1000 and float(S.min()) > 0
     for k in ("means3D", "means2D", "opacities", "scales", "rotations"):
         util.assert_close(k, gs[k].cpu(), gd[k].cpu(), rtol=1e-4, atol_scale=1e-5)
+    # the same call with the heat-maps as separable factors (no plane read): the pseudo-GT it evaluates is bit for bit the
+    # stored one, so gradients and mask counts are identical; the constants come from sks_heatmap_totals
+    from skelsplat_amd.heatmaps import heatmap_factors
+    fac = R.HeatmapFactors(3, C, W, H, device)
+    heatmap_factors(torch.tensor(sc.pose_3d_gt, device=device).float(), gm.get_scaling.detach() * 1.3, gm._rotation.detach(),
+                    torch.tensor(sc.poses_2d, device=device), sc.cameras, views=views, out=fac)
+    for v in range(3):
+        assert torch.equal(fac.planes(v), hm[v])
+    fst = R.GtStats()
+    fst.gt, fst.tile_S, fst.tile_N, fst.factors = None, None, None, fac
+    fst.totals = fac.totals(views, torch.empty((3, 2), dtype=torch.float64, device=device))
+    assert torch.equal(fst.totals[:, 1], stats.totals[:, 1])
+    assert ((fst.totals[:, 0] - stats.totals[:, 0]).abs() <= 1e-6 * stats.totals[:, 0].abs()).all()
+    gf, sums_f = R.backward_fused_loss(st2, fst, *args)
+    assert torch.equal(sums_f[:, 1], sums[:, 1]) and ((sums_f[:, 0] - sums[:, 0]).abs() <= 1e-6 * sums[:, 0].abs()).all()
+    for k in ("means3D", "means2D", "opacities", "scales", "rotations"):
+        assert torch.equal(gf[k], gs[k]), k
 
 
 def test_sparse_loop_equals_dense_loop(device):
