@@ -5,6 +5,7 @@
   <round>_kernel_stats_panoptic.csv   same, Panoptic 31-view workload
   <round>_kernel_stats_stress.csv     same, tools/bench_stress.py (P = 4352, 8 views, 2048^2, binned path)
   <round>_bench.json / <round>_bench_panoptic.json    the bench.py lines of the same box
+  <round>_kernel_stats_frames.csv     same, tools/bench_frames.py 16 (frame-batched loop); <round>_frames.txt: frames/s table
   traffic.json                        HBM bytes per launch per kernel from the PMC passes (bench.py reads this)
 
 PMC units and corrections as prescribed by MI355X_MICROARCH.md (HBM / rocprofv3 section): WRITE_SIZE and FETCH_SIZE
@@ -70,7 +71,11 @@ for wl, tag in (("h36m", ""), ("panoptic", "_panoptic"), ("stress", "_stress")):
         if "roofline" in line:
             line["roofline"]["traffic"] = entry["fwd_bytes_per_launch"]
             json.dump(line, open(bj, "w"))
-for name in ("bench_ssim.txt", "ssim_pmc_fwd.txt", "ssim_pmc_train.txt", "sharded_world1_bench.json", "width_sweep.txt"):   # fused-SSIM timings and SQ counter passes
+st = glob.glob(os.path.join(SRC, "frames_stats", "**", "*kernel_stats.csv"), recursive=True)
+if st:   # tools/bench_frames.py 16: the frame-batched loop (16 H36M frames per launch)
+    shutil.copy(st[0], os.path.join(DST, f"{rnd}_kernel_stats_frames.csv"))
+for name in ("bench_ssim.txt", "ssim_pmc_fwd.txt", "ssim_pmc_train.txt", "sharded_world1_bench.json", "width_sweep.txt",
+             "frames.txt"):   # fused-SSIM timings and SQ counter passes, the sharded path at world 1, sweeps
     src = os.path.join(SRC, name)
     if os.path.exists(src) and os.path.getsize(src):
         shutil.copy(src, os.path.join(DST, f"{rnd}_{name}"))

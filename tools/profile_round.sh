@@ -15,6 +15,8 @@ for WL in h36m panoptic; do
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/${WL}_f" -o f -- python3 "$ROOT/bench.py" --workload $WL --steps 20 --warmup 3 --no-cpu-baseline --no-prof --no-extras > /dev/null 2> "$OUT/${WL}_f.log"
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stress_stats" -o stats -- python3 "$ROOT/tools/bench_stress.py" > "$OUT/stress.log" 2>&1
+# the frame-batched loop: 16 H36M frames per launch (kernel stats of that run alone), then the frames/s table
+ONLY_BATCH=1 STREAMS= ITERS=200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/frames_stats" -o stats -- python3 "$ROOT/tools/bench_frames.py" 16 > "$OUT/frames_under_rocprof.log" 2>&1
 cd "$ROOT"
 python3 tools/bench_ssim.py > "$OUT/bench_ssim.txt" 2>/dev/null
 bash tools/pmc_ssim.sh fwd 4,17,1000,1000 > "$OUT/ssim_pmc_fwd.txt" 2>&1
@@ -25,4 +27,6 @@ python3 bench.py --workload panoptic --steps 50 --warmup 5 > "$OUT/panoptic_benc
 # the sharded path at world size 1 (RCCL all_gather included, the group also replayed as a hipGraph)
 SKS_BENCH_FORCE_DIST=1 SKS_GRAPH_COLLECTIVES=1 python3 bench.py --steps 50 --warmup 5 > "$OUT/sharded_world1_bench.json" 2> "$OUT/sharded_world1_bench.log"
 python3 tools/width_sweep2.py 1000,1002,1024,1920 0 > "$OUT/width_sweep.txt" 2>&1
+python3 tools/bench_frames.py 1 2 4 8 16 2>/dev/null | grep "frames/s" > "$OUT/frames.txt"
+FACTORED=0 ONLY_BATCH=1 python3 tools/bench_frames.py 16 2>/dev/null | grep "frames/s" | sed 's/^/planes (factored=False): /' >> "$OUT/frames.txt"
 find "$OUT" -name "*.csv" | head -40
