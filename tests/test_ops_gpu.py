@@ -863,7 +863,7 @@ def test_full_size_h36m_loop_sparse_equals_dense(device, mixed):
 
 # ------------------------------------------------------------------ frame batching: F frames in the two launches of one
 @pytest.mark.parametrize("factored", [True, False], ids=["factors", "planes"])
-@pytest.mark.parametrize("mode", ["same", "mixed", "graph5", "wide9"])
+@pytest.mark.parametrize("mode", ["same", "mixed", "graph5", "wide9", "panoptic7"])
 def test_frame_batch_equals_separate_loops(device, mode, factored):
     """FrameBatchLoop steps F independent frames per launch (sks_loop_fused_step(frames=F), one tail workgroup per frame);
     every frame must end EXACTLY where a MultiViewLoop running it alone ends: parameters, Adam moments, V-slot buffers,
@@ -874,8 +874,17 @@ def test_frame_batch_equals_separate_loops(device, mode, factored):
     from skelsplat_amd.loop import MultiViewLoop, FrameBatchLoop
     from skelsplat_amd.scene import SyntheticScene, GaussianModel
     F = 3
-    V = {"graph5": 5, "wide9": 9}.get(mode, 4)   # wide9: more than 8 views, the optimiser's LDS-parked slot walk
+    V = {"graph5": 5, "wide9": 9, "panoptic7": 7}.get(mode, 4)   # wide9: more than 8 views, the optimiser's LDS-parked slot walk
+    ds = "panoptic" if mode == "panoptic7" else "h36m"            # panoptic7: 19 joints / channels (the CG = 20 kernels)
     sc, model = _make_loop_scene(device, V=V, seed=51)
+    if ds == "panoptic":
+        sc = SyntheticScene("panoptic", n_views=V, seed=51, W=192, H=112, ring=2500.0, fx=1400.0 * 0.1 * 1.5, device=device)
+
+        def model(device):
+            gm = GaussianModel().create_from_points(sc.pose_3d_init, sc.spatial_lr_scale, sc.n_joints, scaling=3.9,
+                                                    scene_type="panoptic", device=device)
+            gm.training_setup()
+            return gm
     cams = sc.cameras
     if mode == "mixed":
         b = SyntheticScene("h36m", n_views=V, seed=51, W=162, H=128, ring=2500.0, fx=1145.0 * 0.16 * 1.5, device=device)
@@ -888,7 +897,7 @@ def test_frame_batch_equals_separate_loops(device, mode, factored):
     drop[1, 2, [3, 9]] = True          # frame 1 loses two planes of view 2 (training.dropout)
     use_graph = mode == "graph5"
     iters = 44
-    fb = FrameBatchLoop(model(device), cams, F, dataset="h36m", use_graph=use_graph, factored=factored)
+    fb = FrameBatchLoop(model(device), cams, F, dataset=ds, use_graph=use_graph, factored=factored)
     assert (fb.hset is None) == factored
     fb.new_scenes(pts, poses_2d=p2d, drop_masks=drop)
     out = fb.run(iters, groups_per_graph=4).clone()
@@ -897,7 +906,7 @@ def test_frame_batch_equals_separate_loops(device, mode, factored):
     for f in range(F):
         gm = model(device)
         hm0 = [torch.zeros((sc.n_joints, int(c.image_height), int(c.image_width)), device=device) for c in cams]
-        loop = MultiViewLoop(gm, cams, hm0 if mode == "mixed" else torch.stack(hm0), dataset="h36m", sparse=True,
+        loop = MultiViewLoop(gm, cams, hm0 if mode == "mixed" else torch.stack(hm0), dataset=ds, sparse=True,
                              use_graph=use_graph, fused_tail=True)
         assert loop.fused_tail
         from skelsplat_amd.heatmaps import generate_heatmaps
