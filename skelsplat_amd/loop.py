@@ -789,8 +789,11 @@ class FrameBatchLoop:
             raise ValueError(f"{N} frames of points, {p2d.shape[0]} of detections")
         out = torch.empty((N, self.P, 3), dtype=torch.float32, device=self.device)
         for b in range(0, N, F):
-            idx = [min(b + i, N - 1) for i in range(F)]
-            self.new_scenes(pts[idx], poses_2d=p2d[idx])
+            if b + F <= N:
+                self.new_scenes(pts[b:b + F], poses_2d=p2d[b:b + F])
+            else:
+                idx = [min(b + i, N - 1) for i in range(F)]
+                self.new_scenes(pts[idx], poses_2d=p2d[idx])
             res = self.run(iterations, groups_per_graph)
             out[b:min(b + F, N)] = res[:min(F, N - b)]
         return out
@@ -830,9 +833,12 @@ class FramePipeline:
         for w in range(0, len(starts), S):
             active = list(zip(self.loops, self.streams, starts[w:w + S]))
             for fb, st, b in active:
-                idx = [min(b + i, N - 1) for i in range(F)]
                 with torch.cuda.stream(st):
-                    fb.new_scenes(pts[idx], poses_2d=p2d[idx])
+                    if b + F <= N:      # a full batch: views of the inputs, no gather
+                        fb.new_scenes(pts[b:b + F], poses_2d=p2d[b:b + F])
+                    else:
+                        idx = [min(b + i, N - 1) for i in range(F)]
+                        fb.new_scenes(pts[idx], poses_2d=p2d[idx])
             for k in range(0, iterations, max(int(interleave), 1)):
                 for fb, st, b in active:
                     with torch.cuda.stream(st):
