@@ -12,8 +12,6 @@ single all_gather of the (V_local, P, 11) per-view parameter gradients over RCCL
 on every rank, so the mean uses the reference's summation order and every rank takes the identical Adam step
 (no parameter broadcast).  Nothing in the group synchronises with the host.
 """
-import math
-
 import numpy as np
 
 import torch
