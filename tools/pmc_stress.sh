@@ -1,0 +1,24 @@
+#!/bin/bash
+# SQ counter passes over the binned path's kernels (tools/bench_stress.py): bash tools/pmc_stress.sh [kernel-substring]   (GPU box)
+pat=${1:-k_render_bwd_binned}
+root=$(cd "$(dirname "$0")/.." && pwd)
+cd /tmp && export TMPDIR=/tmp
+i=0
+for set in "SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA" \
+           "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU" "SQ_INSTS_SMEM SQ_WAVES SQ_INST_LEVEL_VMEM GRBM_GUI_ACTIVE"; do
+  i=$((i+1))
+  rocprofv3 --pmc $set --output-format csv -d /tmp/pmcs$i -o p -- python3 $root/tools/bench_stress.py > /dev/null 2>&1
+done
+python3 - "$pat" <<'PY'
+import csv, glob, collections, sys
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("/tmp/pmcs*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        if sys.argv[1] not in k: continue
+        acc[k.split("(")[0][-40:]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, d in acc.items():
+    print(k)
+    for c, v in sorted(d.items()):
+        print(f"   {c:24s} {sum(v)/len(v):14.0f}   (n={len(v)})")
+PY
