@@ -863,7 +863,7 @@ def test_full_size_h36m_loop_sparse_equals_dense(device, mixed):
 
 # ------------------------------------------------------------------ frame batching: F frames in the two launches of one
 @pytest.mark.parametrize("factored", [True, False], ids=["factors", "planes"])
-@pytest.mark.parametrize("mode", ["same", "mixed", "graph5", "wide9", "panoptic7"])
+@pytest.mark.parametrize("mode", ["same", "mixed", "graph5", "wide9", "panoptic7", "oneview", "twoviews"])
 def test_frame_batch_equals_separate_loops(device, mode, factored):
     """FrameBatchLoop steps F independent frames per launch (sks_loop_fused_step(frames=F), one tail workgroup per frame);
     every frame must end EXACTLY where a MultiViewLoop running it alone ends: parameters, Adam moments, V-slot buffers,
@@ -874,7 +874,7 @@ def test_frame_batch_equals_separate_loops(device, mode, factored):
     from skelsplat_amd.loop import MultiViewLoop, FrameBatchLoop
     from skelsplat_amd.scene import SyntheticScene, GaussianModel
     F = 3
-    V = {"graph5": 5, "wide9": 9, "panoptic7": 7}.get(mode, 4)   # wide9: more than 8 views, the optimiser's LDS-parked slot walk
+    V = {"graph5": 5, "wide9": 9, "panoptic7": 7, "oneview": 1, "twoviews": 2}.get(mode, 4)   # wide9: > 8 views, LDS-parked slot walk
     ds = "panoptic" if mode == "panoptic7" else "h36m"            # panoptic7: 19 joints / channels (the CG = 20 kernels)
     sc, model = _make_loop_scene(device, V=V, seed=51)
     if ds == "panoptic":
@@ -894,7 +894,7 @@ def test_frame_batch_equals_separate_loops(device, mode, factored):
     pts = np.stack([base3 + rng.normal(0, 30.0 * f, base3.shape) for f in range(F)]).astype(np.float32)
     p2d = np.stack([base2 + rng.normal(0, 3.0 * f, base2.shape) for f in range(F)]).astype(np.float32)
     drop = torch.zeros((F, V, sc.n_joints), dtype=torch.bool)
-    drop[1, 2, [3, 9]] = True          # frame 1 loses two planes of view 2 (training.dropout)
+    drop[1, min(2, V - 1), [3, 9]] = True          # frame 1 loses two planes of one view (training.dropout)
     use_graph = mode == "graph5"
     iters = 44
     fb = FrameBatchLoop(model(device), cams, F, dataset=ds, use_graph=use_graph, factored=factored)
