@@ -134,9 +134,9 @@ def test_forward_h36m_1002_wide_sensor(device, W, H, binned):
 
 
 def test_full_size_h36m_1002(device):
-    """BASELINE config 2 at the real sensor mix: 1002x1000 views at full size.  No oracle at this size (minutes of CPU):
-    the 16-byte half-masked fill equals the 4-byte path bit for bit, every element is written (NaN-poisoned buffer), and the
-    image is supported exactly on the tiles the rects cover."""
+    """BASELINE config 2 at the real sensor mix: 1002x1000 views at full size (oracle parity at this size:
+    tests/test_fullsize_gpu.py).  Here, what the oracle cannot see: the 16-byte half-masked fill equals the 4-byte path bit
+    for bit, every element is written (NaN-poisoned buffer), and the image is supported exactly on the tiles the rects cover."""
     from skelsplat_amd.scene import SyntheticScene, GaussianModel
     sc = SyntheticScene("h36m", n_views=4, seed=0, device=device, W=1002, H=1000)
     gm = GaussianModel().create_from_points(sc.pose_3d_init, sc.spatial_lr_scale, 17, device=device)
@@ -401,7 +401,8 @@ def test_autograd_single_view_api(device):
 
 
 def test_full_size_properties(device):
-    """BASELINE config 2 shape (P=17, C=17, 1000x1000, V=4): size-independent properties instead of the slow oracle."""
+    """BASELINE config 2 shape (P=17, C=17, 1000x1000, V=4): size-independent properties (two code paths agree, linearity
+    and support of the backward); the oracle comparison at this size is tests/test_fullsize_gpu.py."""
     dev = device
     c = util.make_case(seed=11, W=1000, H=1000, n_views=4, scale_log=3.0, rand_rot=False, opac=1.0, ring=5000.0, onehot=True)
     views = R.ViewBatch.from_cameras([cam.to(dev) for cam in c.cams])
@@ -635,8 +636,9 @@ def test_antialiasing_in_the_sparse_loop(device):
 
 
 def test_stress_config_binned_path(device):
-    """BASELINE config 5 shape: 256 skeletons (P = 4352, C = 17), 2048x2048, binned path.  The oracle is too slow at this
-    size, so: oracle parity on a cropped-resolution twin (same P, 512x512) + size-independent properties at full size."""
+    """BASELINE config 5 shape: 256 skeletons (P = 4352, C = 17), 2048x2048, binned path: oracle parity on a
+    cropped-resolution twin (same P, 512x512) + size-independent properties at full size (full-size oracle parity of the
+    same scene: tests/test_fullsize_gpu.py::test_config5_stress_bench_scene)."""
     dev = device
     c = util.make_case(seed=41, W=512, H=512, n_views=1, scale_log=3.3, n_skeletons=256, pitch=1500.0, ring=20000.0, fxmul=4.0)
     assert c.P == 4352

@@ -12,7 +12,7 @@ class Case:
 
 
 def make_case(seed, W, H, dataset="h36m", n_views=2, scale_log=4.0, rand_rot=True, opac=None, fxmul=1.0,
-              ring=2500.0, n_skeletons=1, onehot=False, pitch=700.0):
+              ring=2500.0, n_skeletons=1, onehot=False, pitch=700.0, with_dL=True):
     """Skeleton(s) seen by `n_views` ring cameras; anisotropic random covariances so splats overlap and saturate."""
     sc = SyntheticScene(dataset, n_views=n_views, seed=seed, W=W, H=H, ring=ring,
                         fx=1145.0 * (W / 1000) * fxmul, n_skeletons=n_skeletons, pitch=pitch)
@@ -31,8 +31,9 @@ def make_case(seed, W, H, dataset="h36m", n_views=2, scale_log=4.0, rand_rot=Tru
     c.cams = sc.cameras
     c.ocams = [orc.Cam(W, H, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5),
                        cam.world_view_transform.numpy(), cam.full_proj_transform.numpy()) for cam in c.cams]
-    c.dL_color = rng.normal(0, 1, (n_views, c.C, H, W)).astype(np.float32)
-    c.dL_inv = rng.normal(0, 1, (n_views, 1, H, W)).astype(np.float32)
+    if with_dL:    # (drawn last: leaving them out -- full-size cases make theirs on the GPU -- changes nothing above)
+        c.dL_color = rng.normal(0, 1, (n_views, c.C, H, W)).astype(np.float32)
+        c.dL_inv = rng.normal(0, 1, (n_views, 1, H, W)).astype(np.float32)
     return c
 
 
