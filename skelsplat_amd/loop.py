@@ -82,24 +82,6 @@ class OptEarlyStopping:
         return bool(torch.all(torch.abs(w1 - w2) < self.repeat_tolerance))
 
 
-class EarlyStopping:
-    """utils/general_utils.py:449-464 (patience on the best loss; not in the reference's registry, kept for completeness)."""
-
-    def __init__(self, patience=10, min_delta=1e-6):
-        self.patience = patience
-        self.min_delta = min_delta
-        self.best_loss = float("inf")
-        self.counter = 0
-
-    def __call__(self, current_loss):
-        if current_loss < self.best_loss - self.min_delta:
-            self.best_loss = current_loss
-            self.counter = 0
-        else:
-            self.counter += 1
-        return self.counter >= self.patience
-
-
 class NotStopping:
     """utils/general_utils.py:493-498."""
 

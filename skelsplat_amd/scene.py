@@ -201,21 +201,34 @@ def inverse_sigmoid(x):
     return torch.log(x / (1 - x))
 
 
-def get_expon_lr_func(lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, max_steps=1000000):
-    """utils/general_utils.py:38-71."""
+class ExponentialLR:
+    """The xyz learning-rate schedule (the reference's get_expon_lr_func, utils/general_utils.py:38-71), written in the
+    closed form the device-side optimiser evaluates (csrc/sks_loop_dev.h, adam_block_begin): geometric interpolation
+    lr_init^(1-t) * lr_final^t over t = step / max_steps clamped to [0, 1], times a sine warm-up from `lr_delay_mult` to 1
+    over the first `lr_delay_steps`; zero for a negative step or an all-zero schedule.  Host and device hold the same two
+    logarithms, so `sks_loop_adam_step` and torch.optim.Adam driven by this object take the same step sizes (pinned to the
+    reference's values by tests/golden/reference_python.npz)."""
 
-    def helper(step):
-        if step < 0 or (lr_init == 0.0 and lr_final == 0.0):
+    def __init__(self, lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, max_steps=1000000):
+        self.off = lr_init == 0.0 and lr_final == 0.0
+        self.log_init = math.log(lr_init) if lr_init > 0.0 else 0.0
+        self.log_final = math.log(lr_final) if lr_final > 0.0 else 0.0
+        self.delay_steps, self.delay_mult, self.max_steps = lr_delay_steps, lr_delay_mult, max_steps
+
+    def __call__(self, step):
+        if self.off or step < 0:
             return 0.0
-        if lr_delay_steps > 0:
-            delay_rate = lr_delay_mult + (1 - lr_delay_mult) * np.sin(0.5 * np.pi * np.clip(step / lr_delay_steps, 0, 1))
-        else:
-            delay_rate = 1.0
-        t = np.clip(step / max_steps, 0, 1)
-        log_lerp = np.exp(np.log(lr_init) * (1 - t) + np.log(lr_final) * t)
-        return delay_rate * log_lerp
+        warm = 1.0
+        if self.delay_steps > 0:
+            c = min(max(step / self.delay_steps, 0.0), 1.0)
+            warm = self.delay_mult + (1.0 - self.delay_mult) * math.sin(0.5 * math.pi * c)
+        t = min(max(step / self.max_steps, 0.0), 1.0)
+        return warm * math.exp(self.log_init * (1.0 - t) + self.log_final * t)
 
-    return helper
+
+def get_expon_lr_func(lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, max_steps=1000000):
+    """Name and signature of utils/general_utils.py:38 (scene/gaussian_model.py:241-246 calls it); returns an ExponentialLR."""
+    return ExponentialLR(lr_init, lr_final, lr_delay_steps, lr_delay_mult, max_steps)
 
 
 class OptimizationParams:
