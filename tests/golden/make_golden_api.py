@@ -1,0 +1,183 @@
+"""Generates tests/golden/reference_api.npz: what the REFERENCE's own Python hands to its native module.
+
+Run in the build container:  python tests/golden/make_golden_api.py
+
+Executed from /root/reference, unmodified (tests/golden/_ref_env.py lists what stands in for CUDA and absent packages):
+  gaussian_renderer/__init__.py:28-371      render_h36m / render_panoptic / render_op, render_functions
+  DGR*/diff_gaussian_rasterization_*/__init__.py:21-207   GaussianRasterizer.forward / markVisible, _RasterizeGaussians
+                                            (the 20-argument forward tuple :60-81, the 24-argument backward tuple :101-124,
+                                            the 9-slot gradient return :129-139)
+  scene/gaussian_model.py:32-47,149-200     activations, create_from_pcd (features (J,1,J), log-space scaling, +inf opacity)
+  scene/cameras.py:19-100                   world_view_transform / full_proj_transform / camera_center
+  utils/loss_utils.py:86-100,226-250        l2_loss_gaussian, limb_3d_consistency_loss  (train.py:150-161 call shape)
+The native module itself is oracle/sks_oracle.c behind the pybind signatures (OracleC): the fixture pins the Python half
+of the path -- argument order, shapes, dtypes, the empty-tensor "not provided" sentinels (Q10), which gradient lands on
+which input -- not the kernels' arithmetic.
+
+Per scenario the fixture stores the raw inputs, every recorded `_C` argument, the render package, the loss and the
+gradients train.py:160-161 asks for (+ the screen-space gradient).  tests/test_cpu.py checks the fixture's own
+consistency; tests/test_api_gpu.py holds the repository's render_* -> GaussianRasterizer -> sks_forward / sks_backward
+to it.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import _ref_env as env   # noqa: E402
+
+FWD_NAMES = ("bg", "means3D", "colors_precomp", "opacities", "scales", "rotations", "scale_modifier", "cov3Ds_precomp",
+             "viewmatrix", "projmatrix", "tanfovx", "tanfovy", "image_height", "image_width", "sh", "sh_degree", "campos",
+             "prefiltered", "antialiasing", "debug")
+BWD_NAMES = ("bg", "means3D", "radii", "colors_precomp", "opacities", "scales", "rotations", "scale_modifier",
+             "cov3Ds_precomp", "viewmatrix", "projmatrix", "tanfovx", "tanfovy", "grad_out_color", "grad_out_depth", "sh",
+             "sh_degree", "campos", "geomBuffer", "num_rendered", "binningBuffer", "imgBuffer", "antialiasing", "debug")
+
+SCENARIOS = [
+    # key, dataset, data_root, W, H, pipe switches, bg, scaling_modifier handed to render()
+    dict(key="h36m", dataset="h36m", W=96, H=80, cov_python=False, antialiasing=False, bg=[0.0, 0.0, 0.0], smod=1.0),
+    dict(key="panoptic", dataset="panoptic", W=112, H=64, cov_python=True, antialiasing=True, bg=[0.3, 0.5, 0.2], smod=1.0),
+    dict(key="op", dataset="occlusion-person", W=88, H=72, cov_python=False, antialiasing=False, bg=[0.0, 0.0, 0.0], smod=1.3),
+]
+
+
+def _store(out, prefix, names, args):
+    for n, a in zip(names, args):
+        if isinstance(a, torch.Tensor):
+            out[f"{prefix}{n}"] = a.numpy()
+            out[f"{prefix}{n}__dtype"] = np.array(str(a.dtype))
+        else:
+            out[f"{prefix}{n}"] = np.array(a)
+            out[f"{prefix}{n}__dtype"] = np.array(type(a).__name__)
+
+
+def main():
+    calls = []
+    env.install(calls)
+    sys.path.append(env.ROOT)
+    from skelsplat_amd.scene import SyntheticScene          # (inputs only: skeleton, ring cameras; stored in the fixture)
+    import gaussian_renderer as ref_gr                      # the reference's
+    assert ref_gr.__file__.startswith(env.REF)
+    from scene.gaussian_model import GaussianModel
+    from scene.cameras import Camera
+    from utils.graphics_utils import BasicPointCloud
+    from utils import losses, consistency_losses
+    out = {"scenarios": np.array([s["key"] for s in SCENARIOS]), "fwd_names": np.array(FWD_NAMES), "bwd_names": np.array(BWD_NAMES)}
+    with env.no_gpu():
+        for i, s in enumerate(SCENARIOS):
+            pre = f"{s['key']}_"
+            sc = SyntheticScene(s["dataset"], n_views=2, seed=20 + i, W=s["W"], H=s["H"], ring=2500.0,
+                                fx=1145.0 * (s["W"] / 1000) * 1.5)
+            J = sc.n_joints
+            cam0 = sc.cameras[1]
+            cam = Camera((s["W"], s["H"]), colmap_id=1, R=cam0.R, T=cam0.T, FoVx=cam0.FoVx, FoVy=cam0.FoVy, K=cam0.K,
+                         depth_params=None, image=None, invdepthmap=None, image_name="", uid=1)
+            gm = GaussianModel(1, "default")
+            infos = [type("CI", (), {"image_name": ""})()]
+            gm.create_from_pcd(BasicPointCloud(sc.pose_3d_init, None, None), infos, sc.spatial_lr_scale, True, 3.9, J, 1.2,
+                               s["dataset"])
+            g = torch.Generator().manual_seed(i)
+            with torch.no_grad():      # every activation Jacobian carries signal
+                gm._opacity.fill_(1.5)
+                gm._rotation.add_(0.2 * torch.randn(gm._rotation.shape, generator=g))
+                gm._scaling.add_(0.3 * torch.randn(gm._scaling.shape, generator=g))
+            pipe = env.Cfg(convert_SHs_python=False, compute_cov3D_python=s["cov_python"], debug=False,
+                           antialiasing=s["antialiasing"])
+            bg = torch.tensor(s["bg"], dtype=torch.float32, device="cuda")
+            render = ref_gr.render_functions[f"diff-gaussian-rasterization-{s['key']}"]
+            n0 = len(calls)
+            pkg = render(cam, gm, pipe, bg, scaling_modifier=s["smod"], use_trained_exp=False, separate_sh=False)
+            image = pkg["render"]
+            gt = torch.rand(image.shape, generator=g) * (torch.rand(image.shape, generator=g) > 0.5)
+            l2, _ = losses["l2_gaussian"](image, gt, None, 0.05, reduction="mean")                 # train.py:150
+            lc = consistency_losses["3D_length_consistency"](gm.get_xyz, "data/" + s["dataset"], reduction="mean") * 1e-5
+            loss = l2 + lc
+            params = [gm.get_xyz, gm._scaling, gm._rotation, gm._opacity]                           # train.py:160-161
+            grads = torch.autograd.grad(loss, params + [pkg["viewspace_points"]], create_graph=True, retain_graph=True)
+            mine = calls[n0:]
+            assert [c[0] for c in mine] == ["rasterize_gaussians", "rasterize_gaussians_backward"], [c[0] for c in mine]
+            _store(out, pre + "fwd_", FWD_NAMES, mine[0][1])
+            _store(out, pre + "bwd_", BWD_NAMES, mine[1][1])
+            out.update({
+                pre + "in_xyz": gm._xyz.detach().numpy(), pre + "in_features_dc": gm._features_dc.detach().numpy(),
+                pre + "in_features_rest_shape": np.array(gm._features_rest.shape),
+                pre + "in_scaling": gm._scaling.detach().numpy(), pre + "in_rotation": gm._rotation.detach().numpy(),
+                pre + "in_opacity": gm._opacity.detach().numpy(), pre + "in_cam_R": cam0.R, pre + "in_cam_T": cam0.T,
+                pre + "in_cam_K": cam0.K, pre + "in_WH": np.array([s["W"], s["H"]]), pre + "in_bg": np.array(s["bg"], np.float32),
+                pre + "in_pipe": np.array([s["cov_python"], s["antialiasing"]]), pre + "in_scaling_modifier": np.float64(s["smod"]),
+                pre + "in_gt": gt.numpy(), pre + "in_dataset": np.array(s["dataset"]),
+                pre + "in_active_sh_degree": np.int64(gm.active_sh_degree),
+                pre + "out_render": image.detach().numpy(), pre + "out_radii": pkg["radii"].numpy(),
+                pre + "out_depth": pkg["depth"].detach().numpy(), pre + "out_visibility_filter": pkg["visibility_filter"].numpy(),
+                pre + "out_viewspace_points": pkg["viewspace_points"].detach().numpy(), pre + "out_keys": np.array(list(pkg.keys())),
+                pre + "loss": np.float64(loss.item()), pre + "l2": np.float64(l2.item()),
+                pre + "cam_world_view_transform": cam.world_view_transform.numpy(),
+                pre + "cam_full_proj_transform": cam.full_proj_transform.numpy(), pre + "cam_camera_center": cam.camera_center.numpy(),
+                pre + "cam_fov": np.array([cam.FoVx, cam.FoVy]),
+            })
+            for n, gr in zip(("xyz", "scaling", "rotation", "opacity", "viewspace_points"), grads):
+                out[pre + "grad_" + n] = gr.detach().numpy()
+
+        # GaussianRasterizer called directly (DGR __init__.py:158-207): validation messages, markVisible, and where each
+        # of the 8 native gradients lands among the 9 inputs (:129-139) -- with recognisable constants from a marker `_C`
+        import diff_gaussian_rasterization_h36m as dgr
+        C, P = 17, 5
+        rs = dgr.GaussianRasterizationSettings(image_height=32, image_width=48, tanfovx=0.5, tanfovy=0.4, bg=torch.zeros(3),
+                                               scale_modifier=1.0, viewmatrix=torch.eye(4), projmatrix=torch.eye(4), sh_degree=0,
+                                               campos=torch.zeros(3), prefiltered=False, debug=False, antialiasing=False)
+        out["settings_fields"] = np.array(rs._fields)
+        rast = dgr.GaussianRasterizer(rs)
+        msgs = []
+        m3, m2, op = torch.zeros(P, 3), torch.zeros(P, 3), torch.ones(P, 1)
+        shs, sc_, rot = torch.ones(P, 1, C), torch.ones(P, 3), torch.ones(P, 4)
+        for kw in (dict(), dict(shs=shs, colors_precomp=torch.ones(P, C)), dict(shs=shs), dict(shs=shs, scales=sc_),
+                   dict(shs=shs, scales=sc_, rotations=rot, cov3D_precomp=torch.ones(P, 6))):
+            try:
+                rast(means3D=m3, means2D=m2, opacities=op, **kw)
+                msgs.append("")
+            except Exception as e:
+                msgs.append(f"{type(e).__name__}: {e}")
+        out["validation_messages"] = np.array(msgs)
+
+        class Marker:   # returns constants k+1 in slot k so that the routing of the 8-tuple is visible in the gradients
+            def rasterize_gaussians(self, *a):
+                Pn = a[1].shape[0]
+                return 7, torch.zeros(C, 32, 48), torch.zeros(Pn, dtype=torch.int32), torch.zeros(1), torch.zeros(1), torch.zeros(1), torch.zeros(1, 32, 48)
+
+            def rasterize_gaussians_backward(self, *a):
+                Pn = a[1].shape[0]
+                shapes = ((Pn, 3), (Pn, C), (Pn, 1), (Pn, 3), (Pn, 6), (Pn, 1, C), (Pn, 3), (Pn, 4))
+                return tuple(torch.full(s, float(k + 1)) for k, s in enumerate(shapes))
+        real = dgr._C
+        dgr._C = Marker()
+        try:
+            ins = dict(means3D=torch.zeros(P, 3), means2D=torch.zeros(P, 3), sh=torch.zeros(P, 1, C), colors_precomp=torch.zeros(P, C),
+                       opacities=torch.zeros(P, 1), scales=torch.zeros(P, 3), rotations=torch.zeros(P, 4), cov3Ds_precomp=torch.zeros(P, 6))
+            for t in ins.values():
+                t.requires_grad_(True)
+            color, radii, inv = dgr.rasterize_gaussians(*ins.values(), rs)
+            (color.sum() + inv.sum()).backward()
+            out["slot_order"] = np.array(list(ins))
+            out["slot_marker"] = np.array([float(t.grad.reshape(-1)[0]) for t in ins.values()])
+        finally:
+            dgr._C = real
+        pts = torch.tensor(np.random.default_rng(0).normal(0, 2.0, (40, 3)).astype(np.float32))
+        vm = torch.tensor(out["h36m_cam_world_view_transform"])
+        rs2 = rs._replace(viewmatrix=vm, projmatrix=torch.tensor(out["h36m_cam_full_proj_transform"]))
+        cen = torch.tensor(out["h36m_cam_camera_center"])
+        pts = cen[None] + pts * torch.tensor([1.0, 1.0, 1.0])
+        out["mark_points"] = pts.numpy()
+        out["mark_visible"] = dgr.GaussianRasterizer(rs2).markVisible(pts).numpy()
+        assert calls[-1][0] == "mark_visible" and 5 < out["mark_visible"].sum() < 35
+    path = os.path.join(HERE, "reference_api.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes;", len(out), "arrays")
+    for k in ("validation_messages", "slot_order", "slot_marker", "settings_fields"):
+        print(k, out[k].tolist())
+
+
+if __name__ == "__main__":
+    main()
