@@ -134,7 +134,10 @@ def timed(fn, steps, warmup, sync):
     return time.perf_counter() - t0, out
 
 
-def roofline_entry(alg_bytes, prof_fwd, wl_name, launches, kernel="k_render_fwd_sparse (forward fill + sparse compositor)"):
+def roofline_entry(alg_bytes, prof_fwd, wl_name, launches, kernel="k_render_fwd_sparse (forward fill + sparse compositor)",
+                   traffic_scale=1.0):
+    """`traffic_scale`: a sharded rank launches the kernel for its share of the workload's views; the PMC figure of the
+    whole-workload launch scales with the views (the kernel writes every plane once)."""
     fwd_ms, fwd_n, fwd_q = prof_fwd
     avg_s = fwd_ms * 1e-3 / fwd_n
     traffic, src = None, None
@@ -143,6 +146,9 @@ def roofline_entry(alg_bytes, prof_fwd, wl_name, launches, kernel="k_render_fwd_
         try:
             traffic = json.load(open(tpath)).get(wl_name, {}).get("fwd_bytes_per_launch")
             src = "profiles/traffic.json (rocprofv3 --pmc passes of this command, collected separately: not measured in this run)"
+            if traffic is not None and traffic_scale != 1.0:
+                traffic *= traffic_scale
+                src += f"; the whole workload's launch x {traffic_scale:.4f} (this rank's share of the views)"
         except Exception:
             traffic = None
     return {"bound": "hbm", "kernel": kernel, "achieved": alg_bytes / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -330,7 +336,8 @@ def run_single(args, torch, dev, wl):
             extras["dropin_error"] = repr(e)[:200]
     # ---- other BASELINE configs, as extras of the same line ------------------------------------------------------
     if wl["dataset"] == "h36m":
-        for name, fn in (("h36m_mixed_1002", extra_mixed), ("panoptic", extra_panoptic), ("stress", extra_stress)):
+        for name, fn in (("h36m_mixed_1002", extra_mixed), ("panoptic", extra_panoptic), ("stress", extra_stress),
+                         ("rank_step_8gpu", extra_rank_step)):
             try:
                 extras[name] = fn(args, torch, dev, sync)
             except Exception as e:
@@ -504,6 +511,61 @@ def extra_stress(args, torch, dev, sync):
     return out
 
 
+def extra_rank_step(args, torch, dev, sync):
+    """What ONE rank of the 8-GPU run (BASELINE configs[3]) does per step, measured on this one GPU: forward + backward of
+    its 4 of the 31 Panoptic views into its all_gather shard, the RCCL all_gather_into_tensor (a communicator of ONE rank:
+    the collective's launch and local copy are in, the xGMI hop is not), sks_mean_views over the gathered rank-major rows.
+    predicted_8gpu_speedup = this GPU's 31-view step / that: what `bench.py --gpus 8` should report as strong-scaling
+    speed-up if the exchange over xGMI costs what it costs here."""
+    import torch.distributed as dist
+    from skelsplat_amd import rasterizer as R
+    wl = WORKLOADS["panoptic"]
+    world, V = 8, wl["V"]
+    scene, gm, params = make_scene(torch, wl, dev)
+    W, H, P, C = scene.W, scene.H, scene.n_points, scene.n_joints
+    vmax = (V + world - 1) // world
+    local = [v for v in range(V) if v % world == 0]                      # rank 0 of 8: views 0, 8, 16, 24
+    own = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 2000))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        own = True
+    try:
+        views = R.ViewBatch.from_cameras([scene.cameras[v] for v in local])
+        dL = torch.randn((len(local), C, H, W), device=dev)
+        ws = R.Workspace()
+        shard = torch.zeros((vmax, P, 3), device=dev)
+        allg = torch.zeros((world * vmax, P, 3), device=dev)
+        mean_out = torch.empty((P, 3), device=dev)
+
+        def rank_step():
+            color, inv, radii, st = R.forward_views(views, *params, None, workspace=ws)
+            R.backward_views(st, *params, None, dL, workspace=ws, out_means3D=shard[:len(local)])
+            dist.all_gather_into_tensor(allg[:vmax], shard)               # (world 1: this rank's rows; the others stay zero)
+            return R.mean_views(allg, V, world, out=mean_out)
+
+        def no_exchange():
+            color, inv, radii, st = R.forward_views(views, *params, None, workspace=ws)
+            return R.backward_views(st, *params, None, dL, workspace=ws, out_means3D=shard[:len(local)])
+        n = max(20, args.steps // 2)
+        dt, _ = timed(rank_step, n, 10, sync)
+        dt0, _ = timed(no_exchange, n, 10, sync)
+        full = ApiStep(R.ViewBatch.from_cameras(scene.cameras), params, torch.randn((V, C, H, W), device=dev))
+        nf = max(10, args.steps // 10)
+        dtf, _ = timed(full, nf, 3, sync)
+        out = {"rank_step_4views_panoptic_ms": 1e3 * dt / n, "rank_step_without_exchange_ms": 1e3 * dt0 / n,
+               "one_gpu_31views_ms": 1e3 * dtf / nf, "predicted_8gpu_speedup": (dtf / nf) / (dt / n),
+               "ideal_speedup": V / vmax, "target": 6.0,
+               "note": "rank 0 of 8: 4 views fwd+bwd + all_gather_into_tensor (RCCL, 1-rank communicator) + sks_mean_views"}
+        # the loop's own sharded steps the same way (MultiViewLoop with the exchange branch on the 1-rank communicator
+        # cannot emulate 8 ranks' shard layout; the API step above is what `value` of the --gpus N line measures)
+        return out
+    finally:
+        if own:
+            dist.destroy_process_group()
+
+
 # ------------------------------------------------------------------------------------------------------------
 # N > 1: BASELINE configs[3], the same views split over the ranks (strong scaling)
 # ------------------------------------------------------------------------------------------------------------
@@ -560,6 +622,8 @@ def run_sharded(args, torch, dist, dev, wl, world, rank):
     del step, dL
     ms = 1e3 * dt / args.steps
     vmax = (V + world - 1) // world
+    backend = dist.get_backend()
+    coll = "RCCL over xGMI" if backend == "nccl" else f"{backend}: single-device test mode, timings mean nothing"
     strong = {"ideal_speedup": V / vmax,
               "api_step": {"one_gpu_ms_per_step": one_gpu_ms, "ms_per_step": ms, "speedup": one_gpu_ms / ms}}
     res = {
@@ -567,13 +631,19 @@ def run_sharded(args, torch, dist, dev, wl, world, rank):
         "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": wl["name"], "views_total": V, "views_on_rank0": len(local), "P": P, "C": C, "W": W, "H": H,
-                   "parallelism": f"views sharded v % {world} over {world} ranks; one all_gather_into_tensor (RCCL) of the "
+                   "parallelism": f"views sharded v % {world} over {world} ranks; one all_gather_into_tensor ({coll}) of the "
                                   f"({vmax},P,3) joint gradients per step",
                    "path": "C ABI sks_forward + sks_backward, eager launches"},
+        # the SAME 31-view step on one GPU alone, measured in this run (all ranks side by side, no communication): the
+        # reference point for this line's `value` (the N = 1 line of bench.py times a different workload, BASELINE configs[1])
+        "one_gpu_same_workload_views_per_s": V * n_ref / dt_full,
+        "one_gpu_same_workload_ms_per_step": one_gpu_ms,
+        "speedup_vs_one_gpu_same_workload": one_gpu_ms / ms,
         "weak_scaling_views_per_s": world * V * n_ref / dt_full,
     }
     if pf and pf[1]:
-        res["roofline"] = roofline_entry(4.0 * H * W * (C + 1) * len(local), pf, "-", args.steps)
+        res["roofline"] = roofline_entry(4.0 * H * W * (C + 1) * len(local), pf, wl["name"], args.steps,
+                                         traffic_scale=len(local) / V)
         res["roofline"]["note"] = f"rank 0's launch: its {len(local)} local views"
     if not args.no_extras:
         # (C, D) the loop's own step -- render + masked-L2 + backward + [all_gather] + Adam (train.py:130-222): dense and
@@ -696,6 +766,11 @@ def main():
     wl = WORKLOADS[args.workload or ("panoptic" if use_dist else "h36m")]
     if use_dist:
         res = run_sharded(args, torch, dist, dev, wl, world, rank)
+        if rank == 0 and not args.no_cpu_baseline:      # (the other ranks wait in destroy_process_group)
+            from skelsplat_amd.scene import SyntheticScene
+            sc = SyntheticScene(wl["dataset"], n_views=wl["V"], seed=0)
+            _, _, prm = make_scene(torch, wl, dev)
+            res["cpu_baseline"] = cpu_baseline(sc, prm, n_views=2)
     else:
         res, scene, params = run_single(args, torch, dev, wl)
         if not args.no_cpu_baseline:

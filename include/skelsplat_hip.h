@@ -70,7 +70,8 @@ int sks_scratch_bytes(int V, int P, int C, int W, int H, size_t bin_capacity,
 /* Replaces _C.rasterize_gaussians (DGR/rasterize_points.cu:35-124 -> rasterizer_impl.cu:198-341).
  * features: (P,C) -- the reference reads them from `sh` with M == 1.
  * Outputs: out_color (V,C,H,W), out_invdepth (V,1,H,W), radii (V,P); every element is written
- * (no pre-zeroing needed).  Optional debug outputs final_T (V,H,W) / n_contrib (V,H,W) reproduce the
+ * (no pre-zeroing needed).  out_color / out_invdepth must be 16-byte aligned (refused otherwise); 128-byte aligned
+ * buffers -- every torch allocation is -- take the fastest fill (whole cache lines per pass).  Optional debug outputs final_T (V,H,W) / n_contrib (V,H,W) reproduce the
  * reference's ImageState (rasterizer_impl.h:52-60) for parity tests; pass NULL on the fast path.
  * num_rendered_dev (V ints, may be NULL): number of (Gaussian,tile) pairs, written on the binned path. */
 int sks_forward(int V, int P, int C, int W, int H,

@@ -469,7 +469,8 @@ __global__ __launch_bounds__(256) void k_heatmap_factors(int J, int W, int H, co
 // view, from the separable factors alone (gt = (row[y] * col[x] - cmin) / den, the very expression k_heatmaps stores).
 // Outside the impulse response's 4-sigma support the factors are exactly zero, and then so is cmin and the pixel: only
 // the rows with a non-zero factor are walked (a few dozen of a thousand).  grid (row bands of 16, J, V); the counts are
-// integers (exact in any order), the sums are accumulated in fp64 like k_heatmaps' own.
+// integers (exact in any order), the sums are accumulated in fp64 like k_heatmaps' own and combined across blocks in
+// fixed point (order-independent: reproducible bit for bit).
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_heatmap_totals(int J, int Ws, int Hs, HmTan sz, const float* __restrict__ row,
                                                          const float* __restrict__ col, const float* __restrict__ cmin,
@@ -504,9 +505,22 @@ __global__ __launch_bounds__(256) void k_heatmap_totals(int J, int Ws, int Hs, H
     if ((threadIdx.x & 63) == 0) { s_t[0][threadIdx.x >> 6] = S; s_t[1][threadIdx.x >> 6] = N; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        atomicAdd(&totals[2 * v], (s_t[0][0] + s_t[0][1]) + (s_t[0][2] + s_t[0][3]));
+        // The blocks of a view finish in any order.  Counts are integers (a double sum of them is exact in any order); the
+        // sum of squares is combined in 2^-32 FIXED POINT with integer atomics -- integer addition is associative, so the
+        // total is bit-reproducible run to run (it feeds the reported loss and early stopping) -- and converted back by
+        // k_heatmap_totals_finish.  A view's sum is < J * H * W < 2^27, a block's rounding 2^-33.
+        const double Sb = (s_t[0][0] + s_t[0][1]) + (s_t[0][2] + s_t[0][3]);
+        atomicAdd(reinterpret_cast<unsigned long long*>(&totals[2 * v]), (unsigned long long)llrint(Sb * 4294967296.0));
         atomicAdd(&totals[2 * v + 1], (s_t[1][0] + s_t[1][1]) + (s_t[1][2] + s_t[1][3]));
     }
+}
+
+__global__ void k_heatmap_totals_finish(int V, double* __restrict__ totals)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    const unsigned long long fx = *reinterpret_cast<const unsigned long long*>(&totals[2 * v]);
+    totals[2 * v] = (double)fx * (1.0 / 4294967296.0);
 }
 
 }  // namespace
@@ -616,6 +630,7 @@ int sks_heatmap_totals(int V, int J, int W, int H, const float* row, const float
     HIP_TRY2(hipMemsetAsync(gt_totals, 0, (size_t)V * 2 * sizeof(double), (hipStream_t)stream));
     hipLaunchKernelGGL(k_heatmap_totals, dim3((H + 15) / 16, J, V), dim3(256), 0, (hipStream_t)stream, J, W, H, sz, row, col, cmin,
                        den, gt_totals);
+    hipLaunchKernelGGL(k_heatmap_totals_finish, dim3((V + 63) / 64), dim3(64), 0, (hipStream_t)stream, V, gt_totals);
     HIP_TRY2(hipGetLastError());
     return 0;
 }

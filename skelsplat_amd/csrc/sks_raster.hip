@@ -69,8 +69,11 @@ inline bool fill_half_mode(const FwdArgs& a) { return a.W % 4 == 2 && a.H % 2 ==
 inline void fill_geometry(const FwdArgs& a, bool have_cover, bool binned, int& fsplit, int& pb)
 {
     const int ppt = (a.W % 4 == 0 || fill_half_mode(a)) ? 4 : 1;
-    // (+31: a band that does not start on a 128-byte line begins with a short pass, fwd_fill_role's `shift`)
-    const int lead = ((long long)a.H * a.W % 32 == 0 && TILE * a.W % 32 == 0) ? 0 : 31;
+    // (+31: a band that does not start on a 128-byte line begins with a short pass, fwd_fill_role's `shift`, which the
+    // kernel derives from the ADDRESS: the plane and band strides must be whole lines and so must the two base pointers --
+    // torch allocations are, a direct C-ABI caller's 16-byte aligned sub-buffer need not be)
+    const bool lines = (((uintptr_t)a.out_color | (uintptr_t)a.out_invdepth) & 127u) == 0;
+    const int lead = (lines && (long long)a.H * a.W % 32 == 0 && TILE * a.W % 32 == 0) ? 0 : 31;
     const int passes = (TILE * a.W + lead + 256 * ppt - 1) / (256 * ppt);
     const int tune = (int)((a.flags >> 8) & 0xff);                    // tuning knob: passes (or rows) per fill block
     const int chunks = (a.W + 1023) / 1024;
@@ -221,6 +224,8 @@ int sks_forward(int V, int P, int C, int W, int H, const float* viewmatrix, cons
     if (int rc = check_common(V, P, C, W, H)) return rc;
     hipStream_t st = (hipStream_t)stream;
     if (!out_color || !out_invdepth) return fail(-2, "out_color / out_invdepth must be provided");
+    if (((uintptr_t)out_color | (uintptr_t)out_invdepth) & 15u)
+        return fail(-2, "out_color / out_invdepth must be 16-byte aligned (the planes are written with 16-byte stores)");
     const size_t HW = (size_t)H * W;
     if (P == 0) {  // rasterize_points.cu:88: nothing rendered, outputs stay zero
         HIP_TRY(hipMemsetAsync(out_color, 0, (size_t)V * C * HW * 4, st));

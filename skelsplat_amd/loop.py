@@ -276,6 +276,13 @@ class MultiViewLoop:
             if dropout and poses_2d is not None:
                 from .heatmaps import draw_dropout
                 drop = draw_dropout(self.V, self.P)
+                if self.exchange and self.world > 1:
+                    # the reference makes ONE draw shared by all cameras (general_utils.py:267-283); the ranks' default
+                    # generators are not synchronised, so rank 0's draw is the scene's
+                    buf = drop.to(device=self.device, dtype=torch.uint8)
+                    dist.broadcast(buf, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0,
+                                   group=self.group)
+                    drop = buf.to(device="cpu", dtype=torch.bool)
             for grp in self.size_groups:
                 slots, vb, gt, stats, idx = grp
                 ids = [self.local_ids[k] for k in slots]

@@ -168,8 +168,12 @@ def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotati
                   bin_capacity=None, want_aux=False, tune_flags=0, check_capacity="auto", workspace=None):
     """Raw batched forward.  Returns (color (V,C,H,W), invdepth (V,1,H,W), radii (V,P) int32, state[, final_T, n_contrib]).
     `workspace`: a Workspace whose tensors receive the outputs (see there).  `check_capacity` (binned path, P > 256):
-    True = read the pair count back every call (one host sync, like the reference), "lazy" = never synchronise, detect an
-    overflowed arena at the next call, "auto" = True for the first call of a shape, lazy afterwards, False = no check."""
+    True = read the pair count back every call (one host sync, like the reference: rasterizer_impl.cu:283-288) and redo the
+    forward with a larger arena when it was too small -- never a wrong image; this is what the autograd / drop-in path
+    uses; "lazy" = never synchronise, detect an overflowed arena at the NEXT call of the shape (which raises: the image
+    before it missed entries; the arena has been grown for the calls after it); "auto" (the default of this raw entry
+    point, for loops that own their error handling) = True for the first call of a shape, which also sizes the arena with
+    50 % headroom over that call's count, lazy afterwards; False = no check."""
     lib = _lib.load()
     key = None
     if workspace is not None and not want_aux:
@@ -188,7 +192,13 @@ def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotati
                     return result
                 del workspace._plans["fwd"]     # the binning arena overflowed: the validating path below grows it and redoes
             else:
-                _lazy_probe(ckey, nr, pcap, args[0])
+                try:
+                    _lazy_probe(ckey, nr, pcap, args[0])
+                except RuntimeError:
+                    # the recorded call holds the overflowed arena: drop it, so that the next call takes the validating path
+                    # and allocates the grown one (`_BIN_CAP_HINT`)
+                    del workspace._plans["fwd"]
+                    raise
                 return result
     if views.mixed:
         raise RuntimeError("the dense forward writes one (V,C,H,W) tensor: all views of the batch must share the image size")
@@ -218,6 +228,7 @@ def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotati
     flags = (_lib.SKS_ANTIALIASING if antialiasing else 0) | (_lib.SKS_CLAMP01 if clamp01 else 0) | \
             (_lib.SKS_DEBUG_SYNC if debug else 0) | (_lib.SKS_FORCE_BINNED if force_binned else 0) | int(tune_flags) | _ENV_TUNE
     binned = force_binned or P > _lib.SKS_SMALL_P
+    bin_capacity_given = bin_capacity
     if binned and bin_capacity is None:
         bin_capacity = _BIN_CAP_HINT.get((means3D.device.index, views.V, P, C, views.W, views.H), max(4096, 16 * P))
     cap = int(bin_capacity or 0)
@@ -256,6 +267,9 @@ def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotati
         elif not lazy:
             need = int(nrend[:V].max().item())
             _BIN_CAP_SEEN.add(cap_key)
+            if check_capacity == "auto" and need <= cap and bin_capacity_given is None:
+                # later calls of the shape go unchecked until the call after them: leave them room to grow
+                _BIN_CAP_HINT[cap_key] = max(cap, int(need * 1.5) + 1024)
             if need > cap:
                 _BIN_CAP_HINT[cap_key] = int(need * 1.25) + 1024
                 return forward_views(views, means3D, features, opacities, scales, rotations, cov3D_precomp, scale_modifier,
@@ -473,8 +487,10 @@ class _RasterizeViews(torch.autograd.Function):
                 scale_modifier, antialiasing, clamp01, debug, bg, single):
         P = means3D.shape[0] if means3D.dim() == 2 else 0
         feats, src = _features_of(sh, colors_precomp, P)
+        # check_capacity=True: like the reference, which reads the pair count back on every forward, the autograd path never
+        # returns an image (and then gradients) with dropped entries -- a too-small arena is grown and the forward redone
         color, invdepth, radii, st = forward_views(views, means3D, feats, opacities, scales, rotations, cov3Ds_precomp,
-                                                   scale_modifier, antialiasing, clamp01, debug)
+                                                   scale_modifier, antialiasing, clamp01, debug, check_capacity=True)
         ctx.st, ctx.src, ctx.bg, ctx.single = st, src, bg, single
         ctx.save_for_backward(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp)
         ctx.mark_non_differentiable(radii)

@@ -186,7 +186,14 @@ def load_config(name, **overrides):
     import yaml
 
     def wrap(x):
-        return Cfg({k: wrap(v) for k, v in x.items()}) if isinstance(x, dict) else x
+        if isinstance(x, dict):
+            return Cfg({k: wrap(v) for k, v in x.items()})
+        if isinstance(x, str):          # PyYAML (YAML 1.1) reads `1e-5` as a string; OmegaConf, like YAML 1.2, as a float
+            try:
+                return float(x)
+            except ValueError:
+                return x
+        return x
 
     cfg = wrap(yaml.safe_load(open(os.path.join(REF, "configs", name + ".yaml"))))
     for k, v in overrides.items():

@@ -1,0 +1,195 @@
+"""Generates tests/golden/reference_loop.npz: trajectories of the REFERENCE's own training loop.
+
+Run in the build container:  python tests/golden/make_golden_loop.py [case ...]
+
+`train.training()` of /root/reference/train.py:56-254 is executed as it is -- the per-iteration round-robin view index,
+the V-slot gradient buffer, the last-view overwrite of the scaling / rotation / opacity gradients (Q7), the
+accumulation-step mean (Q8), the per-iteration learning-rate schedule (Q9), torch.optim.Adam(eps=1e-15) -- together with
+the reference's GaussianModel (create_from_pcd, training_setup, update_learning_rate, activations), Camera,
+generate_heatmaps, render_h36m / render_panoptic, GaussianRasterizer / _RasterizeGaussians, l2_loss_gaussian and
+limb_3d_consistency_loss, with the option values of the reference's own configs/h36m.yaml / configs/panoptic.yaml.
+
+What is NOT the reference (tests/golden/_ref_env.py): the compiled `_C` (here oracle/sks_oracle.c behind the same
+signatures), the device strings (CPU), cupy's gaussian_filter (scipy's), and two host-side pieces that need files and
+packages this image lacks:
+  * scene.dataset_readers.DataLoader (walks a licensed dataset tree) -> one synthetic scene with the same tuple layout
+    (pose_3d, pose_3d_gt, poses_2d, cameras, scene_name), cameras as the reference's CameraInfo records;
+  * scene.Scene (writes a ply through plyfile, copies it, dumps cameras.json) -> `Scene` below: the same calls into the
+    reference's getNerfppNorm, cameraList_from_camInfos (-> loadCam -> Camera) and GaussianModel.create_from_pcd that
+    scene/__init__.py:85-99 makes, without the file traffic.
+Recorded per case: the inputs, the parameters after every optimiser step, every iteration's loss and view index.
+Iteration counts of the full-size cases are what 64 GB of host memory allow: train.py:161,175 (`create_graph=True`, then
+`accumulated_grads[idx] = grads_xyz`) chains every iteration's autograd graph, dense saved tensors included, into the
+V-slot buffer, which is never detached -- ~150 MB per iteration at 1000x1000, ~350 MB at 1920x1080 x 19 channels.
+"""
+import logging
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import _ref_env as env   # noqa: E402
+
+CASES = {
+    # name: config file, dataset key of the synthetic scene, V, W, H, iterations, overrides
+    "h36m_small": dict(cfg="h36m", dataset="h36m", V=4, W=64, H=48, iters=40, fx=1145.0 * 0.064 * 1.5, ring=2500.0),
+    "h36m_mid": dict(cfg="h36m", dataset="h36m", V=4, W=112, H=96, iters=500, fx=1145.0 * 0.112 * 1.5, ring=2500.0),
+    "h36m_full": dict(cfg="h36m", dataset="h36m", V=4, W=1000, H=1000, iters=100),
+    "h36m_mixed": dict(cfg="h36m", dataset="h36m", V=4, W=1000, H=1000, iters=40, widths=[1002, 1000, 1000, 1002]),
+    "panoptic_full": dict(cfg="panoptic", dataset="panoptic", V=31, W=1920, H=1080, iters=62,
+                          over={"dataset.nviews": 31, "training.accumulation_steps": 31}),
+}
+
+
+def run_case(name, spec, out):
+    import train as ref_train                      # /root/reference/train.py
+    from scene.dataset_readers import CameraInfo, getNerfppNorm
+    from utils.camera_utils import cameraList_from_camInfos
+    from utils.graphics_utils import BasicPointCloud, focal2fov
+    from utils import losses
+    from skelsplat_amd.scene import SyntheticScene, Camera as OurCamera     # inputs only (stored in the fixture)
+    assert ref_train.__file__.startswith(env.REF)
+    over = {"debug.save_images": False, "debug.save_iterations": [], "optimization.iterations": spec["iters"]}
+    over.update(spec.get("over", {}))
+    cfg = env.load_config(spec["cfg"], **over)
+    sc = SyntheticScene(spec["dataset"], n_views=spec["V"], seed=0, W=spec["W"], H=spec["H"], ring=spec.get("ring"),
+                        fx=spec.get("fx"))
+    cams = sc.cameras
+    if "widths" in spec:        # H36M's sensor mix (dataset_readers.py:68-80): same cameras, 1002-wide sensors for some
+        cams = []
+        for c, w in zip(sc.cameras, spec["widths"]):
+            K = c.K.copy()
+            K[0, 2] += (w - spec["W"]) / 2
+            cams.append(OurCamera(c.uid, c.R, c.T, K, w, spec["H"]))
+    infos = [CameraInfo(uid=i, R=c.R, T=c.T, FovY=focal2fov(c.K[1, 1], c.image_height), FovX=focal2fov(c.K[0, 0], c.image_width),
+                        K=c.K, depth_params=None, image_path="", image_name="", depth_path="", width=c.image_width,
+                        height=c.image_height, heatmap=None) for i, c in enumerate(cams)]
+    n_joints = sc.n_joints
+    rec = dict(steps=[], losses=[], l2=[], views=[], heat_sum=None)
+
+    class Scene:
+        """scene/__init__.py:25-99 without the ply / json files (see the module docstring)."""
+
+        def __init__(self, dataset, model, gaussians, initial_guess_3d, cameras, scene_name, output_dir):
+            self.gaussians, self.scene_name = gaussians, scene_name
+            self.scene_type = dataset.data_root.split("/")[-1]
+            self.cameras_extent = getNerfppNorm(cameras)["radius"]
+            self.train_cameras = {1.0: cameraList_from_camInfos(cameras, 1.0, model, False)}
+            pcd = BasicPointCloud(points=np.asarray(initial_guess_3d, np.float32).reshape(-1, 3), colors=None, normals=None)
+            gaussians.create_from_pcd(pcd, cameras, self.cameras_extent, model.opacity_on, model.scaling, n_joints,
+                                      model.scaling_modifier, self.scene_type)
+            rec["spatial_lr_scale"] = float(self.cameras_extent)
+            rec["gm"] = gaussians
+
+        def getTrainCameras(self, scale=1.0):
+            return self.train_cameras[scale]
+
+        def save_h36m(self, iteration, scene_name):
+            rec.setdefault("saved", []).append(iteration)
+
+    real_step = torch.optim.Adam.step
+
+    def step(self, *a, **k):
+        r = real_step(self, *a, **k)
+        gm = rec["gm"]
+        if self is gm.optimizer:
+            rec["steps"].append([p.detach().clone().numpy() for p in (gm._xyz, gm._scaling, gm._rotation, gm._opacity)])
+        return r
+
+    real_l2 = losses["l2_gaussian"]
+
+    def l2(image, gt, *a, **k):
+        r = real_l2(image, gt, *a, **k)
+        rec["l2"].append(float(r[0]))
+        return r
+
+    real_heat = ref_train.generate_heatmaps
+
+    def heat(*a, **k):
+        hm = real_heat(*a, **k)
+        rec["heatmaps"] = hm
+        return hm
+
+    real_render = dict(ref_train.render_functions)
+
+    def make_render(fn):
+        def render(cam, *a, **k):
+            rec["views"].append(int(cam.uid))
+            return fn(cam, *a, **k)
+        return render
+
+    p2d = torch.tensor(sc.poses_2d, dtype=torch.float32)
+    loader = [(0, (sc.pose_3d_init, sc.pose_3d_gt, p2d, infos, "S1_Directions_0"))]
+    ref_train.Scene = Scene
+    ref_train.generate_heatmaps = heat
+    torch.optim.Adam.step = step
+    losses["l2_gaussian"] = l2
+    for k, fn in real_render.items():
+        ref_train.render_functions[k] = make_render(fn)
+    t0 = time.time()
+    try:
+        with env.no_gpu(), tempfile.TemporaryDirectory() as tmp:
+            ref_train.training(cfg.dataset, cfg.model, cfg.optimization, cfg.pipeline, cfg.debug, cfg.training, loader, tmp,
+                               logging.getLogger("ref"))
+    finally:
+        torch.optim.Adam.step = real_step
+        losses["l2_gaussian"] = real_l2
+        ref_train.render_functions.update(real_render)
+        ref_train.generate_heatmaps = real_heat
+    steps = rec["steps"]
+    acc = cfg.training.accumulation_steps
+    assert len(steps) == spec["iters"] // acc and len(rec["l2"]) == spec["iters"], (len(steps), len(rec["l2"]))
+    assert rec["views"] == [i % spec["V"] for i in range(spec["iters"])]            # round-robin, train.py:136-138
+    pre = name + "_"
+    hm = rec["heatmaps"]
+    planes = [hm[str(v)].numpy() for v in range(spec["V"])]
+    o = cfg.optimization
+    out.update({
+        pre + "dataset": np.array(spec["dataset"]), pre + "iterations": np.int64(spec["iters"]),
+        pre + "accumulation_steps": np.int64(acc), pre + "lambda_consistency": np.float64(cfg.training.lambda_consistency),
+        pre + "pose_3d_init": np.asarray(sc.pose_3d_init), pre + "pose_3d_gt": np.asarray(sc.pose_3d_gt),
+        pre + "poses_2d": np.asarray(sc.poses_2d), pre + "cam_R": np.stack([c.R for c in cams]),
+        pre + "cam_T": np.stack([c.T for c in cams]), pre + "cam_K": np.stack([c.K for c in cams]),
+        pre + "cam_WH": np.array([[c.image_width, c.image_height] for c in cams]),
+        pre + "spatial_lr_scale": np.float64(rec["spatial_lr_scale"]),
+        pre + "model": np.array([cfg.model.scaling, cfg.model.scaling_modifier, float(cfg.model.opacity_on)]),
+        pre + "opt": np.array([o.position_lr_init, o.position_lr_final, o.position_lr_delay_mult, o.position_lr_max_steps,
+                               o.feature_lr, o.opacity_lr, o.scaling_lr, o.rotation_lr]),
+        pre + "l2": np.array(rec["l2"]),
+        pre + "xyz": np.stack([s[0] for s in steps]), pre + "scaling": np.stack([s[1] for s in steps]),
+        pre + "rotation": np.stack([s[2] for s in steps]), pre + "opacity": np.stack([s[3] for s in steps]),
+        # the pseudo-GT the loop ran on, in summary (per-plane sum, sum of squares, count of positive pixels, maximum) ...
+        pre + "heat_stats": np.array([[[p[j].sum(dtype=np.float64), (p[j].astype(np.float64) ** 2).sum(), (p[j] > 0).sum(), p[j].max()]
+                                       for j in range(p.shape[0])] for p in planes]),
+    })
+    if spec["W"] * spec["H"] <= 64 * 64:
+        out[pre + "heatmaps"] = np.stack(planes).astype(np.float32)      # ... and in full where they are small
+    gt = np.asarray(sc.pose_3d_gt)
+    e0 = np.linalg.norm(np.asarray(sc.pose_3d_init) - gt, axis=1).mean()
+    e1 = np.linalg.norm(steps[-1][0] - gt, axis=1).mean()
+    print(f"{name}: {spec['iters']} iterations, {len(steps)} steps in {time.time() - t0:.1f} s; MPJPE {e0:.3f} -> {e1:.3f} mm; "
+          f"l2 {rec['l2'][0]:.3e} -> {rec['l2'][-1]:.3e}")
+
+
+def main():
+    names = sys.argv[1:] or list(CASES)
+    calls = []
+    env.install(calls)
+    path = os.path.join(HERE, "reference_loop.npz")
+    out = dict(np.load(path)) if os.path.exists(path) and sys.argv[1:] else {}
+    for n in names:
+        for k in [k for k in out if k.startswith(n + "_")]:
+            del out[k]
+        run_case(n, CASES[n], out)
+        del calls[:]
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    main()

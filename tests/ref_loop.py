@@ -28,7 +28,10 @@ def view_grads_ref(gm, cam, gt, W, H, dataset, lambda_consistency):
     return loss.detach(), grads
 
 
-def run_reference_loop(gm, cameras, heatmaps, W, H, dataset, iterations, accumulation_steps=4, lambda_consistency=1e-5):
+def run_reference_loop(gm, cameras, heatmaps, W, H, dataset, iterations, accumulation_steps=4, lambda_consistency=1e-5,
+                       on_step=None):
+    """`on_step(gm)`: called after every optimiser step.  (This restatement is itself held to the reference's own
+    train.training(), run in the build container: tests/golden/reference_loop.npz, tests/test_loop_golden.py.)"""
     V = len(cameras)
     accumulated = torch.zeros((V,) + tuple(gm._xyz.shape))
     cam_idx_counter = 0
@@ -44,4 +47,6 @@ def run_reference_loop(gm, cameras, heatmaps, W, H, dataset, iterations, accumul
             with torch.no_grad():
                 gm.optimizer.step()
                 gm.optimizer.zero_grad(set_to_none=True)
+            if on_step is not None:
+                on_step(gm)
     return gm._xyz.detach().clone()

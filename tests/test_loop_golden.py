@@ -1,0 +1,144 @@
+"""The multi-view loop held to trajectories of the REFERENCE's own train.training().
+
+tests/golden/reference_loop.npz (tests/golden/make_golden_loop.py) holds, for a synthetic scene per case, the parameters
+after every optimiser step of /root/reference/train.py:130-222 run unmodified in the build container -- round-robin view
+index, V-slot buffer, last-view overwrite of the scaling / rotation / opacity gradients (Q7), per-iteration LR (Q9),
+Adam(eps=1e-15) -- over the reference's own GaussianModel, Camera, generate_heatmaps, render_*, losses, with
+oracle/sks_oracle.c standing in for the CUDA module.  Held to it here:
+  * CPU: tests/ref_loop.py (the restated loop the other loop tests compare with) on the small case;
+  * GPU: MultiViewLoop on the production path (HIP heat-maps, sparse fused step, hipGraphs) at 64x48, 112x96 (a whole
+    500-iteration scene), BASELINE config 2 at 1000x1000 (100 iterations = 25 optimiser steps) and with H36M's 1002-wide
+    sensor mix (40), and Panoptic's 31 views at 1920x1080 (two accumulation groups).  (The full-size runs are as long as
+    the build container's memory allows: the reference's loop keeps every iteration's autograd graph alive --
+    `accumulated_grads[idx] = grads_xyz` with create_graph=True, train.py:161,175 -- ~150 MB per iteration at 1000x1000.)
+Bars: joints within 0.5 mm and MPJPE within 0.5 mm of the reference's (north_star), and within 2 % of the distance the
+joints moved; log-scales to 1e-3 of their change + 1e-4.  Rotations are not compared: with the initial isotropic scales
+(gaussian_model.py:170-172) a quaternion does not change its Gaussian, its gradient is rounding noise, and Adam's
+1/sqrt(v) turns noise into +-lr steps of arbitrary sign -- in the reference's own run as much as here.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_loop.npz")
+
+
+class _Opt:
+    pass
+
+
+def _setup(G, case, dev):
+    """Our scene objects from the fixture's inputs: cameras, a GaussianModel after training_setup with the reference's
+    configs/*.yaml option values, poses_2d."""
+    from skelsplat_amd.scene import GaussianModel, Camera, cameras_extent
+    pre = case + "_"
+    ds = str(G[pre + "dataset"])
+    cams = [Camera(i, R, T, K, int(wh[0]), int(wh[1]), device=dev)
+            for i, (R, T, K, wh) in enumerate(zip(G[pre + "cam_R"], G[pre + "cam_T"], G[pre + "cam_K"], G[pre + "cam_WH"]))]
+    extent = cameras_extent(cams)
+    assert abs(extent - float(G[pre + "spatial_lr_scale"])) <= 1e-9 * extent        # getNerfppNorm, dataset_readers.py:482-503
+    scaling, smod, op_on = G[pre + "model"]
+    J = G[pre + "pose_3d_init"].shape[0]
+    gm = GaussianModel().create_from_points(G[pre + "pose_3d_init"], extent, J, opacity_on=bool(op_on), scaling=float(scaling),
+                                            scaling_modifier=float(smod), scene_type=ds, device=dev)
+    o = _Opt()
+    (o.position_lr_init, o.position_lr_final, o.position_lr_delay_mult, o.position_lr_max_steps, o.feature_lr, o.opacity_lr,
+     o.scaling_lr, o.rotation_lr) = [float(x) for x in G[pre + "opt"]]
+    o.position_lr_max_steps = int(o.position_lr_max_steps)
+    gm.training_setup(o)
+    return gm, cams, ds, torch.tensor(G[pre + "poses_2d"])
+
+
+def _compare(G, case, step, gm, tag=""):
+    pre = case + "_"
+    init = torch.tensor(G[pre + "pose_3d_init"]).float()
+    want = torch.tensor(G[pre + "xyz"][step])
+    got = gm._xyz.detach().cpu()
+    gt = torch.tensor(G[pre + "pose_3d_gt"]).float()
+    moved = (want - init).norm(dim=1).mean().item()
+    diff = (got - want).norm(dim=1).max().item()
+    e_got, e_want = (got - gt).norm(dim=1).mean().item(), (want - gt).norm(dim=1).mean().item()
+    print(f"{case}{tag} step {step + 1}: moved {moved:.3f} mm, max joint distance to the reference {diff:.5f} mm, "
+          f"MPJPE {e_got:.4f} vs {e_want:.4f} mm")
+    assert moved > 0.05, "vacuous: the reference barely moved"
+    assert diff < 0.5 and abs(e_got - e_want) < 0.5, (diff, e_got, e_want)
+    assert diff < 0.02 * max(moved, 1.0), (diff, moved)
+    s0 = float(G[pre + "model"][0])
+    ws, gs = G[pre + "scaling"][step], gm._scaling.detach().cpu().numpy()
+    tol = 1e-4 + 1e-3 * np.abs(ws - s0).max()
+    assert np.abs(gs - ws).max() <= tol, (np.abs(gs - ws).max(), tol)
+    wo, go = G[pre + "opacity"][step], gm._opacity.detach().cpu().numpy()
+    assert np.array_equal(np.isinf(wo), np.isinf(go)) and np.allclose(go[~np.isinf(go)], wo[~np.isinf(wo)], rtol=1e-3, atol=1e-4)
+
+
+def test_restated_loop_reproduces_the_reference_loop():
+    """CPU.  tests/ref_loop.py + oracle/torch_ref.py against the reference's own 40 iterations at 64x48, on the
+    reference's own heat-maps, step by step."""
+    from tests.ref_loop import run_reference_loop
+    G = np.load(GOLD)
+    case = "h36m_small"
+    gm, cams, ds, p2d = _setup(G, case, "cpu")
+    hm = torch.tensor(G[case + "_heatmaps"])
+    W, H = [int(x) for x in G[case + "_cam_WH"][0]]
+    k = [0]
+
+    def on_step(g):
+        _compare(G, case, k[0], g)
+        k[0] += 1
+    run_reference_loop(gm, cams, hm, W, H, ds, int(G[case + "_iterations"]), int(G[case + "_accumulation_steps"]),
+                       float(G[case + "_lambda_consistency"]), on_step=on_step)
+    assert k[0] == G[case + "_xyz"].shape[0] == 10
+
+
+def _heatmaps(G, case, gm, cams, p2d, dev):
+    """The pseudo-GT from the product's HIP generator, checked against the summary of what the reference's
+    generate_heatmaps (general_utils.py:175-304, scipy twin of cupy's filter) produced for the same inputs."""
+    from skelsplat_amd.heatmaps import generate_heatmaps
+    sizes = {(c.image_width, c.image_height) for c in cams}
+    if len(sizes) == 1:
+        hm = generate_heatmaps(gm._xyz.detach(), gm.get_scaling.detach(), gm._rotation.detach(), p2d.to(dev), cams)
+        planes = [hm[v] for v in range(len(cams))]
+    else:
+        planes = [generate_heatmaps(gm._xyz.detach(), gm.get_scaling.detach(), gm._rotation.detach(), p2d[v:v + 1].to(dev),
+                                    [cams[v]])[0] for v in range(len(cams))]
+        hm = planes
+    want = G[case + "_heat_stats"]
+    for v in (0, len(cams) - 1):
+        p = planes[v].double()
+        got = torch.stack([p.sum((1, 2)), (p * p).sum((1, 2)), (p > 0).sum((1, 2)).double(), p.amax((1, 2))], 1).cpu().numpy()
+        assert np.allclose(got[:, :2], want[v][:, :2], rtol=2e-4), np.abs(got[:, :2] / want[v][:, :2] - 1).max()
+        assert np.allclose(got[:, 2], want[v][:, 2], rtol=2e-3)          # pixels at the 4-sigma truncation edge
+        assert np.allclose(got[:, 3], want[v][:, 3], rtol=1e-5)
+    return hm
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,use_graph", [("h36m_small", False), ("h36m_small", True), ("h36m_mid", True), ("h36m_full", True),
+                                            ("h36m_mixed", True), ("panoptic_full", False)])
+def test_production_loop_follows_the_reference_trajectory(device, case, use_graph):
+    from skelsplat_amd.loop import MultiViewLoop
+    G = np.load(GOLD)
+    pre = case + "_"
+    gm, cams, ds, p2d = _setup(G, case, device)
+    hm = _heatmaps(G, case, gm, cams, p2d, device)
+    acc, iters = int(G[pre + "accumulation_steps"]), int(G[pre + "iterations"])
+    loop = MultiViewLoop(gm, cams, hm, dataset=ds, accumulation_steps=acc, lambda_consistency=float(G[pre + "lambda_consistency"]),
+                         use_graph=use_graph)
+    assert loop.sparse and loop.device_tail and loop.use_graph == use_graph
+    n_steps = G[pre + "xyz"].shape[0]
+    assert n_steps == iters // acc
+    if not use_graph:      # eager: every optimiser step against the reference's
+        for k in range(n_steps):
+            loop.run((k + 1) * acc)
+            if k < 10 or k == n_steps - 1:
+                _compare(G, case, k, gm)
+    else:                  # hipGraphs (25 groups per graph): after 10 steps (or all, if fewer) and at the end of the scene
+        first = min(10, n_steps)
+        loop.run(first * acc)
+        _compare(G, case, first - 1, gm, " [hipGraph]")
+        if n_steps > first:
+            loop.run(iters)
+            _compare(G, case, n_steps - 1, gm, " [hipGraph]")
+    assert loop.iteration == iters

@@ -917,3 +917,85 @@ def test_mean_views_on_gathered_rows_and_backward_into_a_shard(device):
         assert torch.equal(R.mean_views(buf, V, world), ref["means3D_mean"]), world
     with pytest.raises(ValueError):
         R.backward_views(st, *args, dL, out_means3D=shard[:V, :, :2])
+
+
+@pytest.mark.parametrize("W,H", [(640, 48), (1280, 32), (1000, 32)], ids=lambda v: str(v))
+def test_forward_into_16_byte_aligned_sub_buffers(device, W, H):
+    """A direct C-ABI caller may hand over output planes that are 16-byte but not 128-byte aligned (a slice of its own
+    arena).  The fill derives its first short pass from the address, so the host's pass count must allow for it: W % 64 == 0
+    in linear mode is the case where it used to come out one pass short.  Every element written, identical to the aligned
+    call; a 4-byte aligned pointer is refused."""
+    from skelsplat_amd import _lib
+    c = util.make_case(seed=71, W=W, H=H, n_views=2, scale_log=4.3, fxmul=0.2 * 1000.0 / W, ring=2500.0)
+    views = R.ViewBatch.from_cameras([cam.to(device) for cam in c.cams])
+    args = (t(c.means, device), t(c.feat, device), t(c.opac, device), t(c.scales, device), t(c.quats, device))
+    V, P, C = 2, c.P, c.C
+    lib = _lib.load()
+    gbytes, _, _ = _lib.scratch_bytes(V, P, C, W, H, 0)
+    stream = torch.cuda.current_stream(device).cuda_stream
+    for tune in (0, 1 << 21):
+        want_c, want_i, _, _ = R.forward_views(views, *args, None, tune_flags=tune)
+        for off in (4, 12, 20):         # floats: 16, 48, 80 bytes into a line
+            nc, ni = V * C * H * W, V * H * W
+            bufc = torch.full((nc + 64,), float("nan"), device=device)
+            bufi = torch.full((ni + 64,), float("nan"), device=device)
+            radii = torch.empty((V, P), dtype=torch.int32, device=device)
+            geom = torch.empty(gbytes, dtype=torch.uint8, device=device)
+            call = lambda pc, pi: lib.sks_forward(V, P, C, W, H, views.viewmatrix.data_ptr(), views.projmatrix.data_ptr(),
+                                                  views.tanfovx, views.tanfovy, args[0].data_ptr(), args[1].data_ptr(),
+                                                  args[2].data_ptr(), args[3].data_ptr(), args[4].data_ptr(), None, 1.0, tune,
+                                                  pc, pi, radii.data_ptr(), geom.data_ptr(), None, 0, None, None, None, stream)
+            assert call(bufc.data_ptr() + 4 * off, bufi.data_ptr() + 4 * (off + 4)) == 0
+            torch.cuda.synchronize()
+            assert torch.equal(bufc[off:off + nc].view_as(want_c), want_c), (hex(tune), off)
+            assert torch.equal(bufi[off + 4:off + 4 + ni].view_as(want_i), want_i), (hex(tune), off)
+            assert torch.isnan(bufc[:off]).all() and torch.isnan(bufc[off + nc:]).all()      # nothing outside the planes
+            assert torch.isnan(bufi[:off + 4]).all() and torch.isnan(bufi[off + 4 + ni:]).all()
+        assert call(bufc.data_ptr() + 4, bufi.data_ptr()) == -2 and b"16-byte" in lib.sks_last_error()
+
+
+def test_workspace_replay_recovers_from_a_lazy_overflow(device):
+    """A Workspace replays its recorded call; when the lazy probe finds that the recorded arena was too small the call
+    raises ONCE, the recorded plan is dropped, and the next call allocates the grown arena and is right (it used to keep
+    replaying the undersized arena: every other call raised, the ones in between returned images with dropped entries)."""
+    c = util.make_case(seed=0, W=184, H=104, scale_log=4.0, n_views=1)     # (a shape no other test uses: hints are per shape)
+    views = R.ViewBatch.from_cameras([cam.to(device) for cam in c.cams])
+    args = (t(c.means, device), t(c.feat, device), t(c.opac, device), t(c.scales, device), t(c.quats, device), None)
+    o = util.oracle_forward(c, 0)
+    assert o["R"] > 16
+    key = (device.index, 1, c.P, c.C, c.W, c.H)
+    R._BIN_CAP_HINT[key] = 16          # as if an earlier, smaller scene of this shape had sized the arena
+    R._BIN_CAP_SEEN.add(key)           # "auto" is lazy from now on
+    ws = R.Workspace()
+    R.forward_views(views, *args, force_binned=True, workspace=ws)           # records the plan; nobody has looked yet
+    assert "fwd" in ws._plans
+    with pytest.raises(RuntimeError, match="missed entries"):
+        R.forward_views(views, *args, force_binned=True, workspace=ws)       # replay + probe of call 1
+    assert "fwd" not in ws._plans and R._BIN_CAP_HINT[key] >= o["R"]
+    for _ in range(3):                                                       # validating path with the grown arena, then replays
+        col, _, _, st = R.forward_views(views, *args, force_binned=True, workspace=ws)
+        assert st.bin_capacity >= o["R"] and np.array_equal(col[0].cpu().numpy(), o["color"])
+
+
+def test_autograd_path_never_renders_with_dropped_entries(device):
+    """The drop-in GaussianRasterizer path checks the pair count on every forward (like rasterizer_impl.cu:283-288): an
+    arena sized by an earlier, smaller call is grown and the forward redone inside the same call."""
+    import math
+    from skelsplat_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    c = util.make_case(seed=33, W=152, H=120, scale_log=3.6, n_skeletons=16, pitch=150.0, n_views=1)   # P = 272: binned path
+    assert c.P > 256
+    cam = c.cams[0].to(device)
+    rs = GaussianRasterizationSettings(c.H, c.W, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), torch.zeros(3, device=device),
+                                       1.0, cam.world_view_transform, cam.full_proj_transform, 0, cam.camera_center, False, False, False)
+    key = (device.index, 1, c.P, c.C, c.W, c.H)
+    o = util.oracle_forward(c, 0)
+    R._BIN_CAP_HINT[key] = 64
+    R._BIN_CAP_SEEN.add(key)
+    assert o["R"] > 64
+    means = t(c.means, device).requires_grad_(True)
+    color, radii, inv = GaussianRasterizer(rs)(means3D=means, means2D=torch.zeros_like(means), opacities=t(c.opac, device),
+                                               shs=t(c.feat, device)[:, None, :], scales=t(c.scales, device), rotations=t(c.quats, device))
+    assert np.array_equal(color.detach().cpu().numpy(), o["color"])
+    (color * t(c.dL_color[0], device)).sum().backward()
+    b = util.oracle_backward(c, 0, o, with_inv=False)
+    util.assert_close("means", means.grad.cpu(), b["dL_dmeans3D"])
