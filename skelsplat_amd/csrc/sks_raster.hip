@@ -124,7 +124,7 @@ void launch_fwd_binned(const FwdArgs& a, const BinView& bv, int V, int gx, int g
 {
     int fsplit, pb;
     fill_geometry(a, true, true, fsplit, pb);
-    const int xc = (gx + a.C) / (a.C + 1);                            // (view, tile) composite blocks spread over the rows
+    const int xc = ((gx + TGROUP - 1) / TGROUP + a.C) / (a.C + 1);   // composite blocks (TGROUP tile columns each) spread over the rows
     dim3 grid(fsplit + xc, gy, (a.C + 1) * V);
     const bool nt = !(a.flags & SKS_NO_NT_STORES);
     if (a.W % 4 == 0) {

@@ -16,7 +16,8 @@ for f in glob.glob("/tmp/pmcs*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         if sys.argv[1] not in k: continue
-        acc[k.split("(")[0][-40:]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        k = k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:60]
+        acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in acc.items():
     print(k)
     for c, v in sorted(d.items()):
