@@ -273,7 +273,7 @@ int sks_forward(int V, int P, int C, int W, int H, const float* viewmatrix, cons
                        b.cursor, b.keys, b.nrend + V);
     hipLaunchKernelGGL(k_bin_sort, dim3((NT + 3) / 4, V), dim3(256), 0, st, NT, bin_capacity, b.ranges, b.keys);
     STAGE_CHECK("binning");
-    BinView bv{ b.ranges, b.keys, bin_capacity, NT };
+    BinView bv{ b.ranges, b.keys, bin_capacity, NT, b.aux };
     uint32_t* cover = geom_cover_ptr(geom, V, P);
     const int cw = cover_cw(W);
     hipLaunchKernelGGL(k_bin_cover, dim3(gy, V), dim3(64), 0, st, NT, gx, cw, bin_capacity, b.ranges, cover);
@@ -327,7 +327,7 @@ int sks_backward(int V, int P, int C, int W, int H, const float* viewmatrix, con
         if (!binning) return fail(-2, "binned path needs the forward's binning buffer");
         HIP_TRY(hipMemsetAsync(accum, 0, (size_t)V * P * (NACC + C) * sizeof(float), st));  // atomics target
         Bin b = bin_from(const_cast<void*>(binning), V, NT, bin_capacity);
-        BinView bv{ b.ranges, b.keys, bin_capacity, NT };
+        BinView bv{ b.ranges, b.keys, bin_capacity, NT, b.aux };
         dim3 grid(gx, gy, V);
         ProfScope prof(1, st);
         if (dfeat) hipLaunchKernelGGL((k_render_bwd_binned<true>), grid, dim3(256), 0, st, a, bv);
