@@ -106,6 +106,7 @@ class OracleC:
         self._fwd[key] = (o, cam)
         geom = torch.tensor([key], dtype=torch.int64).view(torch.uint8)          # the handle travels in geomBuffer
         t = torch.from_numpy
+        self.last_fwd_out = (int(o["R"]), o["color"].copy(), o["radii"].copy(), o["invdepth"].copy())
         return (int(o["R"]), t(o["color"]), t(o["radii"]), geom, torch.zeros(8, dtype=torch.uint8),
                 torch.zeros(8, dtype=torch.uint8), t(o["invdepth"]))
 
@@ -123,8 +124,10 @@ class OracleC:
         t = lambda a, *s: torch.zeros(s) if a is None else torch.from_numpy(np.ascontiguousarray(a)).reshape(s)
         # rasterize_points.cu:222: (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations).
         # dL_dsh: the reference's kernel leaves garbage there; the stand-in returns zeros.
-        return (t(b["dL_dmeans2D"], P, 3), t(b["dL_dcolors"], P, self.C), t(b["dL_dopacity"], P, 1), t(b["dL_dmeans3D"], P, 3),
-                t(b["dL_dcov3D"], P, 6), torch.zeros((P, 1, self.C)), t(b["dL_dscales"], P, 3), t(b["dL_drotations"], P, 4))
+        out = (t(b["dL_dmeans2D"], P, 3), t(b["dL_dcolors"], P, self.C), t(b["dL_dopacity"], P, 1), t(b["dL_dmeans3D"], P, 3),
+               t(b["dL_dcov3D"], P, 6), torch.zeros((P, 1, self.C)), t(b["dL_dscales"], P, 3), t(b["dL_drotations"], P, 4))
+        self.last_bwd_out = tuple(x.clone() for x in out)
+        return out
 
     def mark_visible(self, means3D, viewmatrix, projmatrix):
         self.calls.append(("mark_visible", self._snap((means3D, viewmatrix, projmatrix))))

@@ -56,7 +56,7 @@ def _store(out, prefix, names, args):
 
 def main():
     calls = []
-    env.install(calls)
+    stubs = env.install(calls)
     sys.path.append(env.ROOT)
     from skelsplat_amd.scene import SyntheticScene          # (inputs only: skeleton, ring cameras; stored in the fixture)
     import gaussian_renderer as ref_gr                      # the reference's
@@ -120,6 +120,14 @@ def main():
             })
             for n, gr in zip(("xyz", "scaling", "rotation", "opacity", "viewspace_points"), grads):
                 out[pre + "grad_" + n] = gr.detach().numpy()
+            # what the native module returned to the reference's Python (rasterize_points.cu:124, 222): the 7-tuple's
+            # tensors and the 8-tuple, in their order
+            R_, color_, radii_, invd_ = stubs[s["key"]].last_fwd_out
+            out.update({pre + "ret_num_rendered": np.int64(R_), pre + "ret_color": color_, pre + "ret_radii": radii_,
+                        pre + "ret_invdepth": invd_})
+            for n, t_ in zip(("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales",
+                              "dL_drotations"), stubs[s["key"]].last_bwd_out):
+                out[pre + "ret_" + n] = t_.numpy()
 
         # GaussianRasterizer called directly (DGR __init__.py:158-207): validation messages, markVisible, and where each
         # of the 8 native gradients lands among the 9 inputs (:129-139) -- with recognisable constants from a marker `_C`
