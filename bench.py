@@ -508,6 +508,27 @@ def extra_stress(args, torch, dev, sync):
     if pb[1]:
         out["bwd_kernel_us"] = pb[0] * 1e3 / pb[1]
         out["bwd_kernel_us_p10_p50_p90"] = [round(1e3 * x, 1) for x in pb[2]]
+    # byte models and PMC traffic (profiles/traffic.json: separate rocprofv3 --pmc passes over tools/bench_stress.py, the same
+    # scene).  Forward: every plane is written once.  Backward: dL/d(colour, inverse depth) is read where a tile's list is not
+    # empty -- at most (C+1) planes of the covered tiles; channels no entry of the list has a feature for are skipped.
+    st = R.forward_views(views, *params, None, bin_capacity=400000)[3]
+    pl, rg, nr = R.export_lists(st)
+    covered = int((rg[..., 1] > rg[..., 0]).sum())
+    out["covered_tiles"] = covered
+    out["pairs_per_view"] = [int(x) for x in nr.cpu()]
+    out["fwd_algorithmic_bytes"] = 4.0 * H * W * (C + 1) * V
+    out["bwd_model_bytes_upper"] = 4.0 * 256 * (C + 1) * covered
+    try:
+        tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["stress_256skeletons_8view_2048x2048_P4352_C17"]["kernels"]
+        f = [v for k, v in tr.items() if k.startswith("k_render_fwd_binned")][0]
+        b = [v for k, v in tr.items() if k.startswith("k_render_bwd_binned")][0]
+        out["fwd_traffic_over_algorithmic"] = f["hbm_bytes_per_launch"] / out["fwd_algorithmic_bytes"]
+        out["bwd_fetch_bytes"] = 2048.0 * b["FETCH_SIZE_KiB_per_launch"]
+        out["bwd_write_bytes"] = 1024.0 * b["WRITE_SIZE_KiB_per_launch"]
+        out["bwd_fetch_over_model_upper"] = out["bwd_fetch_bytes"] / out["bwd_model_bytes_upper"]
+        out["traffic_source"] = "profiles/traffic.json (separate rocprofv3 --pmc passes, not measured in this run)"
+    except Exception:
+        pass
     return out
 
 

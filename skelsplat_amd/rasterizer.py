@@ -115,6 +115,9 @@ def _f32c(t, name):
     return t.contiguous()
 
 
+_VIEW_CACHE = {}     # ViewBatch.from_settings
+
+
 class ViewBatch:
     """V cameras packed for one launch sequence.  The dense entry points (sks_forward / sks_backward write and read
     (V,C,H,W) tensors) need one image size; the sparse fused-loss path writes nothing dense and takes a batch whose
@@ -150,7 +153,20 @@ class ViewBatch:
 
     @classmethod
     def from_settings(cls, rs):
-        return cls(rs.viewmatrix, rs.projmatrix, [rs.tanfovx], [rs.tanfovy], rs.image_width, rs.image_height)
+        """One view from a GaussianRasterizationSettings.  A training loop builds the settings of the same few cameras over
+        and over (train.py:140 -> gaussian_renderer/__init__.py:46-60): the batch of a camera is kept while its two matrices
+        are the same, unmodified tensors (the reference's are transposed views, scene/cameras.py:94-97: each rebuild would
+        cost two small copy kernels and two ctypes arrays)."""
+        vm, pm = rs.viewmatrix, rs.projmatrix
+        key = (vm.data_ptr(), vm._version, pm.data_ptr(), pm._version, rs.tanfovx, rs.tanfovy, rs.image_width, rs.image_height)
+        hit = _VIEW_CACHE.get(key)
+        if hit is not None and hit[1]() is vm and hit[2]() is pm:
+            return hit[0]
+        if len(_VIEW_CACHE) > 256:
+            _VIEW_CACHE.clear()
+        vb = cls(vm, pm, [rs.tanfovx], [rs.tanfovy], rs.image_width, rs.image_height)
+        _VIEW_CACHE[key] = (vb, weakref.ref(vm), weakref.ref(pm))
+        return vb
 
 
 class ForwardState:

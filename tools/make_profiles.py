@@ -6,7 +6,9 @@
   <round>_kernel_stats_stress.csv     same, tools/bench_stress.py (P = 4352, 8 views, 2048^2, binned path)
   <round>_bench.json / <round>_bench_panoptic.json    the bench.py lines of the same box
   <round>_kernel_stats_frames.csv     same, tools/bench_frames.py 16 (frame-batched loop); <round>_frames.txt: frames/s table
-  traffic.json                        HBM bytes per launch per kernel from the PMC passes (bench.py reads this)
+  traffic.json                        HBM bytes per launch per kernel from the PMC passes (bench.py reads this); the stress
+                                      workload's passes run tools/bench_stress.py (tools/pmc_traffic_stress.sh)
+  <round>_stress_traffic.txt / _stress_timeline.txt   the same figures as text; start / end of every kernel of one binned forward call
 
 PMC units and corrections as prescribed by MI355X_MICROARCH.md (HBM / rocprofv3 section): WRITE_SIZE and FETCH_SIZE
 are reported in KiB; on gfx950 FETCH_SIZE counts 64-byte requests as 32 bytes, so it is doubled.
@@ -17,8 +19,9 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
 DST = os.path.join(ROOT, "profiles")
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
-NAMES = {"h36m": "h36m_4view_1000x1000_P17_C17", "panoptic": "panoptic_31view_1920x1080_P19_C19"}
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
+NAMES = {"h36m": "h36m_4view_1000x1000_P17_C17", "panoptic": "panoptic_31view_1920x1080_P19_C19",
+         "stress": "stress_256skeletons_8view_2048x2048_P4352_C17"}
 
 
 def short(name):
@@ -60,7 +63,7 @@ for wl, tag in (("h36m", ""), ("panoptic", "_panoptic"), ("stress", "_stress")):
         ks[k] = {"launches": nW.get(k, 0), "WRITE_SIZE_KiB_per_launch": wk, "FETCH_SIZE_KiB_per_launch": fk,
                  "hbm_bytes_per_launch": 1024.0 * (wk + 2.0 * fk)}
     entry = {"kernels": ks}
-    fwd = [k for k in ks if k.startswith("k_render_fwd_sparse")]
+    fwd = [k for k in ks if k.startswith("k_render_fwd_sparse") or k.startswith("k_render_fwd_binned")]
     if fwd:
         entry["fwd_bytes_per_launch"] = ks[fwd[0]]["hbm_bytes_per_launch"]
     traffic[NAMES[wl]] = entry
@@ -75,7 +78,7 @@ st = glob.glob(os.path.join(SRC, "frames_stats", "**", "*kernel_stats.csv"), rec
 if st:   # tools/bench_frames.py 16: the frame-batched loop (16 H36M frames per launch)
     shutil.copy(st[0], os.path.join(DST, f"{rnd}_kernel_stats_frames.csv"))
 for name in ("bench_ssim.txt", "ssim_pmc_fwd.txt", "ssim_pmc_train.txt", "sharded_world1_bench.json", "width_sweep.txt",
-             "frames.txt"):   # fused-SSIM timings and SQ counter passes, the sharded path at world 1, sweeps
+             "frames.txt", "stress_traffic.txt", "stress_timeline.txt", "stress.log"):   # fused-SSIM timings and SQ counter passes, the sharded path at world 1, sweeps
     src = os.path.join(SRC, name)
     if os.path.exists(src) and os.path.getsize(src):
         shutil.copy(src, os.path.join(DST, f"{rnd}_{name}"))

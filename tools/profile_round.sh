@@ -4,7 +4,7 @@
 # --kernel-trace).  Run on the GPU box from the repo root:  bash tools/profile_round.sh r01
 # Outputs land in gpurun_out/prof/; tools/make_profiles.py turns them into profiles/<round>_*.
 set -u
-R=${1:-r02}
+R=${1:-r03}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof
 mkdir -p "$OUT"
@@ -15,6 +15,10 @@ for WL in h36m panoptic; do
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/${WL}_f" -o f -- python3 "$ROOT/bench.py" --workload $WL --steps 20 --warmup 3 --no-cpu-baseline --no-prof --no-extras > /dev/null 2> "$OUT/${WL}_f.log"
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stress_stats" -o stats -- python3 "$ROOT/tools/bench_stress.py" > "$OUT/stress.log" 2>&1
+# HBM traffic of the binned path's kernels (separate PMC passes, --kernel-trace only) and the timeline of one forward call
+bash "$ROOT/tools/pmc_traffic_stress.sh" "$OUT" > "$OUT/stress_traffic.txt" 2>&1
+bash "$ROOT/tools/trace_stress.sh" > "$OUT/stress_timeline.txt" 2>&1
+cd /tmp
 # the frame-batched loop: 16 H36M frames per launch (kernel stats of that run alone), then the frames/s table
 ONLY_BATCH=1 STREAMS= ITERS=200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/frames_stats" -o stats -- python3 "$ROOT/tools/bench_frames.py" 16 > "$OUT/frames_under_rocprof.log" 2>&1
 cd "$ROOT"
