@@ -134,6 +134,11 @@ def timed(fn, steps, warmup, sync):
     return time.perf_counter() - t0, out
 
 
+def prof_stride(steps):
+    samples = max(5, min(25, steps // 8))
+    return max(1, steps // samples)
+
+
 def roofline_entry(alg_bytes, prof_fwd, wl_name, launches, kernel="k_render_fwd_sparse (forward fill + sparse compositor)",
                    traffic_scale=1.0):
     """`traffic_scale`: a sharded rank launches the kernel for its share of the workload's views; the PMC figure of the
@@ -210,9 +215,11 @@ def run_single(args, torch, dev, wl):
         step()
     sync()
     if prof:
-        # the kernels of every 8th step are bracketed with hipEvents on the launch stream: >= 25 samples of the timed
-        # region at the default 200 steps, without the ~12 us per step that four event records per step would add
-        _lib.prof_enable(True, every=max(1, min(8, args.steps // 8)))
+        # the compositor launches of every n-th step of the timed region carry a hipEvent pair (hipExtLaunchKernelGGL: the
+        # pair is stamped from the kernel's own dispatch, on the launch stream).  A bracketed step costs ~13 us of queue
+        # time (measured: 68.4 us per step without, 69.7 bracketing every 8th, 74-80 every 2nd, 82-85 every step), so the
+        # sample is 5 .. 25 launches: every 8th step at the default 200 steps, every 4th at 20
+        _lib.prof_enable(True, every=int(os.environ.get("SKS_PROF_EVERY", "0")) or prof_stride(args.steps))
         _lib.prof_read(0), _lib.prof_read(1)
     dt, out = timed(step, args.steps, 0, sync)
     pf = pb = None
@@ -631,7 +638,7 @@ def run_sharded(args, torch, dist, dev, wl, world, rank):
     sync()
     prof = not args.no_prof and bool(local)
     if prof:
-        _lib.prof_enable(True, every=max(1, min(8, args.steps // 8)))
+        _lib.prof_enable(True, every=prof_stride(args.steps))
         _lib.prof_read(0), _lib.prof_read(1)
     dt, out = timed(step, args.steps, 0, sync)
     dt = max_over_ranks(dt)

@@ -22,6 +22,7 @@
 //   sks_binned.inc     k_bin_*, k_render_fwd_binned, k_render_bwd_binned
 // followed here by the launchers and the extern "C" entry points of include/skelsplat_hip.h.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdarg.h>
 #include <stdlib.h>
 #include <stdio.h>
@@ -96,7 +97,7 @@ inline void fill_geometry(const FwdArgs& a, bool have_cover, bool binned, int& f
 }
 
 template <int CG>
-void launch_fwd_small(const FwdArgs& a_in, int V, int gy, hipStream_t st)
+void launch_fwd_small(const FwdArgs& a_in, int V, int gy, hipStream_t st, const ProfScope& prof)
 {
     FwdArgs a = a_in;
     const int ncomp = a.tslots * a.P * V;
@@ -110,12 +111,12 @@ void launch_fwd_small(const FwdArgs& a_in, int V, int gy, hipStream_t st)
     dim3 grid(fsplit + xc, gy, (a.C + 1) * V);
     const bool nt = !(a.flags & SKS_NO_NT_STORES);
     if (a.W % 4 == 0) {
-        if (nt) hipLaunchKernelGGL((k_render_fwd_sparse<CG, 4, true>), grid, dim3(256), lds, st, a, a.cp1_magic, gy, fsplit, pb, (const uint32_t*)a.g.cover);
-        else hipLaunchKernelGGL((k_render_fwd_sparse<CG, 4, false>), grid, dim3(256), lds, st, a, a.cp1_magic, gy, fsplit, pb, (const uint32_t*)a.g.cover);
+        if (nt) SKS_LAUNCH(prof, (k_render_fwd_sparse<CG, 4, true>), grid, dim3(256), lds, st, a, a.cp1_magic, gy, fsplit, pb, (const uint32_t*)a.g.cover);
+        else SKS_LAUNCH(prof, (k_render_fwd_sparse<CG, 4, false>), grid, dim3(256), lds, st, a, a.cp1_magic, gy, fsplit, pb, (const uint32_t*)a.g.cover);
     } else if (fill_half_mode(a)) {
-        hipLaunchKernelGGL((k_render_fwd_sparse<CG, 4, true, true>), grid, dim3(256), lds, st, a, a.cp1_magic, gy, fsplit, pb, (const uint32_t*)a.g.cover);
+        SKS_LAUNCH(prof, (k_render_fwd_sparse<CG, 4, true, true>), grid, dim3(256), lds, st, a, a.cp1_magic, gy, fsplit, pb, (const uint32_t*)a.g.cover);
     } else {
-        hipLaunchKernelGGL((k_render_fwd_sparse<CG, 1, false>), grid, dim3(256), lds, st, a, a.cp1_magic, gy, fsplit, pb, (const uint32_t*)a.g.cover);
+        SKS_LAUNCH(prof, (k_render_fwd_sparse<CG, 1, false>), grid, dim3(256), lds, st, a, a.cp1_magic, gy, fsplit, pb, (const uint32_t*)a.g.cover);
     }
 }
 
@@ -169,7 +170,8 @@ inline void launch_bwd_loss(const BwdArgs& a, const ViewTan& vt, const ViewOff& 
 }
 
 template <int CG>
-void launch_bwd_small(const BwdArgs& a, const ViewTan& vt, const ViewOff& vo, int V, int gy, bool dfeat, hipStream_t st)
+void launch_bwd_small(const BwdArgs& a, const ViewTan& vt, const ViewOff& vo, int V, int gy, bool dfeat, hipStream_t st,
+                      const ProfScope& prof)
 {
     (void)gy;
     // slot index slowest: a (view, Gaussian) only has work for its first ceil(pixels / 256) slots, so the idle workgroups
@@ -177,8 +179,8 @@ void launch_bwd_small(const BwdArgs& a, const ViewTan& vt, const ViewOff& vo, in
     // wait for (the fused-loss kernel fits 3 workgroups per CU: 768 of H36M's 1 088 at once)
     if (a.P <= 64 && !(a.flags & (1u << 20))) {  // wave-resident variant (bit 20: force the LDS variant, tests)
         dim3 grid(a.P, V, bwd_wave_groups(V, a.P, a.flags));
-        if (dfeat) hipLaunchKernelGGL((k_render_bwd_wave<CG, true, false>), grid, dim3(256), 0, st, a, vt, vo);
-        else hipLaunchKernelGGL((k_render_bwd_wave<CG, false, false>), grid, dim3(256), 0, st, a, vt, vo);
+        if (dfeat) SKS_LAUNCH(prof, (k_render_bwd_wave<CG, true, false>), grid, dim3(256), 0, st, a, vt, vo);
+        else SKS_LAUNCH(prof, (k_render_bwd_wave<CG, false, false>), grid, dim3(256), 0, st, a, vt, vo);
         return;
     }
     dim3 grid(a.P, V, BWD_SPLITS);
@@ -189,8 +191,8 @@ void launch_bwd_small(const BwdArgs& a, const ViewTan& vt, const ViewOff& vo, in
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render_bwd_gather<CG, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
-    if (dfeat) hipLaunchKernelGGL((k_render_bwd_gather<CG, true>), grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((k_render_bwd_gather<CG, false>), grid, dim3(256), lds, st, a);
+    if (dfeat) SKS_LAUNCH(prof, (k_render_bwd_gather<CG, true>), grid, dim3(256), lds, st, a);
+    else SKS_LAUNCH(prof, (k_render_bwd_gather<CG, false>), grid, dim3(256), lds, st, a);
 }
 
 }  // namespace
@@ -252,12 +254,12 @@ int sks_forward(int V, int P, int C, int W, int H, const float* viewmatrix, cons
     const bool small = P <= SKS_SMALL_P && !(flags & SKS_FORCE_BINNED);
     if (small) {
         {
-            ProfScope prof(0, st);
+            ProfScope prof(0, st, true);
             switch (cg) {
-                case 4: launch_fwd_small<4>(a, V, gy, st); break;
-                case 16: launch_fwd_small<16>(a, V, gy, st); break;
-                case 20: launch_fwd_small<20>(a, V, gy, st); break;
-                default: launch_fwd_small<32>(a, V, gy, st); break;
+                case 4: launch_fwd_small<4>(a, V, gy, st, prof); break;
+                case 16: launch_fwd_small<16>(a, V, gy, st, prof); break;
+                case 20: launch_fwd_small<20>(a, V, gy, st, prof); break;
+                default: launch_fwd_small<32>(a, V, gy, st, prof); break;
             }
         }
         STAGE_CHECK("render(small)");
@@ -315,12 +317,12 @@ int sks_backward(int V, int P, int C, int W, int H, const float* viewmatrix, con
     const bool dfeat = dL_dfeatures != nullptr;
     const bool small = P <= SKS_SMALL_P && !(flags & SKS_FORCE_BINNED);
     if (small) {
-        ProfScope prof(1, st);
+        ProfScope prof(1, st, true);
         switch (cg) {
-            case 4: launch_bwd_small<4>(a, vt, vo, V, gy, dfeat, st); break;
-            case 16: launch_bwd_small<16>(a, vt, vo, V, gy, dfeat, st); break;
-            case 20: launch_bwd_small<20>(a, vt, vo, V, gy, dfeat, st); break;
-            default: launch_bwd_small<32>(a, vt, vo, V, gy, dfeat, st); break;
+            case 4: launch_bwd_small<4>(a, vt, vo, V, gy, dfeat, st, prof); break;
+            case 16: launch_bwd_small<16>(a, vt, vo, V, gy, dfeat, st, prof); break;
+            case 20: launch_bwd_small<20>(a, vt, vo, V, gy, dfeat, st, prof); break;
+            default: launch_bwd_small<32>(a, vt, vo, V, gy, dfeat, st, prof); break;
         }
         STAGE_CHECK("render-backward(small)");
     } else {
