@@ -369,32 +369,10 @@ def test_sparse_loop_equals_dense_loop(device):
     util.assert_close("scaling", outs[0][1], outs[1][1], rtol=1e-4, atol_scale=1e-4)
 
 
-def test_full_scene_converges_to_the_reference_mpjpe(device):
-    """North-star parity bar: a whole scene (500 iterations, the LR schedule of configs/h36m.yaml) through the production
-    path (sparse fused step, hipGraphs) ends at the same MPJPE as the literal per-iteration reference loop on the
-    PyTorch oracle -- within 0.5 mm (in practice a few hundredths)."""
-    from skelsplat_amd.loop import MultiViewLoop, mpjpe
-    from skelsplat_amd.heatmaps import generate_heatmaps
-    from tests.ref_loop import run_reference_loop
-    import copy
-    sc, model = _make_loop_scene(device, W=112, H=96)   # (the CPU reference loop is what takes the time: ~40 s)
-    gm = model(device)
-    hm = generate_heatmaps(gm._xyz.detach(), gm.get_scaling.detach(), gm._rotation.detach(),
-                           torch.tensor(sc.poses_2d, device=device), sc.cameras)
-    loop = MultiViewLoop(gm, sc.cameras, hm, dataset="h36m", accumulation_steps=4, lambda_consistency=1e-5, use_graph=True)
-    assert loop.sparse and loop.use_graph
-    out = loop.run(500).cpu()
-    cams_cpu = [copy.copy(c).to("cpu") for c in sc.cameras]
-    ref = run_reference_loop(model("cpu"), cams_cpu, hm.cpu(), sc.W, sc.H, "h36m", 500)
-    gt = torch.tensor(sc.pose_3d_gt).float()
-    e0 = mpjpe(torch.tensor(sc.pose_3d_init).float(), gt)
-    e_hip, e_ref = mpjpe(out, gt), mpjpe(ref, gt)
-    moved = (ref - torch.tensor(sc.pose_3d_init).float()).norm(dim=1).mean().item()
-    print(f"MPJPE start {e0:.3f} mm -> HIP {e_hip:.4f} mm, reference loop {e_ref:.4f} mm; max joint distance "
-          f"{(out - ref).norm(dim=1).max().item():.4f} mm; joints moved {moved:.2f} mm on average")
-    assert moved > 1.0, f"the optimisation barely moved the joints ({moved} mm): test is vacuous"
-    assert abs(e_hip - e_ref) < 0.5, f"MPJPE {e_hip:.3f} mm (HIP) vs {e_ref:.3f} mm (reference loop), start {e0:.3f} mm"
-    assert (out - ref).norm(dim=1).max().item() < 0.5
+# (The whole-scene MPJPE bar -- 500 iterations through the production path against the per-iteration loop -- is
+#  tests/test_loop_golden.py::test_production_loop_follows_the_reference_trajectory[h36m_mid-True]: the same 112x96 scene
+#  shape, but against the trajectory of the REFERENCE's own train.training() instead of the restated loop run here, which
+#  took 90 s of CPU time per test run.)
 
 
 def test_loop_with_mixed_image_sizes(device):
@@ -1016,6 +994,17 @@ def _two_rank_worker(rank, world, port, mode, ret):
     assert loop.world == world and loop.exchange == (world > 1) and loop.device_tail
     if world > 1:
         assert loop.local_ids == [v for v in range(5) if v % 2 == rank] and tuple(loop._allg.shape) == (6, 17, 11)
+    if mode == "dropout":
+        # training.dropout (general_utils.py:267-283): ONE draw of dropped (camera, joint) planes per scene.  The ranks'
+        # default generators are deliberately out of step here; rank 0's draw must be the scene's on every rank
+        torch.manual_seed(1234 + 77 * rank)
+        loop.new_scene(torch.tensor(sc.pose_3d_init, device=dev, dtype=torch.float32), poses_2d=torch.tensor(sc.poses_2d, device=dev),
+                       dropout=True)
+        with torch.no_grad():
+            gm._opacity.fill_(2.0)
+        if world == 1:   # the draw did drop planes, and some of them belong to views the second rank owns at world 2
+            dropped = [int((pl.reshape(pl.shape[0], -1).abs().amax(1) == 0).sum()) for pl in loop.hset.planes]
+            assert sum(dropped) > 0 and dropped[1] + dropped[3] > 0, dropped
     loop.run(30)
     torch.cuda.synchronize()
     if rank == 0:
@@ -1025,7 +1014,7 @@ def _two_rank_worker(rank, world, port, mode, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["sparse", "dense", "mixed"])
+@pytest.mark.parametrize("mode", ["sparse", "dense", "mixed", "dropout"])
 def test_two_ranks_on_one_gpu_equal_one_rank(device, mode):
     """The view-sharded device path at world size 2 -- uneven shards (3 + 2 views, one zero pad row), all_gather, the
     rank-major optimiser kernel, every rank stepping identically -- as two processes sharing this GPU over gloo (RCCL
