@@ -244,14 +244,20 @@ int sks_forward(int V, int P, int C, int W, int H, const float* viewmatrix, cons
     Geom g = geom_from(geom, V, P, W, H);
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE, NT = gx * gy;
 
+    const bool small = P <= SKS_SMALL_P && !(flags & SKS_FORCE_BINNED);
+    Bin b{};
+    if (!small) {
+        if (!binning) return fail(-2, "binned path needs a binning buffer");
+        b = bin_from(binning, V, NT, bin_capacity);
+    }
     hipLaunchKernelGGL(k_geom_fwd, dim3((P + 255) / 256, V), dim3(256), 0, st, P, W, H, vt, viewmatrix, projmatrix,
-                       means3D, opacities, scales, rotations, cov3D_precomp, scale_modifier, flags, g, radii, 0);
+                       means3D, opacities, scales, rotations, cov3D_precomp, scale_modifier, flags, g, radii, 0,
+                       small ? (uint32_t*)nullptr : b.count, small ? 0u : (unsigned)((size_t)V * NT), small ? (int*)nullptr : b.nrend + V);
     STAGE_CHECK("geometry");
 
     FwdArgs a{ P, C, W, H, flags, g, features, out_color, out_invdepth, final_T, n_contrib, composite_slots(flags, V, P),
                ((1u << 20) + (unsigned)C) / (unsigned)(C + 1), 0 };
     const int cg = pick_cg(C);
-    const bool small = P <= SKS_SMALL_P && !(flags & SKS_FORCE_BINNED);
     if (small) {
         {
             ProfScope prof(0, st, true);
@@ -265,10 +271,6 @@ int sks_forward(int V, int P, int C, int W, int H, const float* viewmatrix, cons
         STAGE_CHECK("render(small)");
         return 0;
     }
-    if (!binning) return fail(-2, "binned path needs a binning buffer");
-    Bin b = bin_from(binning, V, NT, bin_capacity);
-    HIP_TRY(hipMemsetAsync(b.count, 0, (size_t)V * NT * 4, st));
-    HIP_TRY(hipMemsetAsync(b.nrend + V, 0, 4, st));
     hipLaunchKernelGGL(k_bin_count, dim3((P * BIN_SUB + 255) / 256, V), dim3(256), 0, st, P, NT, gx, g.rect, b.count);
     hipLaunchKernelGGL(k_bin_scan, dim3(V), dim3(1024), 0, st, NT, b.count, b.cursor, b.ranges, b.nrend, V, num_rendered_dev);
     hipLaunchKernelGGL(k_bin_scatter, dim3((P * BIN_SUB + 255) / 256, V), dim3(256), 0, st, P, NT, gx, bin_capacity, g.rect, g.xyd,
