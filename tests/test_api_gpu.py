@@ -7,7 +7,6 @@ GPU with the same raw inputs, and every value that crosses into the native libra
 handed to ITS native module: argument by argument (gaussian_renderer/__init__.py:28-138,
 DGR/diff_gaussian_rasterization_h36m/__init__.py:60-81, 101-139).
 """
-import ctypes
 import os
 
 import numpy as np
