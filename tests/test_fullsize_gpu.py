@@ -57,7 +57,7 @@ def _hard_case(dev, dataset, V, W, H, seed, ring, fx, scale_log=3.4, **kw):
     return [cam.to(dev) for cam in c.cams], params
 
 
-def _check_forward(cams, params, dev, binned_too=True, lists=False, bin_capacity=None, groups=None):
+def _check_forward(cams, params, dev, binned_too=True, lists=False, bin_capacity=None, groups=None, aa=False):
     """All views, small and / or binned path, against the oracle.  Returns (oracle outputs per view, the forward state of
     the default path).  `groups`: lists of view indices that share an image size (the dense tensors cannot mix sizes)."""
     np_params = [p.detach().cpu().numpy() for p in params]
@@ -70,11 +70,11 @@ def _check_forward(cams, params, dev, binned_too=True, lists=False, bin_capacity
         for kw in variants:
             if P > 256 or kw:
                 kw = dict(kw, bin_capacity=bin_capacity, check_capacity=True)
-            color, inv, radii, st, final_T, n_contrib = R.forward_views(views, *params, None, want_aux=True, **kw)
+            color, inv, radii, st, final_T, n_contrib = R.forward_views(views, *params, None, want_aux=True, antialiasing=aa, **kw)
             if st.binning is not None and lists:
                 pl, rg, nr = [x.cpu().numpy() for x in R.export_lists(st)]
             for k, i in enumerate(idx):
-                o = outs[i] = outs[i] or orc.forward(*np_params, None, _ocam(cams[i]))
+                o = outs[i] = outs[i] or orc.forward(*np_params, None, _ocam(cams[i]), antialiasing=aa)
                 tag = f"view {i} {'binned' if st.binning is not None else 'small'}"
                 assert np.array_equal(radii[k].cpu().numpy(), o["radii"]), tag
                 assert np.array_equal(n_contrib[k].cpu().numpy().astype(np.uint32), o["n_contrib"]), tag
@@ -91,7 +91,7 @@ def _check_forward(cams, params, dev, binned_too=True, lists=False, bin_capacity
     return outs, states
 
 
-def _check_backward(cams, params, dev, outs, states, seed=0, rtol=1e-3, bg=None, binned_too=True):
+def _check_backward(cams, params, dev, outs, states, seed=0, rtol=1e-3, bg=None, binned_too=True, aa=False):
     """Dense random dL/d(colour) and dL/d(inverse depth) on the GPU, every view's seven gradients against the oracle."""
     np_params = [p.detach().cpu().numpy() for p in params]
     P, C = params[1].shape
@@ -103,7 +103,7 @@ def _check_backward(cams, params, dev, outs, states, seed=0, rtol=1e-3, bg=None,
         bgt = None if bg is None else torch.tensor(bg, device=dev)
         todo = [("default", st)]
         if binned_too and st.binning is None:
-            stb = R.forward_views(views, *params, None, force_binned=True, check_capacity=True)[3]
+            stb = R.forward_views(views, *params, None, force_binned=True, check_capacity=True, antialiasing=aa)[3]
             todo.append(("binned", stb))
         for name, s in todo:
             g = R.backward_views(s, *params, None, dLc, dLi, bg=bgt, want_dfeatures=True)
@@ -111,7 +111,7 @@ def _check_backward(cams, params, dev, outs, states, seed=0, rtol=1e-3, bg=None,
             for k, i in enumerate(idx):
                 if name == "default":
                     outs[i]["_bwd"] = orc.backward(outs[i], *np_params, None, _ocam(cams[i]), dLc[k].cpu().numpy(),
-                                                   dLi[k].cpu().numpy(), bg=bg)
+                                                   dLi[k].cpu().numpy(), bg=bg, antialiasing=aa)
                 b = outs[i]["_bwd"]
                 for ours, theirs in GRADS:
                     util.assert_close(f"view {i} {name} {theirs}", g[ours][k], b[theirs].reshape(g[ours][k].shape), rtol=rtol)
@@ -186,6 +186,9 @@ def test_config2_h36m_hard_parameters(device):
     outs, states = _check_forward(cams, params, device, lists=True)
     assert all((o["n_contrib"] > 1).sum() > 2000 for o in outs)           # overlapping splats
     _check_backward(cams, params, device, outs, states, bg=[0.3, 0.5, 0.2])
+    # pipe.antialiasing = True (forward.cu:226-227, backward.cu:210-246): the opacity scaling and its gradient
+    outs, states = _check_forward(cams[:2], params, device, aa=True)
+    _check_backward(cams[:2], params, device, outs, states, aa=True)
 
 
 def test_config2_h36m_sensor_mix_1002(device):
