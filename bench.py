@@ -106,6 +106,10 @@ class ApiStep:
             self.allg = torch.empty((world * vmax, P, 3), device=dev)
             self.mean_out = torch.empty((P, 3), device=dev)
             self.V_total = V_total
+            # RCCL's ncclAllGather enqueued on the launch stream through a communicator of our own (skelsplat_amd/rccl_direct.py);
+            # None (gloo test mode, SKS_RCCL_DIRECT=0, or any rank failing to build it): torch.distributed's all_gather
+            from skelsplat_amd.rccl_direct import DirectGather
+            self.direct = DirectGather.create(dev, exchange[2])
         self.ws = R.Workspace()
 
     def __call__(self):
@@ -118,7 +122,10 @@ class ApiStep:
         if self.views is not None:       # this rank's views; their joint gradients land in its rows of the shard
             color, inv, radii, st = R.forward_views(self.views, *self.params, None, workspace=self.ws)
             R.backward_views(st, *self.params, None, self.dL, workspace=self.ws, out_means3D=self.shard[:self.views.V])
-        dist.all_gather_into_tensor(self.allg, self.shard, group=self.exchange[2])
+        if self.direct is not None:
+            self.direct.all_gather_into_tensor(self.allg, self.shard)
+        else:
+            dist.all_gather_into_tensor(self.allg, self.shard, group=self.exchange[2])
         return R.mean_views(self.allg, self.V_total, self.exchange[0], out=self.mean_out)   # reads the gathered rows in place
 
 
@@ -567,10 +574,16 @@ def extra_rank_step(args, torch, dev, sync):
         allg = torch.zeros((world * vmax, P, 3), device=dev)
         mean_out = torch.empty((P, 3), device=dev)
 
+        from skelsplat_amd.rccl_direct import DirectGather
+        direct = DirectGather.create(dev)
+
         def rank_step():
             color, inv, radii, st = R.forward_views(views, *params, None, workspace=ws)
             R.backward_views(st, *params, None, dL, workspace=ws, out_means3D=shard[:len(local)])
-            dist.all_gather_into_tensor(allg[:vmax], shard)               # (world 1: this rank's rows; the others stay zero)
+            if direct is not None:                                        # (world 1: this rank's rows; the others stay zero)
+                direct.all_gather_into_tensor(allg[:vmax], shard)
+            else:
+                dist.all_gather_into_tensor(allg[:vmax], shard)
             return R.mean_views(allg, V, world, out=mean_out)
 
         def no_exchange():
@@ -585,7 +598,10 @@ def extra_rank_step(args, torch, dev, sync):
         out = {"rank_step_4views_panoptic_ms": 1e3 * dt / n, "rank_step_without_exchange_ms": 1e3 * dt0 / n,
                "one_gpu_31views_ms": 1e3 * dtf / nf, "predicted_8gpu_speedup": (dtf / nf) / (dt / n),
                "ideal_speedup": V / vmax, "target": 6.0,
-               "note": "rank 0 of 8: 4 views fwd+bwd + all_gather_into_tensor (RCCL, 1-rank communicator) + sks_mean_views"}
+               "gather": "ncclAllGather on the launch stream (rccl_direct)" if direct is not None else "torch.distributed",
+               "note": "rank 0 of 8: 4 views fwd+bwd + all_gather (RCCL, 1-rank communicator) + sks_mean_views"}
+        if direct is not None:
+            direct.destroy()
         # the loop's own sharded steps the same way (MultiViewLoop with the exchange branch on the 1-rank communicator
         # cannot emulate 8 ranks' shard layout; the API step above is what `value` of the --gpus N line measures)
         return out
@@ -647,11 +663,16 @@ def run_sharded(args, torch, dist, dev, wl, world, rank):
         pf = _lib.prof_read_quantiles(0)
         _lib.prof_enable(False)
     assert torch.isfinite(out).all()
+    used_direct = step.direct is not None
+    if used_direct:
+        step.direct.destroy()
     del step, dL
     ms = 1e3 * dt / args.steps
     vmax = (V + world - 1) // world
     backend = dist.get_backend()
     coll = "RCCL over xGMI" if backend == "nccl" else f"{backend}: single-device test mode, timings mean nothing"
+    if backend == "nccl":
+        coll += ", ncclAllGather on the launch stream" if used_direct else ", through torch.distributed"
     strong = {"ideal_speedup": V / vmax,
               "api_step": {"one_gpu_ms_per_step": one_gpu_ms, "ms_per_step": ms, "speedup": one_gpu_ms / ms}}
     res = {

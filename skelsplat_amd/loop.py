@@ -227,10 +227,17 @@ class MultiViewLoop:
             self._sums = torch.zeros((max(Vl, 1), 2), dtype=torch.float64, device=dev)
             self._sums_all = (torch.zeros((self.world * self.vmax, 2), dtype=torch.float64, device=dev)
                               if self.exchange and self._stopping else None)
+            self._direct = None
             if self.exchange:
                 # RCCL builds its communicator on the first collective: do that here, eagerly, never inside a graph
                 # capture or a timed step (the gathered rows are overwritten by every group)
                 dist.all_gather_into_tensor(self._allg, self._shard, group=self.group)
+                # ... and a communicator of our own, so that the group's one all_gather is enqueued on the stream its
+                # neighbours run on (torch's process group runs it on an internal stream: two event hand-overs, ~7 us of the
+                # GPU timeline per step at world 1); None when the backend is not RCCL
+                if dev.type == "cuda":
+                    from .rccl_direct import DirectGather
+                    self._direct = DirectGather.create(dev, self.group)
         elif self._stopping:
             raise ValueError("early stopping is implemented on the device-tail path (default loss, ROCm tensors)")
         # one GPU, sparse step: the whole group is two launches (sks_loop_fused_step); the geometry of the current
@@ -391,7 +398,10 @@ class MultiViewLoop:
         if self.exchange:
             # every rank needs every view's gradients (train.py:175, 215-218): ONE all_gather of the padded shards over
             # RCCL; the optimiser kernel reads the gathered buffer in place (view v = row (v % world) * vmax + v // world)
-            dist.all_gather_into_tensor(self._allg, self._shard, group=self.group)
+            if self._direct is not None:
+                self._direct.all_gather_into_tensor(self._allg, self._shard)     # RCCL on THIS stream (rccl_direct.py)
+            else:
+                dist.all_gather_into_tensor(self._allg, self._shard, group=self.group)
             full, world = self._allg, self.world
         else:
             full, world = self._shard, 1

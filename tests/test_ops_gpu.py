@@ -1,5 +1,6 @@
 """GPU parity of the smaller ops: fused masked-L2, fused SSIM, 3-NN mean distance, and the multi-view loop."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -688,6 +689,33 @@ def test_exchange_branch_on_rccl_equals_unsharded_loop(device, rccl_world1, mode
     for k, (a, b_) in enumerate(zip(*res)):
         assert torch.equal(a, b_), k
     assert (res[0][0].cpu() - torch.tensor(sc.pose_3d_init).float()).norm(dim=1).mean() > 0.5
+
+
+def test_direct_rccl_gather_equals_torch_distributed(device, rccl_world1):
+    """skelsplat_amd.rccl_direct: ncclAllGather through a communicator of the library's own, enqueued on the CURRENT stream
+    (torch.distributed's process group hands every collective to an internal stream), gives what
+    dist.all_gather_into_tensor gives; one communicator per (group, device); SKS_RCCL_DIRECT=0 switches it off."""
+    import torch.distributed as dist
+    from skelsplat_amd.rccl_direct import DirectGather
+    dg = DirectGather.create(device)
+    assert dg is not None and DirectGather.create(device) is dg
+    inp = torch.randn((4, 19, 11), device=device)
+    a, b = torch.empty_like(inp), torch.full_like(inp, float("nan"))
+    dist.all_gather_into_tensor(a, inp)
+    side = torch.cuda.Stream(device)
+    side.wait_stream(torch.cuda.current_stream(device))
+    with torch.cuda.stream(side):      # on whatever stream is current: no hand-over to another one
+        dg.all_gather_into_tensor(b, inp)
+    side.synchronize()
+    assert torch.equal(a, inp) and torch.equal(b, inp)
+    with pytest.raises(ValueError):
+        dg.all_gather_into_tensor(torch.empty(5, device=device), inp)
+    os.environ["SKS_RCCL_DIRECT"] = "0"
+    try:
+        dg.destroy()
+        assert DirectGather.create(device) is None
+    finally:
+        del os.environ["SKS_RCCL_DIRECT"]
 
 
 def test_adam_step_reads_the_gathered_rank_major_layout(device):

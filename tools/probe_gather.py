@@ -31,4 +31,23 @@ for _ in range(300): dist.all_gather_into_tensor(allg[:4], shard)
 ti = time.perf_counter() - t0
 torch.cuda.synchronize()
 print(f"all_gather alone: host issue {1e6*ti/300:.1f} us, complete {1e6*(time.perf_counter()-t0)/300:.1f} us")
+from skelsplat_amd.rccl_direct import DirectGather
+dg = DirectGather.create(dev)
+print("direct communicator:", dg is not None)
+if dg is not None:
+    def step_direct():
+        big.zero_()
+        dg.all_gather_into_tensor(allg[:4], shard)
+        R.mean_views(allg, 31, 8, out=out)
+    shard.normal_()
+    for _ in range(20): step_direct()
+    torch.cuda.synchronize()
+    assert torch.equal(allg[:4], shard)
+    t0 = time.perf_counter()
+    for _ in range(300): step_direct()
+    ti = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    ta = time.perf_counter() - t0
+    print(f"direct ncclAllGather on the current stream: host issue {1e6*ti/300:.1f} us/step, complete {1e6*ta/300:.1f} us/step")
+    dg.destroy()
 dist.destroy_process_group()
