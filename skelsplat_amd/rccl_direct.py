@@ -119,3 +119,9 @@ class DirectGather:
         if self.comm:
             self.lib.ncclCommDestroy(self.comm)
             self.comm = None
+
+
+def destroy_all():
+    """ncclCommDestroy of every communicator this module built (call before dist.destroy_process_group())."""
+    for dg in list(_COMMS.values()):
+        dg.destroy()
