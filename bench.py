@@ -91,13 +91,20 @@ def cpu_baseline(scene, params, n_views):
 class ApiStep:
     """One step through the C ABI: sks_forward + sks_backward of this process's views (dL resident) and the mean of the
     per-view joint gradients over the V views (train.py:175, 215-217) -- on one GPU formed by sks_backward itself
-    (dL_dmeans3D_mean), sharded: all_gather of the per-view gradients, then the mean."""
+    (dL_dmeans3D_mean).  Sharded over ranks, the mean needs ONE collective per step, in one of two forms:
+      "all_reduce": every rank's sks_backward forms the mean over ITS views in the geometry backward's own launch, and one
+                    RCCL all-reduce with a pre-multiplied sum (weight V_local / V) makes it the mean over all V views
+                    (BASELINE configs[3]: "RCCL all-reduce on joint gradients"); needs the library's own communicator
+                    (skelsplat_amd/rccl_direct.py) and is checked against the other form on the running system first;
+      "all_gather": the per-view gradients land in the rank's rows of a shard, all_gather_into_tensor, then sks_mean_views sums
+                    the V rows in VIEW order: bit-identical to one GPU (what MultiViewLoop does, which needs the rows)."""
 
     def __init__(self, views, params, dL, V_total=None, exchange=None):
         import torch
         from skelsplat_amd import rasterizer as R
         self.R, self.views, self.params, self.dL = R, views, params, dL
         self.exchange = exchange          # None, or (world, rank, group)
+        self.mode = None
         if exchange is not None:
             world, rank, _ = exchange
             dev, P = params[0].device, params[0].shape[0]
@@ -105,12 +112,37 @@ class ApiStep:
             self.shard = torch.zeros((vmax, P, 3), device=dev)      # pad rows stay zero
             self.allg = torch.empty((world * vmax, P, 3), device=dev)
             self.mean_out = torch.empty((P, 3), device=dev)
+            self.local_mean = torch.zeros((P, 3), device=dev)      # (a rank without views contributes zeros with weight 0)
             self.V_total = V_total
-            # RCCL's ncclAllGather enqueued on the launch stream through a communicator of our own (skelsplat_amd/rccl_direct.py);
+            self.weight = (views.V if views is not None else 0) / V_total
+            # RCCL's C API on the launch stream through a communicator of our own (skelsplat_amd/rccl_direct.py);
             # None (gloo test mode, SKS_RCCL_DIRECT=0, or any rank failing to build it): torch.distributed's all_gather
             from skelsplat_amd.rccl_direct import DirectGather
             self.direct = DirectGather.create(dev, exchange[2])
+            self.mode = "all_gather"
         self.ws = R.Workspace()
+
+    def choose_mode(self):
+        """Collective.  Switches to "all_reduce" if the communicator exists, SKS_BENCH_EXCHANGE does not say all_gather, and
+        the all-reduce form reproduces the all_gather form's mean on every rank of THIS system (rtol 1e-5)."""
+        import torch
+        import torch.distributed as dist
+        if self.exchange is None or self.direct is None or os.environ.get("SKS_BENCH_EXCHANGE", "all_reduce") != "all_reduce":
+            return self.mode
+        want = self().clone()
+        self.mode = "all_reduce"
+        ok = True
+        try:
+            got = self()
+            torch.cuda.synchronize()
+            ok = bool(torch.allclose(got, want, rtol=1e-5, atol=1e-6 * float(want.abs().max())))
+        except Exception:
+            ok = False
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=want.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.exchange[2])
+        if int(flag.item()) != 1:
+            self.mode = "all_gather"
+        return self.mode
 
     def __call__(self):
         import torch.distributed as dist
@@ -119,6 +151,13 @@ class ApiStep:
             color, inv, radii, st = R.forward_views(self.views, *self.params, None, workspace=self.ws)
             g = R.backward_views(st, *self.params, None, self.dL, workspace=self.ws, want_mean=True)
             return g["means3D_mean"]     # the mean over the views comes out of the backward's own last launch
+        if self.mode == "all_reduce":
+            local = self.local_mean
+            if self.views is not None:
+                color, inv, radii, st = R.forward_views(self.views, *self.params, None, workspace=self.ws)
+                local = R.backward_views(st, *self.params, None, self.dL, workspace=self.ws, want_mean=True)["means3D_mean"]
+            self.direct.all_reduce_weighted(self.mean_out, local, self.weight)
+            return self.mean_out
         if self.views is not None:       # this rank's views; their joint gradients land in its rows of the shard
             color, inv, radii, st = R.forward_views(self.views, *self.params, None, workspace=self.ws)
             R.backward_views(st, *self.params, None, self.dL, workspace=self.ws, out_means3D=self.shard[:self.views.V])
@@ -586,20 +625,33 @@ def extra_rank_step(args, torch, dev, sync):
                 dist.all_gather_into_tensor(allg[:vmax], shard)
             return R.mean_views(allg, V, world, out=mean_out)
 
+        def rank_step_allreduce():     # the form `bench.py --gpus 8` uses when the direct communicator exists (ApiStep)
+            color, inv, radii, st = R.forward_views(views, *params, None, workspace=ws)
+            lm = R.backward_views(st, *params, None, dL, workspace=ws, want_mean=True)["means3D_mean"]
+            direct.all_reduce_weighted(mean_out, lm, len(local) / V)
+            return mean_out
+
         def no_exchange():
             color, inv, radii, st = R.forward_views(views, *params, None, workspace=ws)
             return R.backward_views(st, *params, None, dL, workspace=ws, out_means3D=shard[:len(local)])
         n = max(20, args.steps // 2)
         dt, _ = timed(rank_step, n, 10, sync)
         dt0, _ = timed(no_exchange, n, 10, sync)
+        dta = None
+        if direct is not None:
+            dta, _ = timed(rank_step_allreduce, n, 10, sync)
         full = ApiStep(R.ViewBatch.from_cameras(scene.cameras), params, torch.randn((V, C, H, W), device=dev))
         nf = max(20, args.steps // 10)
         dtf, _ = timed(full, nf, 5, sync)    # (the first calls allocate the 5 GB workspace)
-        out = {"rank_step_4views_panoptic_ms": 1e3 * dt / n, "rank_step_without_exchange_ms": 1e3 * dt0 / n,
-               "one_gpu_31views_ms": 1e3 * dtf / nf, "predicted_8gpu_speedup": (dtf / nf) / (dt / n),
+        best = min(dt, dta) if dta is not None else dt
+        out = {"rank_step_4views_panoptic_ms": 1e3 * best / n, "rank_step_all_gather_ms": 1e3 * dt / n,
+               "rank_step_all_reduce_ms": None if dta is None else 1e3 * dta / n, "rank_step_without_exchange_ms": 1e3 * dt0 / n,
+               "one_gpu_31views_ms": 1e3 * dtf / nf, "predicted_8gpu_speedup": (dtf / nf) / (best / n),
                "ideal_speedup": V / vmax, "target": 6.0,
                "gather": "ncclAllGather on the launch stream (rccl_direct)" if direct is not None else "torch.distributed",
-               "note": "rank 0 of 8: 4 views fwd+bwd + all_gather (RCCL, 1-rank communicator) + sks_mean_views"}
+               "note": "rank 0 of 8: 4 views fwd+bwd + the step's one collective on a 1-rank RCCL communicator: all_gather of the "
+                       "per-view rows + sks_mean_views, or (what --gpus N uses when it can) the local mean from the backward's own "
+                       "launch + one all-reduce with a pre-multiplied sum"}
 
         # the loop's own sharded steps the same way (MultiViewLoop with the exchange branch on the 1-rank communicator
         # cannot emulate 8 ranks' shard layout; the API step above is what `value` of the --gpus N line measures)
@@ -650,6 +702,8 @@ def run_sharded(args, torch, dist, dev, wl, world, rank):
     del dL_all
     torch.cuda.empty_cache()
     step = ApiStep(lviews, params, dL, V_total=V, exchange=(world, rank, None))
+    step()                      # (allocations, the first launches)
+    exchange_mode = step.choose_mode()
     for _ in range(args.warmup):
         step()
     sync()
@@ -671,7 +725,9 @@ def run_sharded(args, torch, dist, dev, wl, world, rank):
     backend = dist.get_backend()
     coll = "RCCL over xGMI" if backend == "nccl" else f"{backend}: single-device test mode, timings mean nothing"
     if backend == "nccl":
-        coll += ", ncclAllGather on the launch stream" if used_direct else ", through torch.distributed"
+        coll += ", RCCL's C API on the launch stream" if used_direct else ", through torch.distributed"
+    what = (f"one all-reduce (pre-multiplied sum, weight V_local / V) of the (P,3) means of the ranks' local joint gradients"
+            if exchange_mode == "all_reduce" else f"one all_gather_into_tensor of the ({vmax},P,3) joint gradients")
     strong = {"ideal_speedup": V / vmax,
               "api_step": {"one_gpu_ms_per_step": one_gpu_ms, "ms_per_step": ms, "speedup": one_gpu_ms / ms}}
     res = {
@@ -679,8 +735,8 @@ def run_sharded(args, torch, dist, dev, wl, world, rank):
         "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": wl["name"], "views_total": V, "views_on_rank0": len(local), "P": P, "C": C, "W": W, "H": H,
-                   "parallelism": f"views sharded v % {world} over {world} ranks; one all_gather_into_tensor ({coll}) of the "
-                                  f"({vmax},P,3) joint gradients per step",
+                   "parallelism": f"views sharded v % {world} over {world} ranks; {what} per step ({coll})",
+                   "exchange": exchange_mode,
                    "path": "C ABI sks_forward + sks_backward, eager launches"},
         # the SAME 31-view step on one GPU alone, measured in this run (all ranks side by side, no communication): the
         # reference point for this line's `value` (the N = 1 line of bench.py times a different workload, BASELINE configs[1])

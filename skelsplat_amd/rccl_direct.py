@@ -30,6 +30,13 @@ def _load():
     lib.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _UniqueId, ctypes.c_int]
     lib.ncclAllGather.restype = ctypes.c_int
     lib.ncclAllGather.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    lib.ncclAllReduce.restype = ctypes.c_int
+    lib.ncclAllReduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                  ctypes.c_void_p]
+    lib.ncclRedOpCreatePreMulSum.restype = ctypes.c_int
+    lib.ncclRedOpCreatePreMulSum.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    lib.ncclRedOpDestroy.restype = ctypes.c_int
+    lib.ncclRedOpDestroy.argtypes = [ctypes.c_int, ctypes.c_void_p]
     lib.ncclCommDestroy.restype = ctypes.c_int
     lib.ncclCommDestroy.argtypes = [ctypes.c_void_p]
     lib.ncclGetErrorString.restype = ctypes.c_char_p
@@ -42,6 +49,7 @@ class DirectGather:
 
     def __init__(self, lib, comm, world, device):
         self.lib, self.comm, self.world, self.device = lib, comm, world, device
+        self._ops = {}     # weight -> ncclRedOp_t of all_reduce_weighted
 
     @classmethod
     def create(cls, device, group=None):
@@ -114,8 +122,32 @@ class DirectGather:
         if rc:
             raise RuntimeError("ncclAllGather: " + self.lib.ncclGetErrorString(rc).decode())
 
+    def all_reduce_weighted(self, out, inp, weight):
+        """out = sum over the ranks of weight_r * inp_r (every rank its own weight), one collective on the current stream:
+        ncclAllReduce with a pre-multiplied sum (ncclRedOpCreatePreMulSum, the scalar a host immediate).  With inp_r = the
+        mean of a rank's V_r local per-view gradients and weight_r = V_r / V this is the mean over all V views
+        (train.py:215-217) without gathering the per-view rows."""
+        if out.shape != inp.shape or not out.is_contiguous() or not inp.is_contiguous() or out.dtype != torch.float32 \
+                or inp.dtype != torch.float32:
+            raise ValueError("DirectGather.all_reduce_weighted: contiguous fp32 tensors of one shape")
+        w = float(weight)
+        op = self._ops.get(w)
+        if op is None:
+            opv, scalar = ctypes.c_int(), ctypes.c_float(w)
+            rc = self.lib.ncclRedOpCreatePreMulSum(ctypes.byref(opv), ctypes.byref(scalar), NCCL_FLOAT, 1, self.comm)   # 1 = ncclScalarHostImmediate
+            if rc:
+                raise RuntimeError("ncclRedOpCreatePreMulSum: " + self.lib.ncclGetErrorString(rc).decode())
+            op = self._ops[w] = opv.value
+        rc = self.lib.ncclAllReduce(inp.data_ptr(), out.data_ptr(), inp.numel(), NCCL_FLOAT, op, self.comm,
+                                    torch._C._cuda_getCurrentRawStream(self.device.index))
+        if rc:
+            raise RuntimeError("ncclAllReduce: " + self.lib.ncclGetErrorString(rc).decode())
+
     def destroy(self):
         _COMMS.pop(getattr(self, "_key", None), None)
+        for op in self._ops.values():
+            self.lib.ncclRedOpDestroy(op, self.comm)
+        self._ops = {}
         if self.comm:
             self.lib.ncclCommDestroy(self.comm)
             self.comm = None

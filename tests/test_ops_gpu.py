@@ -710,6 +710,13 @@ def test_direct_rccl_gather_equals_torch_distributed(device, rccl_world1):
     assert torch.equal(a, inp) and torch.equal(b, inp)
     with pytest.raises(ValueError):
         dg.all_gather_into_tensor(torch.empty(5, device=device), inp)
+    # the weighted all-reduce (pre-multiplied sum): with one rank, out = weight * inp; the op of a weight is built once
+    m, out = torch.randn((19, 3), device=device), torch.empty((19, 3), device=device)
+    for w in (4.0 / 31.0, 1.0, 4.0 / 31.0):
+        dg.all_reduce_weighted(out, m, w)
+        torch.cuda.synchronize()
+        assert torch.allclose(out, m * w, rtol=1e-6, atol=0)
+    assert len(dg._ops) == 2
     os.environ["SKS_RCCL_DIRECT"] = "0"
     try:
         dg.destroy()
