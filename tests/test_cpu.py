@@ -606,3 +606,18 @@ def test_bench_starts_its_own_launcher_for_n_gpus(monkeypatch):
     assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[-6:] == ["--gpus", "4", "--steps", "9", "--warmup", "2"] and cmd[-7].endswith("bench.py")
+
+
+def test_direct_rccl_exchange_is_off_without_rccl():
+    """skelsplat_amd.rccl_direct only engages on an RCCL ("nccl") process group: without one -- no process group at all, or
+    gloo (the CPU tests, the single-device test mode of bench.py) -- create() is None and the callers use torch.distributed."""
+    import torch.distributed as dist
+    from skelsplat_amd.rccl_direct import DirectGather
+    assert DirectGather.create(torch.device("cpu")) is None          # no process group
+    import os
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(29800 + os.getpid() % 1000)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        assert DirectGather.create(torch.device("cpu")) is None      # gloo
+    finally:
+        dist.destroy_process_group()
