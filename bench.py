@@ -276,8 +276,8 @@ def run_single(args, torch, dev, wl):
     assert torch.isfinite(out).all()
     res = {
         "metric": METRIC, "value": V * args.steps / dt, "unit": "views/s", "n_gpus": 1, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": wl["name"], "views_per_step": V, "P": P, "C": C, "W": W, "H": H, "parallelism": "single GPU",
                    "path": "C ABI sks_forward + sks_backward (incl. the mean over the views), eager launches, outputs in a "
                            "reused workspace"},
