@@ -265,12 +265,17 @@ def run_single(args, torch, dev, wl):
         # pair is stamped from the kernel's own dispatch, on the launch stream).  A bracketed step costs ~13 us of queue
         # time (measured: 68.4 us per step without, 69.7 bracketing every 8th, 74-80 every 2nd, 82-85 every step), so the
         # sample is 5 .. 25 launches: every 8th step at the default 200 steps, every 4th at 20
-        _lib.prof_enable(True, every=int(os.environ.get("SKS_PROF_EVERY", "0")) or prof_stride(args.steps))
+        # ... and only the forward compositor (the roofline's kernel) inside the timed region
+        _lib.prof_enable(True, every=int(os.environ.get("SKS_PROF_EVERY", "0")) or prof_stride(args.steps), kinds=(0,))
         _lib.prof_read(0), _lib.prof_read(1)
     dt, out = timed(step, args.steps, 0, sync)
     pf = pb = None
     if prof:
         pf = _lib.prof_read_quantiles(0)
+        _lib.prof_enable(True, every=1, kinds=(1,))     # the backward compositor: a few untimed steps behind the timed region
+        for _ in range(10):
+            step()
+        sync()
         pb = _lib.prof_read_quantiles(1)
         _lib.prof_enable(False)
     assert torch.isfinite(out).all()

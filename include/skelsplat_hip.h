@@ -288,8 +288,9 @@ int sks_loop_fused_step(int V, int P, int C, int W, int H, const float* viewmatr
 
 /* Measurement hook used by bench.py (no reference counterpart; state per HOST THREAD, like the error text): while enabled, the dominant kernel of sks_forward
  * (kind 0: forward compositor) and of sks_backward (kind 1: backward compositor) is bracketed by hipEvents recorded
- * on the caller's stream.  on = 1: every launch; on = n > 1: every n-th launch of each kind (an event pair costs ~3 us of
- * queue time, so sampling keeps the measured loop undisturbed).  sks_prof_read waits for the recorded events, returns
+ * on the caller's stream (the small path's kernels carry the pair on their own dispatch, hipExtLaunchKernelGGL).  The low 16
+ * bits of `on`: 1 = every launch, n > 1 = every n-th launch of each kind (a bracketed launch costs ~6 us of queue time, so
+ * sampling keeps the measured loop undisturbed); bits 16-17: kinds to leave OUT (bit 16: kind 0, bit 17: kind 1).  sks_prof_read waits for the recorded events, returns
  * the summed kernel time in milliseconds and the number of BRACKETED launches since the last read, and resets them. */
 int sks_prof_enable(int on);
 int sks_prof_read(int kind, double* total_ms, long long* launches);

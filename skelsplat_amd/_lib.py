@@ -109,9 +109,11 @@ def farray(vals):
     return (C.c_float * len(vals))(*[float(v) for v in vals])
 
 
-def prof_enable(on, every=1):
-    """Bracket the forward / backward compositor launches with hipEvents (every `every`-th launch of each kind)."""
-    check(load().sks_prof_enable(max(1, int(every)) if on else 0), "sks_prof_enable")
+def prof_enable(on, every=1, kinds=(0, 1)):
+    """Bracket the forward (kind 0) / backward (kind 1) compositor launches with hipEvents: every `every`-th launch of each
+    kind in `kinds`."""
+    skip = sum(1 << (16 + k) for k in (0, 1) if k not in kinds)
+    check(load().sks_prof_enable((min(0xffff, max(1, int(every))) | skip) if on else 0), "sks_prof_enable")
 
 
 def prof_read_quantiles(kind):
