@@ -537,16 +537,14 @@ def extra_panoptic(args, torch, dev, sync):
 def extra_stress(args, torch, dev, sync):
     """BASELINE configs[4]: 256 skeletons (P = 4352, C = 17), 8 views @ 2048x2048, binned path."""
     import numpy as np
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import util
     from skelsplat_amd import _lib
     from skelsplat_amd import rasterizer as R
+    from skelsplat_amd.scene import stress_scene
     V, C, H, W = 8, 17, 2048, 2048
-    big = util.make_case(seed=42, W=W, H=H, n_views=V, scale_log=3.0, n_skeletons=256, pitch=1500.0, ring=20000.0,
-                         fxmul=2300.0 / (1145.0 * 2.048), onehot=True, opac=1.0)
+    sc, g = stress_scene(V, W=W, H=H)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    views = R.ViewBatch.from_cameras([cam.to(dev) for cam in big.cams])
-    params = (t(big.means), t(big.feat), t(big.opac), t(big.scales), t(big.quats))
+    views = R.ViewBatch.from_cameras([cam.to(dev) for cam in sc.cameras])
+    params = (t(g["means"]), t(g["feat"]), t(g["opac"]), t(g["scales"]), t(g["quats"]))
     dL = torch.randn((V, C, H, W), device=dev)
     ws = R.Workspace()
 

@@ -192,6 +192,31 @@ class SyntheticScene:
         self.spatial_lr_scale = cameras_extent(self.cameras)
 
 
+def random_gaussian_params(scene, seed, scale_log=4.0, rand_rot=True, opac=None, onehot=False):
+    """Seeded rasterizer inputs for `scene`'s points that exercise every term (tests, the stress benchmark): anisotropic
+    scales exp(N(scale_log, 0.3)), random unit quaternions (or identity), opacities U(0.3, 1) (or a constant), features
+    one-hot by joint index (+ U(0, 0.1) on every channel unless `onehot`).  numpy fp32 arrays: means (P,3), scales (P,3),
+    quats (P,4), opac (P,1), feat (P,C)."""
+    rng = np.random.default_rng(seed + 100)
+    P, C = scene.n_points, scene.n_joints
+    out = {"means": scene.pose_3d_init.astype(np.float32)}
+    out["scales"] = np.exp(rng.normal(scale_log, 0.3, (P, 3))).astype(np.float32)
+    q = rng.normal(0, 1, (P, 4)) if rand_rot else np.tile([1.0, 0, 0, 0], (P, 1))
+    out["quats"] = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
+    out["opac"] = (np.full((P, 1), opac, np.float32) if opac is not None else rng.uniform(0.3, 1.0, (P, 1)).astype(np.float32))
+    eye = np.eye(C, dtype=np.float32)[np.arange(P) % C]
+    out["feat"] = eye if onehot else (eye + 0.1 * rng.uniform(0, 1, (P, C))).astype(np.float32)
+    out["_rng"] = rng      # (callers that draw more -- upstream gradients -- continue the same stream)
+    return out
+
+
+def stress_scene(n_views=8, seed=42, W=2048, H=2048):
+    """BASELINE configs[4]: 256 skeletons on a 16 x 16 grid of 1 500 mm pitch (P = 4 352, C = 17), ring cameras at 20 m,
+    fx = fy = 2 300, one-hot features, opacity 1.  Returns (scene, params dict of random_gaussian_params)."""
+    sc = SyntheticScene("h36m", n_views=n_views, seed=seed, W=W, H=H, ring=20000.0, fx=2300.0, n_skeletons=256, pitch=1500.0)
+    return sc, random_gaussian_params(sc, seed, scale_log=3.0, onehot=True, opac=1.0)
+
+
 # ------------------------------------------------------------------------------------------------------------
 # Gaussian parameter container (reference: scene/gaussian_model.py:32-47, 102-131, 149-200, 203-248)
 # ------------------------------------------------------------------------------------------------------------

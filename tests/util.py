@@ -16,18 +16,13 @@ def make_case(seed, W, H, dataset="h36m", n_views=2, scale_log=4.0, rand_rot=Tru
     """Skeleton(s) seen by `n_views` ring cameras; anisotropic random covariances so splats overlap and saturate."""
     sc = SyntheticScene(dataset, n_views=n_views, seed=seed, W=W, H=H, ring=ring,
                         fx=1145.0 * (W / 1000) * fxmul, n_skeletons=n_skeletons, pitch=pitch)
-    rng = np.random.default_rng(seed + 100)
+    from skelsplat_amd.scene import random_gaussian_params
+    g = random_gaussian_params(sc, seed, scale_log=scale_log, rand_rot=rand_rot, opac=opac, onehot=onehot)
+    rng = g["_rng"]
     c = Case()
     c.scene = sc
     c.W, c.H, c.P, c.C = W, H, sc.n_points, sc.n_joints
-    c.means = sc.pose_3d_init.astype(np.float32)
-    c.scales = np.exp(rng.normal(scale_log, 0.3, (c.P, 3))).astype(np.float32)
-    q = rng.normal(0, 1, (c.P, 4)) if rand_rot else np.tile([1.0, 0, 0, 0], (c.P, 1))
-    c.quats = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
-    c.opac = (np.full((c.P, 1), opac, np.float32) if opac is not None
-              else rng.uniform(0.3, 1.0, (c.P, 1)).astype(np.float32))
-    eye = np.eye(c.C, dtype=np.float32)[np.arange(c.P) % c.C]
-    c.feat = eye if onehot else (eye + 0.1 * rng.uniform(0, 1, (c.P, c.C))).astype(np.float32)
+    c.means, c.scales, c.quats, c.opac, c.feat = g["means"], g["scales"], g["quats"], g["opac"], g["feat"]
     c.cams = sc.cameras
     c.ocams = [orc.Cam(W, H, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5),
                        cam.world_view_transform.numpy(), cam.full_proj_transform.numpy()) for cam in c.cams]

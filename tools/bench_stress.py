@@ -3,22 +3,22 @@
 Informational -- bench.py's headline stays the H36M configuration."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
 import numpy as np, torch
-import util
 from skelsplat_amd import rasterizer as R, _lib
+from skelsplat_amd.scene import stress_scene
 
 dev = torch.device("cuda", 0)
 t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev) if a is not None else None
 V = int(os.environ.get("V", "8"))
-big = util.make_case(seed=42, W=2048, H=2048, n_views=V, scale_log=3.0, n_skeletons=256, pitch=1500.0, ring=20000.0,
-                     fxmul=2300.0 / (1145.0 * 2.048), onehot=True, opac=1.0)
-views = R.ViewBatch.from_cameras([cam.to(dev) for cam in big.cams])
-args = (t(big.means), t(big.feat), t(big.opac), t(big.scales), t(big.quats), None)
+sc, g = stress_scene(V)
+P = sc.n_points
+views = R.ViewBatch.from_cameras([cam.to(dev) for cam in sc.cameras])
+args = (t(g["means"]), t(g["feat"]), t(g["opac"]), t(g["scales"]), t(g["quats"]), None)
 C, H, W = 17, 2048, 2048
 dL = torch.randn((V, C, H, W), device=dev)
 color, inv, radii, st = R.forward_views(views, *args, bin_capacity=400000)
-print("P", big.P, "num_rendered per view", st.num_rendered_dev[:V].cpu().tolist(), "visible", int((radii > 0).sum()) / V)
+print("P", P, "num_rendered per view", st.num_rendered_dev[:V].cpu().tolist(), "visible", int((radii > 0).sum()) / V)
 for name, fn in (("forward", lambda: R.forward_views(views, *args, bin_capacity=400000)),
                  ("backward", lambda: R.backward_views(st, *args, dL)),
                  ("fwd+bwd", lambda: R.backward_views(R.forward_views(views, *args, bin_capacity=400000)[3], *args, dL))):
@@ -35,7 +35,7 @@ for name, fn in (("forward", lambda: R.forward_views(views, *args, bin_capacity=
 # showed k_render_bwd_binned "43 .. 337 us" for exactly that reason: 43 = all tiles empty, 337 = the stress scene)
 if "--floor" not in sys.argv:
     sys.exit(0)
-far = (torch.tensor([[0.0, 0.0, 1e9]], device=dev).repeat(big.P, 1),) + args[1:]
+far = (torch.tensor([[0.0, 0.0, 1e9]], device=dev).repeat(P, 1),) + args[1:]
 c2, i2, r2, st2 = R.forward_views(views, *far, force_binned=True, bin_capacity=400000)
 for name, fn in (("forward, all tiles empty", lambda: R.forward_views(views, *far, force_binned=True, bin_capacity=400000)),
                  ("backward, all tiles empty", lambda: R.backward_views(st2, *far, dL))):
