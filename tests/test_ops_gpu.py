@@ -82,6 +82,26 @@ def test_fused_ssim_matches_conv2d_ssim(device, shape, padding):
         assert abs(fused_ssim(img1.detach(), img2, padding=padding, train=False).item() - val.item()) <= 1e-7
 
 
+def test_fused_ssim_wrapper_reproduces_the_reference_wrapper(device):
+    """tests/golden/reference_ssim.npz: the reference's own fused_ssim/__init__.py executed over its own PyTorch SSIM
+    (tests/golden/make_golden_ssim.py): constants, "same" / "valid", train / inference, the mean over the cropped map and
+    the gradient that reaches img1 -- value 1e-5, gradient 1e-4 of its scale (the kernels keep fp32 sums in another order)."""
+    from fused_ssim import fused_ssim, allowed_padding
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_ssim.npz"))
+    assert list(allowed_padding) == G["allowed_padding"].tolist()
+    for tag in ("a", "b", "c"):
+        img2 = torch.tensor(G[tag + "_img2"], device=device)
+        for padding in ("same", "valid"):
+            for mode in ("train", "infer"):
+                x = torch.tensor(G[tag + "_img1"], device=device).requires_grad_(True)
+                val = fused_ssim(x, img2, padding=padding, train=mode == "train")
+                key = f"{tag}_{padding}_{mode}"
+                assert abs(val.item() - float(G[key + "_value"])) <= 1e-5 * abs(float(G[key + "_value"])), key
+                if mode == "train":
+                    (3.0 * val).backward()
+                    util.assert_close(key, x.grad.cpu().numpy(), G[key + "_grad"], rtol=1e-3, atol_scale=1e-4)
+
+
 @pytest.mark.parametrize("min_blocks", ["1", "40"], ids=["strips-of-8", "strips-of-2"])
 def test_fused_ssim_long_strips(device, min_blocks, monkeypatch):
     """The kernels walk strips of tiles down the image and carry 10 filtered rows from tile to tile; small test images
