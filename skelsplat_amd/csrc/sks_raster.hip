@@ -204,14 +204,14 @@ void sks_set_error_(const char* msg)  // used by the other translation units of 
 {
     snprintf(g_err, sizeof(g_err), "%s", msg);
 }
-int sks_version(void) { return 5; }
+int sks_version(void) { return 6; }
 
 int sks_scratch_bytes(int V, int P, int C, int W, int H, size_t bin_capacity, size_t* geom, size_t* binning, size_t* accum)
 {
     if (int rc = check_common(V, P, C, W, H)) return rc;
     const int NT = ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
     if (geom) *geom = geom_bytes(V, P > 0 ? P : 1, W, H);
-    if (binning) *binning = bin_bytes(V, NT, bin_capacity);
+    if (binning) *binning = bin_bytes(V, P, NT, bin_capacity);
     if (accum) *accum = (size_t)V * (P > 0 ? P : 1) * BWD_SPLITS * (NACC + C) * sizeof(float);
     return 0;
 }
@@ -248,11 +248,15 @@ int sks_forward(int V, int P, int C, int W, int H, const float* viewmatrix, cons
     Bin b{};
     if (!small) {
         if (!binning) return fail(-2, "binned path needs a binning buffer");
-        b = bin_from(binning, V, NT, bin_capacity);
+        if (bin_capacity < 1) return fail(-1, "binned path needs bin_capacity >= 1");
+        b = bin_from(binning, V, P, NT, bin_capacity);
+        // header (overflow flag, long-tile counter) + the per-tile counters k_geom_fwd adds to: one contiguous clear
+        HIP_TRY(hipMemsetAsync(b.hdr, 0, 256 + (size_t)V * NT * 4, st));
     }
     hipLaunchKernelGGL(k_geom_fwd, dim3((P + 255) / 256, V), dim3(256), 0, st, P, W, H, vt, viewmatrix, projmatrix,
                        means3D, opacities, scales, rotations, cov3D_precomp, scale_modifier, flags, g, radii, 0,
-                       small ? (uint32_t*)nullptr : b.count, small ? 0u : (unsigned)((size_t)V * NT), small ? (int*)nullptr : b.nrend + V);
+                       small ? (uint32_t*)nullptr : b.count, small ? (uint32_t*)nullptr : b.touched, features, C,
+                       small ? (uint32_t*)nullptr : b.fmask);
     STAGE_CHECK("geometry");
 
     FwdArgs a{ P, C, W, H, flags, g, features, out_color, out_invdepth, final_T, n_contrib, composite_slots(flags, V, P),
@@ -271,16 +275,18 @@ int sks_forward(int V, int P, int C, int W, int H, const float* viewmatrix, cons
         STAGE_CHECK("render(small)");
         return 0;
     }
-    hipLaunchKernelGGL(k_bin_count, dim3((P * BIN_SUB + 255) / 256, V), dim3(256), 0, st, P, NT, gx, g.rect, b.count);
-    hipLaunchKernelGGL(k_bin_scan, dim3(V), dim3(1024), 0, st, NT, b.count, b.cursor, b.ranges, b.nrend, V, num_rendered_dev);
-    hipLaunchKernelGGL(k_bin_scatter, dim3((P * BIN_SUB + 255) / 256, V), dim3(256), 0, st, P, NT, gx, bin_capacity, g.rect, g.xyd,
-                       b.cursor, b.keys, b.nrend + V);
-    hipLaunchKernelGGL(k_bin_sort, dim3((NT + 3) / 4, V), dim3(256), 0, st, NT, bin_capacity, b.ranges, b.keys);
-    STAGE_CHECK("binning");
-    BinView bv{ b.ranges, b.keys, bin_capacity, NT, b.aux };
     uint32_t* cover = geom_cover_ptr(geom, V, P);
     const int cw = cover_cw(W);
-    hipLaunchKernelGGL(k_bin_cover, dim3(gy, V), dim3(64), 0, st, NT, gx, cw, bin_capacity, b.ranges, cover);
+    {
+        const int bpc = gx >= SCAN_T * 8 ? 1 : (SCAN_T * 8) / gx;   // whole tile bands per scan block (<= SCAN_T * SCAN_IPT tiles)
+        const int nchunk_t = (gy + bpc - 1) / bpc, nchunk_g = (P + SCAN_G - 1) / SCAN_G;
+        hipLaunchKernelGGL(k_bin_scan, dim3(nchunk_t + nchunk_g, V), dim3(SCAN_T), (size_t)bpc * cw * 4, st, P, gx, gy, cw, bpc,
+                           nchunk_t, bin_capacity, b, cover, num_rendered_dev, V);
+    }
+    hipLaunchKernelGGL(k_bin_scatter, dim3((P * BIN_SUB + 255) / 256, V), dim3(256), 0, st, P, NT, gx, bin_capacity, g, b);
+    hipLaunchKernelGGL(k_bin_sort_long, dim3(SORT_LONG_BLOCKS), dim3(256), 0, st, V, P, NT, gx, bin_capacity, g, b);
+    STAGE_CHECK("binning");
+    BinView bv = bin_view(b, NT, bin_capacity);
     {
         ProfScope prof(0, st);
         switch (cg) {
@@ -329,18 +335,29 @@ int sks_backward(int V, int P, int C, int W, int H, const float* viewmatrix, con
         STAGE_CHECK("render-backward(small)");
     } else {
         if (!binning) return fail(-2, "binned path needs the forward's binning buffer");
-        HIP_TRY(hipMemsetAsync(accum, 0, (size_t)V * P * (NACC + C) * sizeof(float), st));  // atomics target
-        Bin b = bin_from(const_cast<void*>(binning), V, NT, bin_capacity);
-        BinView bv{ b.ranges, b.keys, bin_capacity, NT, b.aux };
-        dim3 grid(gx, gy, V);
+        Bin b = bin_from(const_cast<void*>(binning), V, P, NT, bin_capacity);
+        BinView bv = bin_view(b, NT, bin_capacity);
+        // the per-Gaussian sums go through the slot rows of the binning scratch (plain stores, every row written); only the
+        // feature gradient, when wanted, is accumulated with atomics
+        if (dfeat) HIP_TRY(hipMemsetAsync(accum, 0, (size_t)V * P * (NACC + C) * sizeof(float), st));
+        dim3 grid((gx + 3) / 4, gy, V);
+        const bool extra = bg != nullptr || dL_dout_invdepth != nullptr;
         ProfScope prof(1, st);
-        if (dfeat) hipLaunchKernelGGL((k_render_bwd_binned<true>), grid, dim3(256), 0, st, a, bv);
-        else hipLaunchKernelGGL((k_render_bwd_binned<false>), grid, dim3(256), 0, st, a, bv);
+        if (dfeat) hipLaunchKernelGGL((k_render_bwd_tile<true, true>), grid, dim3(256), 0, st, a, bv, gx);
+        else if (extra) hipLaunchKernelGGL((k_render_bwd_tile<false, true>), grid, dim3(256), 0, st, a, bv, gx);
+        else hipLaunchKernelGGL((k_render_bwd_tile<false, false>), grid, dim3(256), 0, st, a, bv, gx);
         STAGE_CHECK("render-backward(binned)");
     }
     GeomBwdArgs ga{ P, C, W, H, flags, viewmatrix, projmatrix, means3D, opacities, scales, rotations, cov3D_precomp,
-                    scale_modifier, radii, (const float*)accum, small ? BWD_SPLITS : 1, nullptr, nullptr, nullptr, dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dscales,
+                    scale_modifier, radii, (const float*)accum, small ? BWD_SPLITS : 0, nullptr, nullptr, nullptr, dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dscales,
                     dL_drotations, dL_dcov3D, dL_dfeatures };
+    if (!small) {
+        Bin b = bin_from(const_cast<void*>(binning), V, P, NT, bin_capacity);
+        ga.rect = g.rect;
+        ga.goff = b.goff;
+        ga.part = b.part;
+        ga.cap = bin_capacity;
+    }
     if (dL_dmeans3D_mean && V * P <= 256) {
         hipLaunchKernelGGL(k_geom_bwd_all, dim3(1), dim3(256), 0, st, ga, vt, V, dL_dmeans3D_mean);
     } else {
@@ -563,10 +580,12 @@ int sks_export_lists(int V, int W, int H, const void* binning, size_t bin_capaci
 {
     if (!binning || !point_list || !ranges) return fail(-2, "missing required pointer");
     const int NT = ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
-    Bin b = bin_from(const_cast<void*>(binning), V, NT, bin_capacity);
+    Bin b = bin_from(const_cast<void*>(binning), V, 1, NT, bin_capacity);   // (nothing per Gaussian is read: its arrays come last)
     const size_t m = bin_capacity > (size_t)NT ? bin_capacity : (size_t)NT;
     hipLaunchKernelGGL(k_export_lists, dim3((unsigned)((m + 255) / 256), V), dim3(256), 0, (hipStream_t)stream, NT,
-                       bin_capacity, b.ranges, b.keys, b.nrend, point_list, ranges);
+                       bin_capacity, b.ranges, b.nrend, point_list, ranges);
+    hipLaunchKernelGGL(k_export_sorted, dim3((NT + 3) / 4, V), dim3(256), 0, (hipStream_t)stream, bin_view(b, NT, bin_capacity),
+                       point_list);
     HIP_TRY(hipGetLastError());
     return 0;
 }
