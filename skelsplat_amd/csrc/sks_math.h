@@ -61,6 +61,28 @@ __device__ __forceinline__ float expf_fixed(float x)
     return __int_as_float(__float_as_int(p) + ki * (1 << 23));
 }
 
+// The same polynomial without the two range branches, for compositor loops that only use the result where power <= 0 and
+// reject alpha < 1/255: x is clamped at -80 (exp(-80) = 1.8e-35 is rejected like the 0 expf_fixed returns below -80), x > 0
+// never reaches a use.  Bit-identical to expf_fixed on [-80, 0].
+__device__ __forceinline__ float expf_fixed_neg(float x)
+{
+    x = fmaxf(x, -80.0f);
+    float t = x * 1.44269504088896341f;
+    float k = __builtin_rintf(t);
+    float r = __builtin_fmaf(k, -0.693145751953125f, x);
+    r = __builtin_fmaf(k, -1.42860682030941723e-6f, r);
+    float p = 1.98412698412698413e-4f;
+    p = __builtin_fmaf(p, r, 1.38888888888888894e-3f);
+    p = __builtin_fmaf(p, r, 8.33333333333333322e-3f);
+    p = __builtin_fmaf(p, r, 4.16666666666666644e-2f);
+    p = __builtin_fmaf(p, r, 1.66666666666666657e-1f);
+    p = __builtin_fmaf(p, r, 0.5f);
+    p = __builtin_fmaf(p, r, 1.0f);
+    p = __builtin_fmaf(p, r, 1.0f);
+    int ki = (int)k;
+    return __int_as_float(__float_as_int(p) + ki * (1 << 23));
+}
+
 // auxiliary.h:40-43 -- double arithmetic as written in the reference
 __device__ __forceinline__ float ndc2Pix(float v, int S) { return (float)(((v + 1.0) * S - 1.0) * 0.5); }
 
@@ -216,8 +238,18 @@ __device__ __forceinline__ float wave_sum8(const float (&v)[8])
     // lane i now holds value (i & 3) of x[0] (values 0..3) / x[1] (values 4..7), summed over its quad
     float z = (b2 ? x[1] : x[0]) + dpp_move<0x124>(b2 ? x[0] : x[1]);   // from lane i - 4 (mod 16): the other bit-2 class
     z += dpp_move<0x128>(z);                                             // from lane i - 8 (mod 16): the row's other two quads
-    z += __shfl_xor(z, 16, 64);
-    z += __shfl_xor(z, 32, 64);
+    // the other rows: gfx950's row / half swaps (VALU; a __shfl_xor is a ds_bpermute: an LDS round trip in the middle of the
+    // caller's loop).  v_permlane16_swap exchanges the odd rows of its first operand with the even rows of its second,
+    // v_permlane32_swap the upper half of the first with the lower half of the second: fed z twice, the two results are
+    // (z of the even / lower partner, z of the odd / upper partner) in every lane -- their sum is z + z[lane ^ 16 / 32].
+    {
+        const auto q = __builtin_amdgcn_permlane16_swap(__float_as_uint(z), __float_as_uint(z), false, false);
+        z = __uint_as_float(q[0]) + __uint_as_float(q[1]);
+    }
+    {
+        const auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(z), __float_as_uint(z), false, false);
+        z = __uint_as_float(q[0]) + __uint_as_float(q[1]);
+    }
     return z;
 }
 

@@ -138,6 +138,21 @@ void launch_fwd_binned(const FwdArgs& a, const BinView& bv, int V, int gx, int g
     }
 }
 
+// workgroups of the binned backward: a fixed number per compute unit of the current device, each walking the tile list
+inline int bwd_tile_blocks()
+{
+    static const int n = [] {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            hipDeviceProp_t pr;
+            if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount;
+        }
+        const char* e = getenv("SKS_BWD_TILE_BLOCKS");   // tuning sweeps only
+        return (e && atoi(e) > 0) ? atoi(e) : cus * BWD_TILE_BLOCKS_PER_CU;
+    }();
+    return n;
+}
+
 // workgroups per (view, Gaussian) of k_render_bwd_wave (they share the BWD_SPLITS partial-sum slots; see the kernel)
 inline int bwd_wave_groups(int V, int P, unsigned flags)
 {
@@ -256,7 +271,7 @@ int sks_forward(int V, int P, int C, int W, int H, const float* viewmatrix, cons
     hipLaunchKernelGGL(k_geom_fwd, dim3((P + 255) / 256, V), dim3(256), 0, st, P, W, H, vt, viewmatrix, projmatrix,
                        means3D, opacities, scales, rotations, cov3D_precomp, scale_modifier, flags, g, radii, 0,
                        small ? (uint32_t*)nullptr : b.count, small ? (uint32_t*)nullptr : b.touched, features, C,
-                       small ? (uint32_t*)nullptr : b.fmask);
+                       small ? (uint2*)nullptr : b.fmask);
     STAGE_CHECK("geometry");
 
     FwdArgs a{ P, C, W, H, flags, g, features, out_color, out_invdepth, final_T, n_contrib, composite_slots(flags, V, P),
@@ -340,12 +355,13 @@ int sks_backward(int V, int P, int C, int W, int H, const float* viewmatrix, con
         // the per-Gaussian sums go through the slot rows of the binning scratch (plain stores, every row written); only the
         // feature gradient, when wanted, is accumulated with atomics
         if (dfeat) HIP_TRY(hipMemsetAsync(accum, 0, (size_t)V * P * (NACC + C) * sizeof(float), st));
-        dim3 grid((gx + 3) / 4, gy, V);
+        dim3 grid(bwd_tile_blocks());
+        const unsigned magic_nt = (unsigned)(((1ull << 32) + (unsigned)NT - 1) / (unsigned)NT), magic_gx = (unsigned)(((1ull << 32) + (unsigned)gx - 1) / (unsigned)gx);
         const bool extra = bg != nullptr || dL_dout_invdepth != nullptr;
         ProfScope prof(1, st);
-        if (dfeat) hipLaunchKernelGGL((k_render_bwd_tile<true, true>), grid, dim3(256), 0, st, a, bv, gx);
-        else if (extra) hipLaunchKernelGGL((k_render_bwd_tile<false, true>), grid, dim3(256), 0, st, a, bv, gx);
-        else hipLaunchKernelGGL((k_render_bwd_tile<false, false>), grid, dim3(256), 0, st, a, bv, gx);
+        if (dfeat) hipLaunchKernelGGL((k_render_bwd_tile<true, true>), grid, dim3(256), 0, st, a, bv, gx, V, magic_nt, magic_gx, b.tlist, b.hdr);
+        else if (extra) hipLaunchKernelGGL((k_render_bwd_tile<false, true>), grid, dim3(256), 0, st, a, bv, gx, V, magic_nt, magic_gx, b.tlist, b.hdr);
+        else hipLaunchKernelGGL((k_render_bwd_tile<false, false>), grid, dim3(256), 0, st, a, bv, gx, V, magic_nt, magic_gx, b.tlist, b.hdr);
         STAGE_CHECK("render-backward(binned)");
     }
     GeomBwdArgs ga{ P, C, W, H, flags, viewmatrix, projmatrix, means3D, opacities, scales, rotations, cov3D_precomp,
@@ -358,7 +374,7 @@ int sks_backward(int V, int P, int C, int W, int H, const float* viewmatrix, con
         ga.part = b.part;
         ga.cap = bin_capacity;
     }
-    if (dL_dmeans3D_mean && V * P <= 256) {
+    if (dL_dmeans3D_mean && V * P <= 256 && small) {   // (the binned path's k_geom_bwd also re-arms the work cursors)
         hipLaunchKernelGGL(k_geom_bwd_all, dim3(1), dim3(256), 0, st, ga, vt, V, dL_dmeans3D_mean);
     } else {
         hipLaunchKernelGGL(k_geom_bwd, dim3((P + 255) / 256, V), dim3(256), 0, st, ga, vt);
