@@ -48,6 +48,10 @@ extern "C" {
 #define SKS_RAW_PARAMS   32u   /* opacities / scales / rotations are the LEAF parameters (_opacity logits, _scaling
                                  log-scales, raw _rotation); sigmoid / exp / normalize (scene/gaussian_model.py:39-47)
                                  run inside the kernels (sks_geometry, sks_forward, sks_backward*) */
+#define SKS_BIN_CLEAN    64u    /* sks_forward, binned path: `binning` is as the previous sks_forward with the same V, W, H left it
+                                  (completed without error, nothing else written to it since): its per-tile counters are zero
+                                  again by then and the clearing launch in front of the call is skipped.  A caller that reuses
+                                  one buffer for every step sets it from the second call on; a fresh buffer must not carry it */
 #define SKS_FILL_LINEAR (1u << 21)  /* tuning/tests: forward fill blocks always in linear (pass-major) mode */
 #define SKS_FILL_ROWS (1u << 22)    /* tuning/tests: row-aligned fill blocks whenever W % 4 == 0 */
 /* bits 26..29: tuning, composite blocks per (view, Gaussian) of the small-path forward (0 = default 4) */

@@ -19,6 +19,7 @@ SKS_FORCE_BINNED = 4
 SKS_DEBUG_SYNC = 8
 SKS_NO_NT_STORES = 16
 SKS_RAW_PARAMS = 32
+SKS_BIN_CLEAN = 64
 SKS_SSIM_SCRATCH_BYTES = 64 * 8
 
 _vp, _i, _u, _f, _sz = C.c_void_p, C.c_int, C.c_uint, C.c_float, C.c_size_t

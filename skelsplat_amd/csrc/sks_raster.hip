@@ -266,12 +266,14 @@ int sks_forward(int V, int P, int C, int W, int H, const float* viewmatrix, cons
         if (bin_capacity < 1) return fail(-1, "binned path needs bin_capacity >= 1");
         b = bin_from(binning, V, P, NT, bin_capacity);
         // header (overflow flag, long-tile counter) + the per-tile counters k_geom_fwd adds to: one contiguous clear
-        HIP_TRY(hipMemsetAsync(b.hdr, 0, 256 + (size_t)V * NT * 4, st));
+        // (a buffer the previous forward left behind has them zero already: k_bin_scatter clears the counters once they have
+        // served, k_geom_fwd the header -- SKS_BIN_CLEAN)
+        if (!(flags & SKS_BIN_CLEAN)) HIP_TRY(hipMemsetAsync(b.hdr, 0, 256 + (size_t)V * NT * 4, st));
     }
     hipLaunchKernelGGL(k_geom_fwd, dim3((P + 255) / 256, V), dim3(256), 0, st, P, W, H, vt, viewmatrix, projmatrix,
                        means3D, opacities, scales, rotations, cov3D_precomp, scale_modifier, flags, g, radii, 0,
                        small ? (uint32_t*)nullptr : b.count, small ? (uint32_t*)nullptr : b.touched, features, C,
-                       small ? (uint2*)nullptr : b.fmask);
+                       small ? (uint2*)nullptr : b.fmask, small ? (uint32_t*)nullptr : b.hdr);
     STAGE_CHECK("geometry");
 
     FwdArgs a{ P, C, W, H, flags, g, features, out_color, out_invdepth, final_T, n_contrib, composite_slots(flags, V, P),
@@ -377,7 +379,8 @@ int sks_backward(int V, int P, int C, int W, int H, const float* viewmatrix, con
     if (dL_dmeans3D_mean && V * P <= 256 && small) {   // (the binned path's k_geom_bwd also re-arms the work cursors)
         hipLaunchKernelGGL(k_geom_bwd_all, dim3(1), dim3(256), 0, st, ga, vt, V, dL_dmeans3D_mean);
     } else {
-        hipLaunchKernelGGL(k_geom_bwd, dim3((P + 255) / 256, V), dim3(256), 0, st, ga, vt);
+        if (small) hipLaunchKernelGGL(k_geom_bwd, dim3((P + 255) / 256, V), dim3(256), 0, st, ga, vt);
+        else hipLaunchKernelGGL(k_geom_bwd_binned, dim3((P + GEOMB_G - 1) / GEOMB_G, V), dim3(256), 0, st, ga, vt);
         if (dL_dmeans3D_mean)
             hipLaunchKernelGGL(k_mean_views, dim3((3 * P + 255) / 256), dim3(256), 0, st, V, P, dL_dmeans3D, dL_dmeans3D_mean);
     }

@@ -199,7 +199,10 @@ def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotati
         plan = workspace._plans.get("fwd")
         if plan is not None and plan[0] == key:
             _, _views, args, dev_index, result, cap_check = plan
-            _lib.check(_replay(lib.sks_forward, args, dev_index), "sks_forward")
+            rc = _replay(lib.sks_forward, args, dev_index)
+            if rc != 0:
+                del workspace._plans["fwd"]     # (the recorded call promises a binning buffer a completed call left behind)
+            _lib.check(rc, "sks_forward")
             if cap_check is None:
                 return result
             nr, pcap, ckey = cap_check
@@ -299,6 +302,11 @@ def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotati
     if key is not None and all(sg is not False for sg in key[1:7]) and not torch.cuda.is_current_stream_capturing():
         # (the tensors the pointers belong to stay alive in `keep`; the views object is held so that its id stays its own)
         keep = (means3D, feat2, opacities, scales, rotations, cov3D_precomp)
+        if binned:
+            # the replayed call finds the binning buffer as this call leaves it: its tile counters are zero again, so the
+            # clearing launch in front of the binning kernels is skipped (include/skelsplat_hip.h: SKS_BIN_CLEAN)
+            args = list(args)
+            args[16] = flags | _lib.SKS_BIN_CLEAN
         workspace._plans["fwd"] = (key, (views, keep), args, dev.index, (color, invdepth, radii, st),
                                    (nrend[:V], cap, (dev.index, V, P, C, W, H)) if binned and check_capacity else None)
     return color, invdepth, radii, st
