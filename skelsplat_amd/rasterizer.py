@@ -199,6 +199,14 @@ def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotati
         plan = workspace._plans.get("fwd")
         if plan is not None and plan[0] == key:
             _, _views, args, dev_index, result, cap_check = plan
+            if cap_check is not None and check_capacity is not True:
+                try:
+                    _lazy_check(cap_check[2], cap_check[0], cap_check[1])     # the previous call's counts; re-arms the probe
+                except RuntimeError:
+                    # the recorded call holds the overflowed arena: drop it, so that the next call takes the validating path
+                    # and allocates the grown one (`_BIN_CAP_HINT`)
+                    del workspace._plans["fwd"]
+                    raise
             rc = _replay(lib.sks_forward, args, dev_index)
             if rc != 0:
                 del workspace._plans["fwd"]     # (the recorded call promises a binning buffer a completed call left behind)
@@ -207,18 +215,11 @@ def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotati
                 return result
             nr, pcap, ckey = cap_check
             if check_capacity is True:
-                if int(nr.max().item()) <= pcap:
+                if int(nr[:args[0]].max().item()) <= pcap:
                     return result
                 del workspace._plans["fwd"]     # the binning arena overflowed: the validating path below grows it and redoes
             else:
-                try:
-                    _lazy_probe(ckey, nr, pcap, args[0])
-                except RuntimeError:
-                    # the recorded call holds the overflowed arena: drop it, so that the next call takes the validating path
-                    # and allocates the grown one (`_BIN_CAP_HINT`)
-                    del workspace._plans["fwd"]
-                    raise
-                return result
+                return result     # (lazy: the counts of this call are looked at when the next one comes in, see above)
     if views.mixed:
         raise RuntimeError("the dense forward writes one (V,C,H,W) tensor: all views of the batch must share the image size")
     if means3D is None or means3D.dim() != 2 or means3D.shape[1] != 3:
@@ -262,7 +263,14 @@ def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotati
     radii = new("radii", (V, P), torch.int32)
     geom = new("geom", (gbytes,), torch.uint8)
     binning = new("binning", (bbytes,), torch.uint8) if binned else None
-    nrend = new("nrend", (V + 1,), torch.int32) if binned else None   # [0, V): written by k_bin_scan
+    cap_key = (dev.index, V, P, C, W, H)
+    lazy = binned and (check_capacity == "lazy" or (check_capacity == "auto" and cap_key in _BIN_CAP_SEEN))
+    if lazy:
+        # the pair counts go straight to pinned host memory (k_bin_scan stores them there: no copy launch, no event): they are
+        # looked at when the NEXT call of the shape comes in -- first the previous call's, which may raise
+        nrend = _lazy_check(cap_key, None, cap)
+    else:
+        nrend = new("nrend", (V + 1,), torch.int32) if binned else None   # [0, V): written by k_bin_scan
     final_T = torch.empty((V, H, W), dtype=torch.float32, device=dev) if want_aux else None
     n_contrib = torch.empty((V, H, W), dtype=torch.int32, device=dev) if want_aux else None
     args = [V, P, C, W, H, views.viewmatrix.data_ptr(), views.projmatrix.data_ptr(), views.tanfovx,
@@ -276,14 +284,10 @@ def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotati
         # blocking D2H copy between the scan and the duplication).  Here the arena is persistent and the count stays on
         # the device: check_capacity=True reads it back (exact: grow and redo when the arena was too small -- entries
         # beyond it were dropped); "lazy" (what "auto" does after it has sized the arena once per shape with a
-        # synchronous first call) leaves an asynchronous copy + event behind and looks at it when the NEXT call for the
-        # shape comes in -- no host synchronisation on the fast path; an overflow found that way grows the arena for the
-        # calls to come and raises, because the image that call produced was missing entries.
-        cap_key = (dev.index, V, P, C, W, H)
-        lazy = check_capacity == "lazy" or (check_capacity == "auto" and cap_key in _BIN_CAP_SEEN)
-        if lazy:
-            _lazy_probe(cap_key, nrend[:V], cap, V)
-        elif not lazy:
+        # synchronous first call) has the counts stored into pinned host memory and looks at them when the NEXT call for the
+        # shape comes in (_lazy_check) -- no host synchronisation, no copy launch on the fast path; an overflow found that way
+        # grows the arena for the calls to come and raises, because the image that call produced was missing entries.
+        if not lazy:
             need = int(nrend[:V].max().item())
             _BIN_CAP_SEEN.add(cap_key)
             if check_capacity == "auto" and need <= cap and bin_capacity_given is None:
@@ -302,42 +306,55 @@ def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotati
     if key is not None and all(sg is not False for sg in key[1:7]) and not torch.cuda.is_current_stream_capturing():
         # (the tensors the pointers belong to stay alive in `keep`; the views object is held so that its id stays its own)
         keep = (means3D, feat2, opacities, scales, rotations, cov3D_precomp)
+        cap_check = None
         if binned:
             # the replayed call finds the binning buffer as this call leaves it: its tile counters are zero again, so the
             # clearing launch in front of the binning kernels is skipped (include/skelsplat_hip.h: SKS_BIN_CLEAN)
             args = list(args)
             args[16] = flags | _lib.SKS_BIN_CLEAN
-        workspace._plans["fwd"] = (key, (views, keep), args, dev.index, (color, invdepth, radii, st),
-                                   (nrend[:V], cap, (dev.index, V, P, C, W, H)) if binned and check_capacity else None)
+            if check_capacity is True:
+                cap_check = (nrend, cap, cap_key)
+            elif check_capacity:
+                # replays are lazy calls: their counts go to the shape's pinned host buffer
+                host = nrend if lazy else _lazy_check(cap_key, None, cap)
+                args[23] = host.data_ptr()
+                cap_check = (host, cap, cap_key)
+        workspace._plans["fwd"] = (key, (views, keep), args, dev.index, (color, invdepth, radii, st), cap_check)
     return color, invdepth, radii, st
 
 
 _SCRATCH_BYTES = {}
 _BIN_CAP_HINT = {}     # (device, V, P, C, W, H) -> arena capacity learned from an overflow
 _BIN_CAP_SEEN = set()  # shapes whose arena a synchronous call has sized already ("auto" goes lazy after that)
-_BIN_PROBE = {}        # shape -> (pinned host counts, event, capacity) of the last lazy call
+_BIN_PROBE = {}        # shape -> (pinned host counts the lazy calls of the shape write, capacity of the last one)
 
 
-def _lazy_probe(cap_key, nrend, cap, V):
-    """Look at the previous lazy call's pair counts (see forward_views) and leave this call's behind."""
-    if torch.cuda.is_current_stream_capturing():
-        return
-    prev = _BIN_PROBE.pop(cap_key, None)
-    if prev is not None:
-        host, ev, pcap = prev
-        if not ev.query():
-            ev.synchronize()
-        pneed = int(host.max())
+def _lazy_check(cap_key, host, cap):
+    """The lazy capacity check (see forward_views).  Every shape has one pinned int32 buffer that k_bin_scan writes the pair
+    counts of a call into (device-visible host memory: a V-int store, no copy launch, no event).  Called in front of a call:
+    looks at what the previous call of the shape left there (waiting for it if it has not run yet), raises if that call's arena
+    was too small -- the arena has been grown for the calls to come --, re-arms the buffer (-1 = not written yet) and returns
+    it, to be handed to sks_forward as `num_rendered_dev`."""
+    V = cap_key[1]
+    prev = _BIN_PROBE.get(cap_key)
+    if host is None:
+        host = prev[0] if prev is not None else torch.full((V + 1,), -1, dtype=torch.int32).pin_memory()
+    capturing = torch.cuda.is_current_stream_capturing()
+    if prev is not None and prev[0] is host and not capturing:
+        pcap = prev[1]
+        if int(host[:V].min()) < 0:
+            torch.cuda.current_stream(cap_key[0]).synchronize()     # the previous call has not been through its scan yet
+        pneed = int(host[:V].max()) if int(host[:V].min()) >= 0 else -1     # (still unwritten: that call went elsewhere)
         if pneed > pcap:
             _BIN_CAP_HINT[cap_key] = int(pneed * 1.25) + 1024
+            del _BIN_PROBE[cap_key]
             raise RuntimeError(f"skelsplat_amd: a previous binned forward of this shape needed {pneed} (Gaussian, tile) pairs "
                                f"per view but its arena held {pcap}: that image missed entries.  The arena has been grown; "
                                "call again (check_capacity=True checks every call synchronously).")
-    host = torch.empty(nrend.shape[0], dtype=torch.int32, pin_memory=True)
-    host.copy_(nrend, non_blocking=True)
-    ev = torch.cuda.Event()
-    ev.record(torch.cuda.current_stream(nrend.device))
-    _BIN_PROBE[cap_key] = (host, ev, cap)
+    if not capturing:
+        host[:V] = -1
+    _BIN_PROBE[cap_key] = (host, cap)
+    return host
 
 
 def _scratch_bytes_cached(V, P, C, W, H, cap):
@@ -485,7 +502,11 @@ def export_lists(st: ForwardState):
         rc = lib.sks_export_lists(V, W, H, st.binning.data_ptr(), st.bin_capacity, pl.data_ptr(), rg.data_ptr(),
                                   torch.cuda.current_stream(dev).cuda_stream)
     _lib.check(rc, "sks_export_lists")
-    return pl, rg, st.num_rendered_dev[:V]
+    nr = st.num_rendered_dev[:V]
+    if not nr.is_cuda:      # a lazily checked call: the counts went to the shape's pinned host buffer (see _lazy_check)
+        torch.cuda.current_stream(dev).synchronize()
+        nr = nr.clone()
+    return pl, rg, nr
 
 
 # ------------------------------------------------------------------------------------------------------------
