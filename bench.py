@@ -32,6 +32,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+ROOF_MIN_LAUNCHES = 32  # forward launches whose duration goes into `roofline`, at least
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy kernel achieves
 
 WORKLOADS = {
@@ -83,9 +84,22 @@ def cpu_baseline(scene, params, n_views):
         if time.perf_counter() - t0 > 25.0:
             break
     dt = time.perf_counter() - t0
-    return dict(value=done / dt, unit="views/s", cores=torch.get_num_threads(), kind="port",
-                host_cpus=os.cpu_count(), cpu_model=cpu_model(), threads=torch.get_num_threads(),
-                sample=f"{done} views fwd+bwd of the same scene, oracle/torch_ref.py (pure PyTorch, fp32), {dt:.1f}s")
+    res = dict(value=done / dt, unit="views/s", cores=torch.get_num_threads(), kind="port",
+               host_cpus=os.cpu_count(), cpu_model=cpu_model(), threads=torch.get_num_threads(),
+               sample=f"{done} views fwd+bwd of the same scene, oracle/torch_ref.py (pure PyTorch, fp32), {dt:.1f}s")
+    # ... and once with every host thread (BASELINE.md section 3 planned os.cpu_count(); these are small ops: more threads
+    # mostly add synchronisation, which is why the figure above uses 32)
+    allc = os.cpu_count() or threads
+    if allc != threads:
+        torch.set_num_threads(allc)
+        t1, d2 = time.perf_counter(), 0
+        while d2 < 1 or (time.perf_counter() - t1 < 3.0 and d2 < 8):
+            one(scene.cameras[d2 % len(scene.cameras)])
+            d2 += 1
+        res["value_all_host_threads"] = d2 / (time.perf_counter() - t1)
+        res["all_host_threads"] = allc
+        torch.set_num_threads(threads)
+    return res
 
 
 class ApiStep:
@@ -123,21 +137,20 @@ class ApiStep:
         self.ws = R.Workspace()
 
     def choose_mode(self):
-        """Collective.  Switches to "all_reduce" if the communicator exists, SKS_BENCH_EXCHANGE does not say all_gather, and
-        the all-reduce form reproduces the all_gather form's mean on every rank of THIS system (rtol 1e-5)."""
+        """Collective.  The default exchange is the loop's: all_gather of the per-view rows through torch.distributed.  Switches
+        to "all_reduce" only if the library's own communicator exists (opt-in: SKS_RCCL_DIRECT=1), SKS_BENCH_EXCHANGE does not
+        say all_gather, and the all-reduce form reproduces the all_gather form's mean on every rank of THIS system (rtol 1e-5)."""
         import torch
         import torch.distributed as dist
         if self.exchange is None or self.direct is None or os.environ.get("SKS_BENCH_EXCHANGE", "all_reduce") != "all_reduce":
             return self.mode
         want = self().clone()
         self.mode = "all_reduce"
-        ok = True
-        try:
-            got = self()
-            torch.cuda.synchronize()
-            ok = bool(torch.allclose(got, want, rtol=1e-5, atol=1e-6 * float(want.abs().max())))
-        except Exception:
-            ok = False
+        # (no try / except around the collective: a rank that left it through an exception while its peers are inside
+        # ncclAllReduce would turn an error into a hang; an error here ends the run on every rank instead)
+        got = self()
+        torch.cuda.synchronize()
+        ok = bool(torch.allclose(got, want, rtol=1e-5, atol=1e-6 * float(want.abs().max())))
         flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=want.device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.exchange[2])
         if int(flag.item()) != 1:
@@ -204,6 +217,7 @@ def roofline_entry(alg_bytes, prof_fwd, wl_name, launches, kernel="k_render_fwd_
             traffic = None
     return {"bound": "hbm", "kernel": kernel, "achieved": alg_bytes / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": alg_bytes / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src if traffic else None,
+            "frac_median": alg_bytes / (fwd_q[1] * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "avg_launch_us": avg_s * 1e6, "launch_us_p10_p50_p90": [round(1e3 * x, 2) for x in fwd_q],
             "launches_timed": fwd_n, "launches": launches, "algorithmic_bytes_per_launch": alg_bytes}
 
@@ -270,8 +284,31 @@ def run_single(args, torch, dev, wl):
         _lib.prof_read(0), _lib.prof_read(1)
     dt, out = timed(step, args.steps, 0, sync)
     pf = pb = None
+    zero_us = None
     if prof:
+        # at least ROOF_MIN_LAUNCHES forward launches carry an event pair whatever --steps is: what the timed region did not
+        # sample is made up by untimed steps behind it, every launch bracketed (the kernel's duration does not depend on it)
+        have = _lib.prof_count(0)
+        if have < ROOF_MIN_LAUNCHES:
+            _lib.prof_enable(True, every=1, kinds=(0,), keep=True)
+            for _ in range(ROOF_MIN_LAUNCHES - have):
+                step()
+            sync()
         pf = _lib.prof_read_quantiles(0)
+        # the box's own ceiling for these bytes, in the same run: tensor.zero_() of a buffer the size of the forward's planes
+        try:
+            zbuf = torch.empty((V * (C + 1), H, W), device=dev)
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(12)]
+            for a_, b_ in evs:
+                a_.record()
+                zbuf.zero_()
+                b_.record()
+            sync()
+            zt = sorted(a_.elapsed_time(b_) for a_, b_ in evs[2:])
+            zero_us = 1e3 * zt[len(zt) // 2]
+            del zbuf
+        except Exception:
+            zero_us = None
         _lib.prof_enable(True, every=1, kinds=(1,))     # the backward compositor: a few untimed steps behind the timed region
         for _ in range(10):
             step()
@@ -289,6 +326,9 @@ def run_single(args, torch, dev, wl):
     }
     if pf and pf[1]:
         res["roofline"] = roofline_entry(4.0 * H * W * (C + 1) * V, pf, wl["name"], args.steps)
+        if zero_us:
+            res["roofline"]["zero_fill_same_bytes_us"] = zero_us
+            res["roofline"]["frac_of_zero_fill"] = zero_us / (1e3 * pf[2][1])     # (median launch against the median zero_())
         if pb and pb[1]:
             res["bwd_kernel_avg_us"] = pb[0] * 1e3 / pb[1]
             res["bwd_kernel_us_p10_p50_p90"] = [round(1e3 * x, 2) for x in pb[2]]
@@ -577,7 +617,7 @@ def extra_stress(args, torch, dev, sync):
     try:
         tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["stress_256skeletons_8view_2048x2048_P4352_C17"]["kernels"]
         f = [v for k, v in tr.items() if k.startswith("k_render_fwd_binned")][0]
-        b = [v for k, v in tr.items() if k.startswith("k_render_bwd_binned")][0]
+        b = [v for k, v in tr.items() if k.startswith("k_render_bwd_tile") or k.startswith("k_render_bwd_binned")][0]
         out["fwd_traffic_over_algorithmic"] = f["hbm_bytes_per_launch"] / out["fwd_algorithmic_bytes"]
         out["bwd_fetch_bytes"] = 2048.0 * b["FETCH_SIZE_KiB_per_launch"]
         out["bwd_write_bytes"] = 1024.0 * b["WRITE_SIZE_KiB_per_launch"]
@@ -651,6 +691,9 @@ def extra_rank_step(args, torch, dev, sync):
                "rank_step_all_reduce_ms": None if dta is None else 1e3 * dta / n, "rank_step_without_exchange_ms": 1e3 * dt0 / n,
                "one_gpu_31views_ms": 1e3 * dtf / nf, "predicted_8gpu_speedup": (dtf / nf) / (best / n),
                "ideal_speedup": V / vmax, "target": 6.0,
+               # what real xGMI latency would leave of it: the exchange measured here crosses no link (a communicator of ONE rank)
+               "predicted_8gpu_speedup_at_exchange_us": {str(us): (dtf / nf) / (dt0 / n + us * 1e-6) for us in (0, 10, 20, 30)},
+               "status": "PREDICTION from one GPU, not a measurement: no multi-GPU run was available to this build",
                "gather": "ncclAllGather on the launch stream (rccl_direct)" if direct is not None else "torch.distributed",
                "note": "rank 0 of 8: 4 views fwd+bwd + the step's one collective on a 1-rank RCCL communicator: all_gather of the "
                        "per-view rows + sks_mean_views, or (what --gpus N uses when it can) the local mean from the backward's own "
@@ -809,6 +852,13 @@ def run_sharded(args, torch, dist, dev, wl, world, rank):
         except Exception as e:
             res["loop_error"] = repr(e)[:300]
     res["strong_scaling"] = strong
+    # the three steps' speed-ups at the top level: north_star's >= 6 x is expected of the DENSE loop step (it is made of bytes,
+    # DESIGN.md section 6); the API step's ~35 us of fixed cost and one exchange leave it around 6 x, the sparse step is a
+    # 90 us chain of latencies that does not shard
+    res["api_step_speedup_vs_one_gpu"] = strong["api_step"]["speedup"]
+    for tag in ("loop_dense", "loop_sparse"):
+        if tag in strong:
+            res[tag + "_speedup_vs_one_gpu"] = strong[tag]["speedup"]
     return res
 
 

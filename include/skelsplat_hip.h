@@ -297,6 +297,9 @@ int sks_loop_fused_step(int V, int P, int C, int W, int H, const float* viewmatr
  * sampling keeps the measured loop undisturbed); bits 16-17: kinds to leave OUT (bit 16: kind 0, bit 17: kind 1).  sks_prof_read waits for the recorded events, returns
  * the summed kernel time in milliseconds and the number of BRACKETED launches since the last read, and resets them. */
 int sks_prof_enable(int on);
+/* bracketed launches of one kind collected since the last read (sks_prof_enable does not reset them: a caller may change the
+ * sampling stride in the middle of a collection) */
+int sks_prof_count(int kind, long long* launches);
 int sks_prof_read(int kind, double* total_ms, long long* launches);
 /* Same, plus the 10th / 50th / 90th percentile of the bracketed launch durations (milliseconds). */
 int sks_prof_read_quantiles(int kind, double* q_ms /* 3 */, double* total_ms, long long* launches);

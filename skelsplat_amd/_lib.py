@@ -59,6 +59,7 @@ SIGNATURES = {
                                  _i, _vp, _vp]),
     "sks_prof_enable": (_i, [_i]),
     "sks_prof_read": (_i, [_i, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
+    "sks_prof_count": (_i, [_i, C.POINTER(C.c_longlong)]),
     "sks_prof_read_quantiles": (_i, [_i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
 }
 
@@ -110,9 +111,16 @@ def farray(vals):
     return (C.c_float * len(vals))(*[float(v) for v in vals])
 
 
-def prof_enable(on, every=1, kinds=(0, 1)):
+def prof_count(kind):
+    """Bracketed launches of one kind collected since the last read."""
+    n = C.c_longlong(0)
+    check(load().sks_prof_count(kind, C.byref(n)), "sks_prof_count")
+    return n.value
+
+
+def prof_enable(on, every=1, kinds=(0, 1), keep=False):
     """Bracket the forward (kind 0) / backward (kind 1) compositor launches with hipEvents: every `every`-th launch of each
-    kind in `kinds`."""
+    kind in `kinds`.  (`keep`: documentation only -- what was collected so far always stays until it is read.)"""
     skip = sum(1 << (16 + k) for k in (0, 1) if k not in kinds)
     check(load().sks_prof_enable((min(0xffff, max(1, int(every))) | skip) if on else 0), "sks_prof_enable")
 

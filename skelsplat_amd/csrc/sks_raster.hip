@@ -536,6 +536,13 @@ int sks_prof_enable(int on)
     return 0;
 }
 
+int sks_prof_count(int kind, long long* launches)
+{
+    if (kind < 0 || kind > 1 || !launches) return fail(-2, "bad profile query");
+    *launches = tl_prof ? tl_prof->kind[kind].n : 0;
+    return 0;
+}
+
 int sks_prof_read(int kind, double* total_ms, long long* launches)
 {
     if (kind < 0 || kind > 1 || !total_ms || !launches) return fail(-2, "bad profile query");

@@ -232,9 +232,9 @@ class MultiViewLoop:
                 # RCCL builds its communicator on the first collective: do that here, eagerly, never inside a graph
                 # capture or a timed step (the gathered rows are overwritten by every group)
                 dist.all_gather_into_tensor(self._allg, self._shard, group=self.group)
-                # ... and a communicator of our own, so that the group's one all_gather is enqueued on the stream its
-                # neighbours run on (torch's process group runs it on an internal stream: two event hand-overs, ~7 us of the
-                # GPU timeline per step at world 1); None when the backend is not RCCL
+                # ... and, when asked for (SKS_RCCL_DIRECT=1), a communicator of our own, so that the group's one all_gather is
+                # enqueued on the stream its neighbours run on (torch's process group runs it on an internal stream: two event
+                # hand-overs, ~7 us of the GPU timeline per step at world 1); None by default and when the backend is not RCCL
                 if dev.type == "cuda":
                     from .rccl_direct import DirectGather
                     self._direct = DirectGather.create(dev, self.group)

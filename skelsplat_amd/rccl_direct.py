@@ -3,10 +3,13 @@
 torch.distributed's NCCL process group runs every collective on its own internal stream and hands over with events on both
 sides; for the loop's one tiny all_gather per step (a few KB, latency-bound) that hand-over is most of its cost on the GPU
 timeline.  A communicator of our own -- ncclCommInitRank with an id rank 0 creates and torch.distributed broadcasts -- lets
-`ncclAllGather` be enqueued on the stream the kernels around it run on.  Opt-in (`DirectGather.create` returns None when
-anything is missing); torch.distributed stays the bootstrap and the fallback."""
+`ncclAllGather` be enqueued on the stream the kernels around it run on.  OPT-IN: `DirectGather.create` returns None unless the
+environment says SKS_RCCL_DIRECT=1 (and whenever anything is missing); torch.distributed stays the bootstrap and the default
+exchange.  Status: exercised on a communicator of ONE rank only (no multi-GPU hardware was available to this build); `create`
+therefore runs one all_gather through both paths and keeps the communicator only if every rank saw identical results."""
 import ctypes
 import os
+import weakref
 
 import torch
 import torch.distributed as dist
@@ -14,7 +17,7 @@ import torch.distributed as dist
 NCCL_FLOAT = 7      # ncclFloat32 (nccl.h: ncclInt8 0, ncclUint8 1, ncclInt32 2, ncclUint32 3, ncclInt64 4, ncclUint64 5, ncclFloat16 6, ncclFloat32 7)
 
 
-_COMMS = {}     # (group, device index) -> DirectGather
+_COMMS = {}     # (group id or 0, device index) -> (DirectGather, weak reference to the group or None, world size it was built for)
 
 
 class _UniqueId(ctypes.Structure):
@@ -56,11 +59,18 @@ class DirectGather:
         """Collective over `group` (every rank must call it).  Returns None -- on EVERY rank -- unless every rank got its
         communicator (the ranks agree through one all_reduce of torch.distributed), the backend is RCCL and
         SKS_RCCL_DIRECT is not 0."""
-        if os.environ.get("SKS_RCCL_DIRECT", "1") == "0" or not dist.is_initialized() or dist.get_backend(group) != "nccl":
+        if os.environ.get("SKS_RCCL_DIRECT", "0") != "1" or not dist.is_initialized() or dist.get_backend(group) != "nccl":
+            return None
+        if device.type != "cuda" or device.index is None:
             return None
         key = (id(group) if group is not None else 0, device.index)
-        if key in _COMMS:       # one communicator per (group, device): every loop object of a process shares it
-            return _COMMS[key]
+        hit = _COMMS.get(key)
+        if hit is not None:     # one communicator per (group, device): every loop object of a process shares it
+            dg, gref, world0 = hit
+            # (a process group that was destroyed and built again -- same key, another membership -- must not find this one)
+            if (gref is None or gref() is group) and world0 == dist.get_world_size(group) and dg.comm:
+                return dg
+            dg.destroy()
 
         def agree(flag):        # True only if `flag` holds on every rank
             t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
@@ -91,7 +101,8 @@ class DirectGather:
                 blob = [ctypes.string_at(ctypes.byref(uid), 128)]
             except Exception as e:
                 note("ncclGetUniqueId", e)
-        dist.broadcast_object_list(blob, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        dist.broadcast_object_list(blob, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group,
+                                   device=device)
         if blob[0] is None:
             return None
         ctypes.memmove(ctypes.byref(uid), blob[0], 128)
@@ -106,14 +117,36 @@ class DirectGather:
             me._key = key
         except Exception as e:
             note("ncclCommInitRank", e)
-        if agree(me is not None):
-            _COMMS[key] = me
-            return me
-        if me is not None:
+        if not agree(me is not None):
+            if me is not None:
+                me.destroy()
+            return None
+        # one all_gather through both paths: the communicator is kept only if every rank saw the same rows
+        same = False
+        try:
+            probe = torch.arange(8, dtype=torch.float32, device=device) + 100.0 * rank
+            a, b = torch.empty(8 * world, device=device), torch.empty(8 * world, device=device)
+            dist.all_gather_into_tensor(a, probe, group=group)
+            me.all_gather_into_tensor(b, probe)
+            torch.cuda.synchronize(device)
+            same = bool(torch.equal(a, b))
+        except Exception as e:
+            note("self-check", e)
+        if not agree(same):
             me.destroy()
-        return None
+            return None
+        gref = None
+        if group is not None:
+            try:
+                gref = weakref.ref(group)
+            except TypeError:
+                gref = None
+        _COMMS[key] = (me, gref, world)
+        return me
 
     def all_gather_into_tensor(self, out, inp):
+        if out.device != self.device or inp.device != self.device:
+            raise ValueError(f"DirectGather: tensors must live on {self.device} (the communicator's device)")
         if out.numel() != self.world * inp.numel() or not out.is_contiguous() or not inp.is_contiguous() \
                 or out.dtype != torch.float32 or inp.dtype != torch.float32:
             raise ValueError("DirectGather: contiguous fp32 tensors, out = world x inp")
@@ -127,6 +160,8 @@ class DirectGather:
         ncclAllReduce with a pre-multiplied sum (ncclRedOpCreatePreMulSum, the scalar a host immediate).  With inp_r = the
         mean of a rank's V_r local per-view gradients and weight_r = V_r / V this is the mean over all V views
         (train.py:215-217) without gathering the per-view rows."""
+        if out.device != self.device or inp.device != self.device:
+            raise ValueError(f"DirectGather: tensors must live on {self.device} (the communicator's device)")
         if out.shape != inp.shape or not out.is_contiguous() or not inp.is_contiguous() or out.dtype != torch.float32 \
                 or inp.dtype != torch.float32:
             raise ValueError("DirectGather.all_reduce_weighted: contiguous fp32 tensors of one shape")
@@ -155,5 +190,5 @@ class DirectGather:
 
 def destroy_all():
     """ncclCommDestroy of every communicator this module built (call before dist.destroy_process_group())."""
-    for dg in list(_COMMS.values()):
+    for dg, _, _ in list(_COMMS.values()):
         dg.destroy()

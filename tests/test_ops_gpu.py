@@ -714,11 +714,16 @@ def test_exchange_branch_on_rccl_equals_unsharded_loop(device, rccl_world1, mode
 def test_direct_rccl_gather_equals_torch_distributed(device, rccl_world1):
     """skelsplat_amd.rccl_direct: ncclAllGather through a communicator of the library's own, enqueued on the CURRENT stream
     (torch.distributed's process group hands every collective to an internal stream), gives what
-    dist.all_gather_into_tensor gives; one communicator per (group, device); SKS_RCCL_DIRECT=0 switches it off."""
+    dist.all_gather_into_tensor gives; one communicator per (group, device); opt-in: without SKS_RCCL_DIRECT=1 there is none."""
     import torch.distributed as dist
     from skelsplat_amd.rccl_direct import DirectGather
-    dg = DirectGather.create(device)
-    assert dg is not None and DirectGather.create(device) is dg
+    assert os.environ.get("SKS_RCCL_DIRECT") is None and DirectGather.create(device) is None     # off unless asked for
+    os.environ["SKS_RCCL_DIRECT"] = "1"
+    try:
+        dg = DirectGather.create(device)
+        assert dg is not None and DirectGather.create(device) is dg
+    finally:
+        del os.environ["SKS_RCCL_DIRECT"]
     inp = torch.randn((4, 19, 11), device=device)
     a, b = torch.empty_like(inp), torch.full_like(inp, float("nan"))
     dist.all_gather_into_tensor(a, inp)
@@ -737,12 +742,10 @@ def test_direct_rccl_gather_equals_torch_distributed(device, rccl_world1):
         torch.cuda.synchronize()
         assert torch.allclose(out, m * w, rtol=1e-6, atol=0)
     assert len(dg._ops) == 2
-    os.environ["SKS_RCCL_DIRECT"] = "0"
-    try:
-        dg.destroy()
-        assert DirectGather.create(device) is None
-    finally:
-        del os.environ["SKS_RCCL_DIRECT"]
+    with pytest.raises(ValueError):       # tensors of another device than the communicator's
+        dg.all_gather_into_tensor(torch.empty(4), torch.empty(4))
+    dg.destroy()
+    assert DirectGather.create(device) is None
 
 
 def test_adam_step_reads_the_gathered_rank_major_layout(device):
