@@ -287,7 +287,11 @@ class GaussianModel:
         ch = torch.arange(P, device=device) % n_joints
         features = torch.zeros(P, n_joints, device=device).scatter_(1, ch[:, None], 1.0)[:, None, :]  # (P,1,C)
         scales = torch.ones_like(pts) * scaling
-        ends = torch.tensor(DATASETS[scene_type]["limb_ends"], device=device)
+        # gaussian_model.py:173-178 is an if / elif chain over the scene types "h36m", "panoptic", "occlusion-person"; any other
+        # string falls through WITHOUT a modifier.  That includes the reference's own configs/h36m-occ.yaml: its data_root
+        # "data/h36m-occ" makes scene_type "h36m-occ" (scene/__init__.py:40), so its scaling_modifier 1.25 is never applied
+        # (held to the reference's run of that config: tests/golden/reference_loop.npz, case h36m_occ).
+        ends = torch.tensor(DATASETS.get(scene_type, {}).get("limb_ends", []), device=device, dtype=torch.long)
         sel = (ch[:, None] == ends[None, :]).any(1)
         scales[sel] *= scaling_modifier
         rots = torch.zeros((P, 4), device=device)

@@ -43,6 +43,21 @@ CASES = {
     "h36m_mixed": dict(cfg="h36m", dataset="h36m", V=4, W=1000, H=1000, iters=40, widths=[1002, 1000, 1000, 1002]),
     "panoptic_full": dict(cfg="panoptic", dataset="panoptic", V=31, W=1920, H=1080, iters=62,
                           over={"dataset.nviews": 31, "training.accumulation_steps": 31}),
+    # round 4: the shipped configs and loop quirks the five cases above do not touch
+    "op_720p": dict(cfg="occlusion-person", dataset="occlusion-person", V=4, W=1280, H=720, iters=48),   # -op package, C = 15,
+                                                                           # scaling_modifier 1.25, position_lr_init 0.005, rotation_lr 0
+    "h36m_occ": dict(cfg="h36m-occ", dataset="h36m", V=4, W=1000, H=1000, iters=40),                    # scaling_modifier 1.25
+    "panoptic_shipped": dict(cfg="panoptic", dataset="panoptic", V=4, W=1920, H=1080, iters=40),        # nviews 4 as shipped
+    "q8_v5": dict(cfg="h36m", dataset="h36m", V=5, W=64, H=48, iters=40, fx=1145.0 * 0.064 * 1.5, ring=2500.0,
+                  over={"dataset.nviews": 5}),                      # quirk Q8: V = 5 slots, a step every 4 iterations
+    "q8_v3": dict(cfg="h36m", dataset="h36m", V=3, W=64, H=48, iters=40, fx=1145.0 * 0.064 * 1.5, ring=2500.0,
+                  over={"dataset.nviews": 3}),                      # ... and V = 3
+    "early_stop": dict(cfg="h36m", dataset="h36m", V=4, W=64, H=48, iters=4000, fx=1145.0 * 0.064 * 1.5, ring=2500.0,
+                       over={"training.early_stopping": "opt_early_stopping"}, may_stop=True),
+    "dropout": dict(cfg="h36m", dataset="h36m", V=4, W=64, H=48, iters=40, fx=1145.0 * 0.064 * 1.5, ring=2500.0,
+                    over={"training.dropout": True}),
+    "antialias": dict(cfg="h36m", dataset="h36m", V=4, W=64, H=48, iters=40, fx=1145.0 * 0.064 * 1.5, ring=2500.0,
+                      over={"pipeline.antialiasing": True}),
 }
 
 
@@ -84,6 +99,7 @@ def run_case(name, spec, out):
             gaussians.create_from_pcd(pcd, cameras, self.cameras_extent, model.opacity_on, model.scaling, n_joints,
                                       model.scaling_modifier, self.scene_type)
             rec["spatial_lr_scale"] = float(self.cameras_extent)
+            rec["scene_type"] = self.scene_type
             rec["gm"] = gaussians
 
         def getTrainCameras(self, scale=1.0):
@@ -143,14 +159,22 @@ def run_case(name, spec, out):
         ref_train.generate_heatmaps = real_heat
     steps = rec["steps"]
     acc = cfg.training.accumulation_steps
-    assert len(steps) == spec["iters"] // acc and len(rec["l2"]) == spec["iters"], (len(steps), len(rec["l2"]))
-    assert rec["views"] == [i % spec["V"] for i in range(spec["iters"])]            # round-robin, train.py:136-138
+    ran = len(rec["l2"])                                   # iterations executed (early stopping ends the scene, train.py:231-233)
+    if spec.get("may_stop"):
+        assert ran < spec["iters"], "early stopping never fired: lengthen the case"
+        assert len(steps) == ran // acc + (1 if ran % acc else 0), (len(steps), ran)     # the stopping iteration steps too (:182)
+        assert rec.get("saved") == [ran]
+    else:
+        assert len(steps) == spec["iters"] // acc and ran == spec["iters"], (len(steps), ran)
+    assert rec["views"] == [i % spec["V"] for i in range(ran)]            # round-robin, train.py:136-138
     pre = name + "_"
     hm = rec["heatmaps"]
     planes = [hm[str(v)].numpy() for v in range(spec["V"])]
     o = cfg.optimization
     out.update({
-        pre + "dataset": np.array(spec["dataset"]), pre + "iterations": np.int64(spec["iters"]),
+        pre + "dataset": np.array(spec["dataset"]), pre + "scene_type": np.array(rec["scene_type"]), pre + "iterations": np.int64(ran),
+        pre + "iterations_max": np.int64(spec["iters"]), pre + "early_stopping": np.array(str(cfg.training.early_stopping)),
+        pre + "antialiasing": np.bool_(bool(cfg.pipeline.antialiasing)), pre + "dropout": np.bool_(bool(cfg.training.dropout)),
         pre + "accumulation_steps": np.int64(acc), pre + "lambda_consistency": np.float64(cfg.training.lambda_consistency),
         pre + "pose_3d_init": np.asarray(sc.pose_3d_init), pre + "pose_3d_gt": np.asarray(sc.pose_3d_gt),
         pre + "poses_2d": np.asarray(sc.poses_2d), pre + "cam_R": np.stack([c.R for c in cams]),
@@ -172,7 +196,7 @@ def run_case(name, spec, out):
     gt = np.asarray(sc.pose_3d_gt)
     e0 = np.linalg.norm(np.asarray(sc.pose_3d_init) - gt, axis=1).mean()
     e1 = np.linalg.norm(steps[-1][0] - gt, axis=1).mean()
-    print(f"{name}: {spec['iters']} iterations, {len(steps)} steps in {time.time() - t0:.1f} s; MPJPE {e0:.3f} -> {e1:.3f} mm; "
+    print(f"{name}: {ran} iterations, {len(steps)} steps in {time.time() - t0:.1f} s; MPJPE {e0:.3f} -> {e1:.3f} mm; "
           f"l2 {rec['l2'][0]:.3e} -> {rec['l2'][-1]:.3e}")
 
 
