@@ -254,8 +254,10 @@ inline const char* fill_adam_args(AdamArgs& a, int V, int P, const float* grads,
     a.xyz = xyz; a.scaling = scaling; a.rotation = rotation; a.opacity = opacity; a.m = exp_avg; a.vv = exp_avg_sq;
     a.counters = counters; a.acc_steps = acc_steps;
     a.lr_init = lr_sched[0]; a.lr_final = lr_sched[1]; a.lr_delay_mult = lr_sched[2];
-    a.log_lr_init = lr_sched[0] > 0.0 ? log(lr_sched[0]) : 0.0;
-    a.log_lr_final = lr_sched[1] > 0.0 ? log(lr_sched[1]) : 0.0;
+    // (log(0) = -inf like np.log in the reference, general_utils.py:66: a schedule with one zero end point is 0 where that end
+    // point has weight and NaN where its weight is exactly 0; an all-zero schedule is switched off before it gets here)
+    a.log_lr_init = log(lr_sched[0]);
+    a.log_lr_final = log(lr_sched[1]);
     a.lr_delay_steps = (int)lr_sched[3]; a.lr_max_steps = (int)lr_sched[4];
     a.lr_scaling = lrs[0]; a.lr_rotation = lrs[1]; a.lr_opacity = lrs[2];
     a.beta1 = adam[0]; a.beta2 = adam[1]; a.eps = adam[2];

@@ -284,6 +284,7 @@ typedef float hm_v4f __attribute__((ext_vector_type(4)));
 
 // TOTALS: also accumulates, per view, the sum of out^2 and the count of out > 0 (what sks_gt_tile_stats would read back
 // from the planes: the masked-L2 loss of an all-zero render), so a frame's heat-maps are written and never re-read.
+__global__ void k_heatmap_totals_finish(int V, double* __restrict__ totals);
 template <bool TOTALS>
 __global__ __launch_bounds__(256) void k_heatmaps(int W, int H, int J, const float* __restrict__ row, const float* __restrict__ col,
                                                    const float* __restrict__ cmin, const float* __restrict__ den,
@@ -326,8 +327,12 @@ __global__ __launch_bounds__(256) void k_heatmaps(int W, int H, int J, const flo
         if ((threadIdx.x & 63) == 0) { s_t[0][threadIdx.x >> 6] = tS; s_t[1][threadIdx.x >> 6] = tN; }
         __syncthreads();
         if (threadIdx.x == 0) {
+            // like k_heatmap_totals: the blocks of a view finish in any order, so the sum of squares is combined in 2^-32 fixed
+            // point with integer atomics (order-independent: the loss constants, and with them the reported loss and the early
+            // stopping input, are reproducible bit for bit); k_heatmap_totals_finish converts it back
             const int v = vj / J;
-            atomicAdd(&totals[2 * v], (s_t[0][0] + s_t[0][1]) + (s_t[0][2] + s_t[0][3]));
+            const double Sb = (s_t[0][0] + s_t[0][1]) + (s_t[0][2] + s_t[0][3]);
+            atomicAdd(reinterpret_cast<unsigned long long*>(&totals[2 * v]), (unsigned long long)llrint(Sb * 4294967296.0));
             atomicAdd(&totals[2 * v + 1], (s_t[1][0] + s_t[1][1]) + (s_t[1][2] + s_t[1][3]));
         }
     }
@@ -586,6 +591,7 @@ int sks_heatmaps(int V, int J, int W, int H, const float* row, const float* col,
     if (gt_totals) {
         HIP_TRY2(hipMemsetAsync(gt_totals, 0, (size_t)V * 2 * sizeof(double), (hipStream_t)stream));
         hipLaunchKernelGGL(k_heatmaps<true>, grid, dim3(256), 0, (hipStream_t)stream, W, H, J, row, col, cmin, den, out, gt_totals);
+        hipLaunchKernelGGL(k_heatmap_totals_finish, dim3((V + 63) / 64), dim3(64), 0, (hipStream_t)stream, V, gt_totals);
     } else {
         hipLaunchKernelGGL(k_heatmaps<false>, grid, dim3(256), 0, (hipStream_t)stream, W, H, J, row, col, cmin, den, out, nullptr);
     }

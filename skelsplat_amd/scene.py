@@ -236,8 +236,10 @@ class ExponentialLR:
 
     def __init__(self, lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, max_steps=1000000):
         self.off = lr_init == 0.0 and lr_final == 0.0
-        self.log_init = math.log(lr_init) if lr_init > 0.0 else 0.0
-        self.log_final = math.log(lr_final) if lr_final > 0.0 else 0.0
+        # np.log(0) = -inf in the reference (general_utils.py:66): a schedule with ONE zero end point is 0 wherever that end
+        # point has weight (exp(-inf)) and NaN where its weight is exactly 0 (0 * -inf); IEEE arithmetic below gives the same
+        self.log_init = math.log(lr_init) if lr_init > 0.0 else (-math.inf if lr_init == 0.0 else math.nan)
+        self.log_final = math.log(lr_final) if lr_final > 0.0 else (-math.inf if lr_final == 0.0 else math.nan)
         self.delay_steps, self.delay_mult, self.max_steps = lr_delay_steps, lr_delay_mult, max_steps
 
     def __call__(self, step):

@@ -121,6 +121,17 @@ def test_lr_schedule_matches_reference():
     # reference calls numpy's)
     np.testing.assert_allclose(np.array([f(int(s)) for s in GOLD["lr_steps"]]), GOLD["lr_values"], rtol=4.5e-16, atol=0)
     np.testing.assert_allclose(np.array([f2(int(s)) for s in GOLD["lr_steps"]]), GOLD["lr2_values"], rtol=4.5e-16, atol=0)
+    # one zero end point (general_utils.py:57-69 takes np.log(0) = -inf): 0 wherever that end point has weight, NaN where its
+    # weight is exactly 0, like `np.exp(np.log(lr_init) * (1 - t) + np.log(lr_final) * t)` itself
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ref = lambda a, b, t: float(np.exp(np.log(a) * (1 - t) + np.log(b) * t))
+        for a, b in ((0.0, 1e-3), (1e-3, 0.0)):
+            g = get_expon_lr_func(a, b, max_steps=100)
+            for step in (0, 1, 50, 99, 100, 150):
+                want = ref(a, b, min(max(step / 100, 0.0), 1.0))
+                got = g(step)
+                assert (np.isnan(want) and np.isnan(got)) or got == want, (a, b, step, got, want)
+    assert get_expon_lr_func(0.0, 0.0)(10) == 0.0 and get_expon_lr_func(1e-3, 1e-4)(-1) == 0.0
 
 
 def test_losses_match_reference():

@@ -866,6 +866,28 @@ def test_heatmap_dropout_zeroes_the_drawn_planes(device):
     assert torch.equal(totals[:, 1], (hm > 0).sum(dim=(1, 2, 3)).double())
 
 
+def test_heatmap_totals_are_reproducible_bit_for_bit(device):
+    """The per-view loss constants (sum of gt^2, count of gt > 0) feed the reported loss and the early-stopping criterion:
+    both ways of forming them -- on the way while sks_heatmaps writes the planes (what MultiViewLoop.new_scene takes), and from
+    the factors alone (sks_heatmap_totals) -- combine their workgroups' sums in fixed point, so repeated runs agree exactly
+    although the workgroups finish in a different order every time."""
+    from skelsplat_amd.scene import SyntheticScene, GaussianModel
+    from skelsplat_amd.heatmaps import generate_heatmaps
+    sc = SyntheticScene("h36m", n_views=4, seed=3, device=device, W=1000, H=1000)
+    gm = GaussianModel().create_from_points(sc.pose_3d_init, sc.spatial_lr_scale, sc.n_joints, device=device)
+    p2d = torch.tensor(sc.poses_2d, device=device)
+    args = (gm._xyz.detach(), gm.get_scaling.detach(), gm._rotation.detach(), p2d, sc.cameras)
+    runs = []
+    for _ in range(6):
+        totals = torch.zeros((4, 2), dtype=torch.float64, device=device)
+        hm = generate_heatmaps(*args, totals=totals)
+        runs.append(totals.clone())
+    for t in runs[1:]:
+        assert torch.equal(t, runs[0])
+    torch.testing.assert_close(runs[0][:, 0], (hm.double() ** 2).sum(dim=(1, 2, 3)), rtol=1e-6, atol=0)
+    assert torch.equal(runs[0][:, 1], (hm > 0).sum(dim=(1, 2, 3)).double())
+
+
 @pytest.mark.parametrize("mixed", [False, True], ids=["4x1000", "1002-1000-1000-1002"])
 def test_full_size_h36m_loop_sparse_equals_dense(device, mixed):
     """BASELINE config 2 at full size, through the loop: 40 iterations of the sparse fused step (two launches per group,
