@@ -1,12 +1,18 @@
 """Drop-in for the reference's gaussian_renderer package (gaussian_renderer/__init__.py:28-371): the three
 render_* functions and the `render_functions` registry keyed by `pipeline.rendering` (configs/*.yaml:45).
 
-Differences that do not change results:
+Differences that do not change results (fp32 round-off aside):
+  * when the model is the reference's GaussianModel -- get_opacity / get_scaling / get_rotation are torch.sigmoid / torch.exp /
+    F.normalize of the leaves (scene/gaussian_model.py:39-47,100-110) -- the leaves themselves go to the rasterizer and the
+    three activations and their autograd run inside its kernels (`raw_params`): eight tiny launches less per render(), ten
+    less per backward, in an iteration that is bound by its launches.  FAST_ACTIVATIONS = False (or SKS_RENDER_FAST=0)
+    keeps the reference's literal call: the activated tensors, autograd through torch's activation nodes;
   * `rendered_image.clamp(0, 1)` (reference :129) is folded into the rasterizer's store and its backward mask
     (SKS_CLAMP01) instead of running as two extra dense passes;
   * `(radii > 0).nonzero()` (reference :133) forces a host sync, so `visibility_filter` is computed on first access.
 """
 import math
+import os
 
 import torch
 
@@ -16,6 +22,20 @@ from diff_gaussian_rasterization_panoptic import GaussianRasterizationSettings a
 from diff_gaussian_rasterization_panoptic import GaussianRasterizer as GaussianRasterizerPanoptic
 from diff_gaussian_rasterization_op import GaussianRasterizationSettings as GaussianRasterizationSettingsOp
 from diff_gaussian_rasterization_op import GaussianRasterizer as GaussianRasterizerOp
+
+
+FAST_ACTIVATIONS = os.environ.get("SKS_RENDER_FAST", "1") != "0"
+
+
+def _leaves_of(pc):
+    """(_opacity, _scaling, _rotation) if pc's three activations are exactly the reference's, else None."""
+    try:
+        if (pc.opacity_activation is torch.sigmoid and pc.scaling_activation is torch.exp
+                and pc.rotation_activation is torch.nn.functional.normalize):
+            return pc._opacity, pc._scaling, pc._rotation
+    except AttributeError:
+        pass
+    return None
 
 
 class RenderPackage(dict):
@@ -72,11 +92,8 @@ class RenderPackage(dict):
 def _render(Settings, Rasterizer, viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, separate_sh=False,
             override_color=None, use_trained_exp=False):
     # zero tensor whose gradient receives the 2D (screen-space) mean gradients (reference :36-40)
-    screenspace_points = torch.zeros_like(pc.get_xyz, dtype=pc.get_xyz.dtype, requires_grad=True) + 0
-    try:
-        screenspace_points.retain_grad()
-    except Exception:
-        pass
+    # (the reference adds 0 to make it a non-leaf and calls retain_grad(); a leaf keeps its .grad by itself: one launch less)
+    screenspace_points = torch.zeros_like(pc.get_xyz, dtype=pc.get_xyz.dtype, requires_grad=True)
     tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
     tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)
     raster_settings = Settings(
@@ -97,11 +114,15 @@ def _render(Settings, Rasterizer, viewpoint_camera, pc, pipe, bg_color, scaling_
     rasterizer = Rasterizer(raster_settings=raster_settings)
     means3D = pc.get_xyz
     means2D = screenspace_points
-    opacity = pc.get_opacity
+    leaves = _leaves_of(pc) if (FAST_ACTIVATIONS and not pipe.compute_cov3D_python) else None
     scales = rotations = cov3D_precomp = None
-    if pipe.compute_cov3D_python:
+    if leaves is not None:
+        opacity, scales, rotations = leaves
+    elif pipe.compute_cov3D_python:
+        opacity = pc.get_opacity
         cov3D_precomp = pc.get_covariance(scaling_modifier)
     else:
+        opacity = pc.get_opacity
         scales = pc.get_scaling
         rotations = pc.get_rotation
     shs = colors_precomp = None
@@ -119,7 +140,7 @@ def _render(Settings, Rasterizer, viewpoint_camera, pc, pipe, bg_color, scaling_
         colors_precomp = override_color
     rendered_image, radii, depth_image = rasterizer(
         means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, opacities=opacity,
-        scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp, clamp01=True)
+        scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp, clamp01=True, raw_params=leaves is not None)
     return RenderPackage(render=rendered_image, viewspace_points=screenspace_points, radii=radii, depth=depth_image)
 
 

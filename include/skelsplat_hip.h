@@ -48,6 +48,8 @@ extern "C" {
 #define SKS_RAW_PARAMS   32u   /* opacities / scales / rotations are the LEAF parameters (_opacity logits, _scaling
                                  log-scales, raw _rotation); sigmoid / exp / normalize (scene/gaussian_model.py:39-47)
                                  run inside the kernels (sks_geometry, sks_forward, sks_backward*) */
+#define SKS_RAW_GRADS    128u   /* sks_backward with SKS_RAW_PARAMS: dL_dopacity / dL_dscales / dL_drotations are the gradients of the
+                                  LEAF parameters (the activation Jacobians applied here) instead of those of the activated ones */
 #define SKS_BIN_CLEAN    64u    /* sks_forward, binned path: `binning` is as the previous sks_forward with the same V, W, H left it
                                   (completed without error, nothing else written to it since): its per-tile counters are zero
                                   again by then and the clearing launch in front of the call is skipped.  A caller that reuses
@@ -135,6 +137,11 @@ int sks_export_lists(int V, int W, int H, const void* binning, size_t bin_capaci
  * parameter gradients by 1 / N_v instead of re-reading the image.  sums: V x {S_v, N_v} doubles (zeroed by the call). */
 int sks_masked_l2(int V, size_t n_per_view, const float* render, const float* gt, float* dL_unscaled, double* sums,
                   void* stream);
+/* The same as a criterion: additionally loss[v] = S_v / N_v and scale[v] = 1 / N_v (mean != 0; an empty mask gives NaN like the
+ * reference's `error[mask].mean()`), or S_v and 1 (mean == 0): what `l2_loss_gaussian(..., reduction="mean" / "sum")` returns
+ * and what its backward scales dL_unscaled by -- formed on the device by one more tiny launch instead of five tensor ops. */
+int sks_masked_l2_loss(int V, size_t n_per_view, const float* render, const float* gt, float* dL_unscaled, double* sums,
+                       float* loss /* V */, float* scale /* V */, int mean, void* stream);
 
 /* Pseudo-GT heat-maps of a scene (utils/general_utils.py:175-304 generate_heatmaps + normalize_heatmaps).  The
  * reference filters one 255 impulse per joint plane with cupyx gaussian_filter (V*J full-resolution calls) and

@@ -20,6 +20,7 @@ SKS_DEBUG_SYNC = 8
 SKS_NO_NT_STORES = 16
 SKS_RAW_PARAMS = 32
 SKS_BIN_CLEAN = 64
+SKS_RAW_GRADS = 128
 SKS_SSIM_SCRATCH_BYTES = 64 * 8
 
 _vp, _i, _u, _f, _sz = C.c_void_p, C.c_int, C.c_uint, C.c_float, C.c_size_t
@@ -37,6 +38,7 @@ SIGNATURES = {
     "sks_mean_views": (_i, [_i, _i, _vp, _i, _vp, _vp]),
     "sks_export_lists": (_i, [_i, _i, _i, _vp, _sz, _vp, _vp, _vp]),
     "sks_masked_l2": (_i, [_i, _sz, _vp, _vp, _vp, _vp, _vp]),
+    "sks_masked_l2_loss": (_i, [_i, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "sks_fused_ssim_fwd": (_i, [_i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sks_fused_ssim_bwd": (_i, [_i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sks_fused_ssim_bwd_uniform": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp]),

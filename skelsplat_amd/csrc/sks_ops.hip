@@ -528,6 +528,19 @@ __global__ void k_heatmap_totals_finish(int V, double* __restrict__ totals)
     totals[2 * v] = (double)fx * (1.0 / 4294967296.0);
 }
 
+// loss and gradient scale of the criterion from a view's {S, N} (utils/loss_utils.py:96-99): mean -> S / N and 1 / N (an empty
+// mask gives inf * 0 = NaN like torch's mean of nothing), sum -> S and 1
+__global__ void k_masked_l2_finish(int V, const double* __restrict__ sums, float* __restrict__ loss, float* __restrict__ scale,
+                                   int mean)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    const double S = sums[2 * v], N = sums[2 * v + 1];
+    const double sc = mean ? 1.0 / N : 1.0;
+    loss[v] = (float)(S * sc);
+    scale[v] = (float)sc;
+}
+
 }  // namespace
 
 extern "C" {
@@ -543,6 +556,16 @@ int sks_masked_l2(int V, size_t n_per_view, const float* render, const float* gt
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_masked_l2, dim3((unsigned)blocks, V), dim3(256), 0, st, n_per_view, render, gt, dL_unscaled, sums);
+    HIP_TRY2(hipGetLastError());
+    return 0;
+}
+
+int sks_masked_l2_loss(int V, size_t n_per_view, const float* render, const float* gt, float* dL_unscaled, double* sums,
+                       float* loss, float* scale, int mean, void* stream)
+{
+    if (!loss || !scale) return fail2(-2, "masked_l2_loss: missing pointer");
+    if (int rc = sks_masked_l2(V, n_per_view, render, gt, dL_unscaled, sums, stream)) return rc;
+    hipLaunchKernelGGL(k_masked_l2_finish, dim3((V + 63) / 64), dim3(64), 0, (hipStream_t)stream, V, sums, loss, scale, mean);
     HIP_TRY2(hipGetLastError());
     return 0;
 }

@@ -46,16 +46,23 @@ class _FusedL2LossGaussian(torch.autograd.Function):
         r, g = _chk(rendering, "rendering"), _chk(gt, "gt_heatmap")
         if r.shape != g.shape:
             raise RuntimeError(f"rendering {tuple(r.shape)} and gt_heatmap {tuple(g.shape)} differ")
-        dL, S, N = masked_l2(r.reshape(1, -1), g.reshape(1, -1))
-        scale = (1.0 / N) if mean else torch.ones_like(N)       # N == 0 -> inf * 0 = nan, like the mean of nothing
-        ctx.save_for_backward(dL, scale.to(torch.float32))
+        dev = r.device
+        dL = torch.empty_like(r)
+        sums = torch.empty((1, 2), dtype=torch.float64, device=dev)
+        out = torch.empty(2, dtype=torch.float32, device=dev)     # [loss, gradient scale]: N == 0 -> nan, like the mean of nothing
+        with torch.cuda.device(dev):
+            rc = _lib.load().sks_masked_l2_loss(1, r.numel(), r.data_ptr(), g.data_ptr(), dL.data_ptr(), sums.data_ptr(),
+                                                out.data_ptr(), out.data_ptr() + 4, 1 if mean else 0,
+                                                torch._C._cuda_getCurrentRawStream(dev.index))
+        _lib.check(rc, "sks_masked_l2_loss")
+        ctx.save_for_backward(dL, out)
         ctx.shape = rendering.shape
-        return (S * scale).to(torch.float32).reshape(())
+        return out[0]
 
     @staticmethod
     def backward(ctx, gout):
-        dL, scale = ctx.saved_tensors
-        return (dL * (gout.to(torch.float32) * scale)).reshape(ctx.shape), None, None
+        dL, out = ctx.saved_tensors
+        return (dL * (gout * out[1])).reshape(ctx.shape), None, None
 
 
 def l2_loss_gaussian(rendering, gt_heatmap, gt_2d=None, lambda_loss=1.0, reduction="mean"):

@@ -529,13 +529,17 @@ class _RasterizeViews(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, views,
-                scale_modifier, antialiasing, clamp01, debug, bg, single):
+                scale_modifier, antialiasing, clamp01, debug, bg, single, raw=False):
         P = means3D.shape[0] if means3D.dim() == 2 else 0
         feats, src = _features_of(sh, colors_precomp, P)
+        # raw: opacities / scales / rotations are the LEAF parameters; the kernels run sigmoid / exp / normalize themselves and
+        # the backward returns the leaves' gradients (SKS_RAW_PARAMS | SKS_RAW_GRADS): no activation launches around the call
+        tune = (_lib.SKS_RAW_PARAMS | _lib.SKS_RAW_GRADS) if raw else 0
         # check_capacity=True: like the reference, which reads the pair count back on every forward, the autograd path never
         # returns an image (and then gradients) with dropped entries -- a too-small arena is grown and the forward redone
         color, invdepth, radii, st = forward_views(views, means3D, feats, opacities, scales, rotations, cov3Ds_precomp,
-                                                   scale_modifier, antialiasing, clamp01, debug, check_capacity=True)
+                                                   scale_modifier, antialiasing, clamp01, debug, check_capacity=True,
+                                                   tune_flags=tune)
         ctx.st, ctx.src, ctx.bg, ctx.single = st, src, bg, single
         ctx.save_for_backward(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp)
         ctx.mark_non_differentiable(radii)
@@ -562,16 +566,16 @@ class _RasterizeViews(torch.autograd.Function):
         has_cov = cov3Ds_precomp is not None and cov3Ds_precomp.numel() > 0
         return (red(g["means3D"]), red(g["means2D"]), grad_sh, grad_cp, red(g["opacities"]).reshape(opacities.shape),
                 red(g["scales"]), red(g["rotations"]), red(g["cov3D"]) if has_cov else None,
-                None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                        raster_settings, clamp01=False):
+                        raster_settings, clamp01=False, raw_params=False):
     """DGR/diff_gaussian_rasterization_h36m/__init__.py:21-42."""
     views = ViewBatch.from_settings(raster_settings)
     return _RasterizeViews.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                                  views, raster_settings.scale_modifier, bool(raster_settings.antialiasing), clamp01,
-                                 bool(raster_settings.debug), raster_settings.bg, True)
+                                 bool(raster_settings.debug), raster_settings.bg, True, bool(raw_params))
 
 
 def rasterize_views(views: ViewBatch, means3D, means2D, sh, opacities, scales=None, rotations=None, cov3D_precomp=None,
@@ -608,7 +612,10 @@ class GaussianRasterizer(nn.Module):
         return present
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                cov3D_precomp=None, clamp01=False):
+                cov3D_precomp=None, clamp01=False, raw_params=False):
+        """The reference's signature plus two extensions: `clamp01` folds render_*'s clamp(0, 1) into the kernels;
+        `raw_params`: `opacities`, `scales`, `rotations` are the model's LEAF parameters (_opacity logits, _scaling log-scales,
+        raw _rotation, scene/gaussian_model.py:39-47) -- the activations and their Jacobians run inside the kernels."""
         raster_settings = self.raster_settings
         if raster_settings.prefiltered:
             # the reference's kernels TRAP the device when prefiltered is set and a point fails the frustum test
@@ -635,8 +642,10 @@ class GaussianRasterizer(nn.Module):
             if f.shape[-1] != self.num_channels:
                 raise RuntimeError(f"this rasterizer package is fixed to NUM_CHANNELS={self.num_channels}, "
                                    f"got features with {f.shape[-1]} channels")
+        if raw_params and (scales.numel() == 0 or rotations.numel() == 0):
+            raise Exception('raw_params needs the scale/rotation pair (the leaves), not a precomputed 3D covariance')
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
-                                   raster_settings, clamp01=clamp01)
+                                   raster_settings, clamp01=clamp01, raw_params=raw_params)
 
 
 def make_package(num_channels):

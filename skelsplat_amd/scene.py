@@ -328,10 +328,14 @@ class GaussianModel:
         cov = covariance_from_scaling_rotation(self.get_scaling, self._rotation, scaling_modifier)
         return torch.stack([cov[:, 0, 0], cov[:, 0, 1], cov[:, 0, 2], cov[:, 1, 1], cov[:, 1, 2], cov[:, 2, 2]], dim=1)
 
+    # setup_functions, scene/gaussian_model.py:26-47: the activations as attributes, the getters through them (:100-110)
+    scaling_activation = staticmethod(torch.exp)
+    opacity_activation = staticmethod(torch.sigmoid)
+    rotation_activation = staticmethod(torch.nn.functional.normalize)
     get_xyz = property(lambda self: self._xyz)
-    get_scaling = property(lambda self: torch.exp(self._scaling))
-    get_rotation = property(lambda self: torch.nn.functional.normalize(self._rotation))
-    get_opacity = property(lambda self: torch.sigmoid(self._opacity))
+    get_scaling = property(lambda self: self.scaling_activation(self._scaling))
+    get_rotation = property(lambda self: self.rotation_activation(self._rotation))
+    get_opacity = property(lambda self: self.opacity_activation(self._opacity))
     get_features = property(lambda self: self._features_dc)
     get_features_dc = property(lambda self: self._features_dc)
     get_features_rest = property(lambda self: self._features_rest)

@@ -46,9 +46,15 @@ def _model_and_camera(G, key, dev):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fast", [False, True], ids=["literal", "fast-activations"])
 @pytest.mark.parametrize("key", ["h36m", "panoptic", "op"])
-def test_render_hands_the_native_library_what_the_reference_hands_its_own(device, key, monkeypatch):
+def test_render_hands_the_native_library_what_the_reference_hands_its_own(device, key, fast, monkeypatch):
+    """`fast`: gaussian_renderer.FAST_ACTIVATIONS -- the model's LEAF parameters go to the rasterizer, which runs sigmoid / exp /
+    normalize and their Jacobians in its kernels; held to the same reference run (activations of what was handed over ==
+    the reference's activated arguments; images, loss and all five gradients to the same bars)."""
+    import gaussian_renderer
     from gaussian_renderer import render_functions
+    monkeypatch.setattr(gaussian_renderer, "FAST_ACTIVATIONS", fast)
     from skelsplat_amd import rasterizer as R, _lib
     from skelsplat_amd.loop import l2_loss_gaussian, limb_3d_consistency_loss
     G = np.load(GOLD)
@@ -101,6 +107,12 @@ def test_render_hands_the_native_library_what_the_reference_hands_its_own(device
     P, C = G[pre + "fwd_means3D"].shape[0], G[pre + "fwd_sh"].shape[2]
     close = lambda got, want, name, rtol=2e-6: util.assert_close(name, got.detach().cpu().numpy().reshape(want.shape), want,
                                                                   rtol=rtol, atol_scale=1e-6)
+    raw_call = fast and not bool(G[pre + "in_pipe"][0])      # (compute_cov3D_python keeps the literal call)
+    assert bool(int(rec["f"][16]) & _lib.SKS_RAW_PARAMS) == raw_call
+    opac_h, scales_h, rots_h = opac, scales, rots               # what was handed over (pointer checks below)
+    if raw_call:      # the leaves: their activations are what the reference handed to its native module
+        assert opac.data_ptr() == gm._opacity.data_ptr() and scales.data_ptr() == gm._scaling.data_ptr()
+        opac, scales, rots = torch.sigmoid(opac), torch.exp(scales), torch.nn.functional.normalize(rots)
     close(means3D, G[pre + "fwd_means3D"], "means3D")
     close(opac, G[pre + "fwd_opacities"], "opacities")
     close(feats, G[pre + "fwd_sh"], "features (read from `sh`, quirk Q1)")
@@ -122,9 +134,9 @@ def test_render_hands_the_native_library_what_the_reference_hands_its_own(device
     assert f[5] == views.viewmatrix.data_ptr() and f[6] == views.projmatrix.data_ptr()
     assert np.float32(f[7][0]) == np.float32(G[pre + "fwd_tanfovx"]) and np.float32(f[8][0]) == np.float32(G[pre + "fwd_tanfovy"])
     ptr = lambda t: None if t is None or t.numel() == 0 else t.data_ptr()
-    assert f[9] == means3D.data_ptr() and f[11] == opac.data_ptr()
+    assert f[9] == means3D.data_ptr() and f[11] == opac_h.data_ptr()
     assert f[10] == feats.reshape(P, -1).data_ptr()
-    assert (f[12], f[13], f[14]) == (ptr(scales), ptr(rots), ptr(cov))   # NULL == the reference's empty-tensor sentinel (Q10)
+    assert (f[12], f[13], f[14]) == (ptr(scales_h), ptr(rots_h), ptr(cov))   # NULL == the reference's empty-tensor sentinel (Q10)
     assert f[15] == pytest.approx(float(G[pre + "fwd_scale_modifier"])) and float(G[pre + "fwd_scale_modifier"]) == smod
     flags = int(f[16])
     assert bool(flags & _lib.SKS_ANTIALIASING) == bool(G[pre + "fwd_antialiasing"])
