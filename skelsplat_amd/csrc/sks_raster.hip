@@ -270,6 +270,7 @@ int sks_forward(int V, int P, int C, int W, int H, const float* viewmatrix, cons
         // served, k_geom_fwd the header -- SKS_BIN_CLEAN)
         if (!(flags & SKS_BIN_CLEAN)) HIP_TRY(hipMemsetAsync(b.hdr, 0, 256 + (size_t)V * NT * 4, st));
     }
+    if (!small) g.cover = nullptr;   // (the binned path's cover rows come from k_bin_scan)
     hipLaunchKernelGGL(k_geom_fwd, dim3((P + 255) / 256, V), dim3(256), 0, st, P, W, H, vt, viewmatrix, projmatrix,
                        means3D, opacities, scales, rotations, cov3D_precomp, scale_modifier, flags, g, radii, 0,
                        small ? (uint32_t*)nullptr : b.count, small ? (uint32_t*)nullptr : b.touched, features, C,
