@@ -533,6 +533,7 @@ int sks_prof_enable(int on)
     tl_prof->on = on != 0;
     tl_prof->every = (on & 0xffff) > 1 ? (on & 0xffff) : 1;
     tl_prof->skip = (on >> 16) & 3;
+    tl_prof->recorded = (on >> 18) & 1;
     tl_prof->seen[0] = tl_prof->seen[1] = 0;
     return 0;
 }

@@ -17,11 +17,14 @@ views = R.ViewBatch.from_cameras([cam.to(dev) for cam in sc.cameras])
 args = (t(g["means"]), t(g["feat"]), t(g["opac"]), t(g["scales"]), t(g["quats"]), None)
 C, H, W = 17, 2048, 2048
 dL = torch.randn((V, C, H, W), device=dev)
-color, inv, radii, st = R.forward_views(views, *args, bin_capacity=400000)
+color, inv, radii, st = R.forward_views(views, *args, bin_capacity=400000, check_capacity=True)
 print("P", P, "num_rendered per view", st.num_rendered_dev[:V].cpu().tolist(), "visible", int((radii > 0).sum()) / V)
-for name, fn in (("forward", lambda: R.forward_views(views, *args, bin_capacity=400000)),
-                 ("backward", lambda: R.backward_views(st, *args, dL)),
-                 ("fwd+bwd", lambda: R.backward_views(R.forward_views(views, *args, bin_capacity=400000)[3], *args, dL))):
+ws = R.Workspace()     # what a loop does: the same buffers every step (no allocation, no clearing launch: SKS_BIN_CLEAN)
+fwd = lambda: R.forward_views(views, *args, bin_capacity=400000, workspace=ws)
+st = fwd()[3]
+for name, fn in (("forward", fwd),
+                 ("backward", lambda: R.backward_views(st, *args, dL, workspace=ws)),
+                 ("fwd+bwd", lambda: R.backward_views(fwd()[3], *args, dL, workspace=ws))):
     for _ in range(3): fn()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     n = 20

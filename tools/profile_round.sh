@@ -4,7 +4,7 @@
 # --kernel-trace).  Run on the GPU box from the repo root:  bash tools/profile_round.sh r01
 # Outputs land in gpurun_out/prof/; tools/make_profiles.py turns them into profiles/<round>_*.
 set -u
-R=${1:-r03}
+R=${1:-r04}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof
 mkdir -p "$OUT"

@@ -13,8 +13,8 @@ for f in glob.glob("/tmp/trs/**/*kernel_trace.csv", recursive=True):
 rows.sort()
 # the 12th forward call: find k_geom_fwd occurrences
 starts = [i for i, r in enumerate(rows) if r[2].startswith("k_geom_fwd")]
-i0 = starts[12]
+i0 = starts[-6]
 t0 = rows[i0][0]
-for r in rows[i0:i0 + 14]:
+for r in rows[i0:i0 + 12]:
     print(f"{(r[0]-t0)/1e3:9.1f} -> {(r[1]-t0)/1e3:9.1f} us  ({(r[1]-r[0])/1e3:7.1f})  q{r[3]}  {r[2]}")
 PY
