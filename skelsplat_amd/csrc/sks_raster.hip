@@ -278,7 +278,8 @@ int sks_forward(int V, int P, int C, int W, int H, const float* viewmatrix, cons
     STAGE_CHECK("geometry");
 
     FwdArgs a{ P, C, W, H, flags, g, features, out_color, out_invdepth, final_T, n_contrib, composite_slots(flags, V, P),
-               ((1u << 20) + (unsigned)C) / (unsigned)(C + 1), 0 };
+               ((1u << 20) + (unsigned)C) / (unsigned)(C + 1), 0,
+               (W >= 2 && W < 16384) ? (unsigned)(((1ull << 32) + (unsigned)W - 1) / (unsigned)W) : 0u };
     const int cg = pick_cg(C);
     if (small) {
         {
