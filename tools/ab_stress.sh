@@ -3,6 +3,6 @@
 root=$(cd "$(dirname "$0")/.." && pwd)
 for rep in 1 2 3; do
   for lib in "$@"; do
-    SKS_LIB_OVERRIDE=$root/skelsplat_amd/$lib python3 $root/tools/bench_stress.py 2>/dev/null | grep -E "^(forward|backward|fwd\+bwd)" | tr '\n' ' ' | sed "s/^/$lib: /"; echo
+    echo -n "$lib: "; SKS_LIB_OVERRIDE=$root/skelsplat_amd/$lib python3 $root/tools/stress_kernels.py 1 2>/dev/null
   done
 done
