@@ -186,7 +186,8 @@ def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotati
     `workspace`: a Workspace whose tensors receive the outputs (see there).  `check_capacity` (binned path, P > 256):
     True = read the pair count back every call (one host sync, like the reference: rasterizer_impl.cu:283-288) and redo the
     forward with a larger arena when it was too small -- never a wrong image; this is what the autograd / drop-in path
-    uses; "lazy" = never synchronise, detect an overflowed arena at the NEXT call of the shape (which raises: the image
+    uses; "lazy" = never synchronise, detect an overflowed arena at a LATER call of the shape, as soon as the GPU has been through
+    the overflowed one (that call raises: the image
     before it missed entries; the arena has been grown for the calls after it); "auto" (the default of this raw entry
     point, for loops that own their error handling) = True for the first call of a shape, which also sizes the arena with
     50 % headroom over that call's count, lazy afterwards; False = no check."""
@@ -201,12 +202,14 @@ def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotati
             _, _views, args, dev_index, result, cap_check = plan
             if cap_check is not None and check_capacity is not True:
                 try:
-                    _lazy_check(cap_check[2], cap_check[0], cap_check[1])     # the previous call's counts; re-arms the probe
+                    host = _lazy_probe(cap_check[2], cap_check[1])     # earlier calls' counts; a buffer for this call's (or None)
                 except RuntimeError:
                     # the recorded call holds the overflowed arena: drop it, so that the next call takes the validating path
                     # and allocates the grown one (`_BIN_CAP_HINT`)
                     del workspace._plans["fwd"]
                     raise
+                args[23] = None if host is None else host.data_ptr()
+                result[3].num_rendered_dev = host
             rc = _replay(lib.sks_forward, args, dev_index)
             if rc != 0:
                 del workspace._plans["fwd"]     # (the recorded call promises a binning buffer a completed call left behind)
@@ -268,7 +271,7 @@ def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotati
     if lazy:
         # the pair counts go straight to pinned host memory (k_bin_scan stores them there: no copy launch, no event): they are
         # looked at when the NEXT call of the shape comes in -- first the previous call's, which may raise
-        nrend = _lazy_check(cap_key, None, cap)
+        nrend = _lazy_probe(cap_key, cap)     # (None while enough probes are in flight: this call then goes unprobed)
     else:
         nrend = new("nrend", (V + 1,), torch.int32) if binned else None   # [0, V): written by k_bin_scan
     final_T = torch.empty((V, H, W), dtype=torch.float32, device=dev) if want_aux else None
@@ -285,7 +288,7 @@ def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotati
         # the device: check_capacity=True reads it back (exact: grow and redo when the arena was too small -- entries
         # beyond it were dropped); "lazy" (what "auto" does after it has sized the arena once per shape with a
         # synchronous first call) has the counts stored into pinned host memory and looks at them when the NEXT call for the
-        # shape comes in (_lazy_check) -- no host synchronisation, no copy launch on the fast path; an overflow found that way
+        # shape comes in (_lazy_probe) -- no host synchronisation, no copy launch on the fast path; an overflow found that way
         # grows the arena for the calls to come and raises, because the image that call produced was missing entries.
         if not lazy:
             need = int(nrend[:V].max().item())
@@ -315,10 +318,7 @@ def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotati
             if check_capacity is True:
                 cap_check = (nrend, cap, cap_key)
             elif check_capacity:
-                # replays are lazy calls: their counts go to the shape's pinned host buffer
-                host = nrend if lazy else _lazy_check(cap_key, None, cap)
-                args[23] = host.data_ptr()
-                cap_check = (host, cap, cap_key)
+                cap_check = (None, cap, cap_key)     # replays are lazy calls: each takes a probe buffer of the shape (_lazy_probe)
         workspace._plans["fwd"] = (key, (views, keep), args, dev.index, (color, invdepth, radii, st), cap_check)
     return color, invdepth, radii, st
 
@@ -326,35 +326,55 @@ def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotati
 _SCRATCH_BYTES = {}
 _BIN_CAP_HINT = {}     # (device, V, P, C, W, H) -> arena capacity learned from an overflow
 _BIN_CAP_SEEN = set()  # shapes whose arena a synchronous call has sized already ("auto" goes lazy after that)
-_BIN_PROBE = {}        # shape -> (pinned host counts the lazy calls of the shape write, capacity of the last one)
+_BIN_PROBE = {}        # shape -> _Probes: the pinned host buffers lazy calls of the shape write their pair counts into
 
 
-def _lazy_check(cap_key, host, cap):
-    """The lazy capacity check (see forward_views).  Every shape has one pinned int32 buffer that k_bin_scan writes the pair
-    counts of a call into (device-visible host memory: a V-int store, no copy launch, no event).  Called in front of a call:
-    looks at what the previous call of the shape left there (waiting for it if it has not run yet), raises if that call's arena
-    was too small -- the arena has been grown for the calls to come --, re-arms the buffer (-1 = not written yet) and returns
-    it, to be handed to sks_forward as `num_rendered_dev`."""
+class _Probes:
+    __slots__ = ("pending", "free")
+
+    def __init__(self):
+        self.pending, self.free = [], []      # pending: [(pinned int32 tensor, its numpy view, capacity of that call)], oldest first
+
+
+_PROBES_IN_FLIGHT = 8
+
+
+def _lazy_probe(cap_key, cap):
+    """The lazy capacity check (see forward_views): never synchronises.  A probed call hands sks_forward a pinned int32 buffer
+    as `num_rendered_dev`; k_bin_scan stores the call's pair counts there (device-visible host memory: a V-int store, no copy
+    launch, no event).  Called in front of every lazy call of the shape: looks at the buffers of EARLIER calls that the GPU has
+    been through by now (they complete in call order; -1 = not written yet), raises if one of them needed more pairs than its
+    arena held -- that image missed entries; the arena has been grown for the calls to come --, and returns a buffer for this
+    call, or None when _PROBES_IN_FLIGHT calls are still waiting to be looked at (the host runs hundreds of microseconds ahead
+    of the GPU on this path: waiting for the previous call's counts, as an earlier version did, stalled every step)."""
     V = cap_key[1]
-    prev = _BIN_PROBE.get(cap_key)
-    if host is None:
-        host = prev[0] if prev is not None else torch.full((V + 1,), -1, dtype=torch.int32).pin_memory()
-    capturing = torch.cuda.is_current_stream_capturing()
-    if prev is not None and prev[0] is host and not capturing:
-        pcap = prev[1]
-        if int(host[:V].min()) < 0:
-            torch.cuda.current_stream(cap_key[0]).synchronize()     # the previous call has not been through its scan yet
-        pneed = int(host[:V].max()) if int(host[:V].min()) >= 0 else -1     # (still unwritten: that call went elsewhere)
+    st = _BIN_PROBE.get(cap_key)
+    if st is None:
+        st = _BIN_PROBE[cap_key] = _Probes()
+    while st.pending and int(st.pending[0][1][:V].min()) >= 0:
+        host, view, pcap = st.pending.pop(0)
+        pneed = int(view[:V].max())
+        st.free.append((host, view))
         if pneed > pcap:
             _BIN_CAP_HINT[cap_key] = int(pneed * 1.25) + 1024
+            _BIN_ZOMBIES.extend(st.pending)      # (the GPU may still write them: kept alive, never looked at again)
             del _BIN_PROBE[cap_key]
             raise RuntimeError(f"skelsplat_amd: a previous binned forward of this shape needed {pneed} (Gaussian, tile) pairs "
                                f"per view but its arena held {pcap}: that image missed entries.  The arena has been grown; "
                                "call again (check_capacity=True checks every call synchronously).")
-    if not capturing:
-        host[:V] = -1
-    _BIN_PROBE[cap_key] = (host, cap)
+    if torch.cuda.is_current_stream_capturing() or len(st.pending) >= _PROBES_IN_FLIGHT:
+        return None
+    if st.free:
+        host, view = st.free.pop()
+    else:
+        host = torch.empty((V + 1,), dtype=torch.int32).pin_memory()
+        view = host.numpy()
+    view[:V] = -1
+    st.pending.append((host, view, cap))
     return host
+
+
+_BIN_ZOMBIES = []
 
 
 def _scratch_bytes_cached(V, P, C, W, H, cap):
@@ -502,10 +522,9 @@ def export_lists(st: ForwardState):
         rc = lib.sks_export_lists(V, W, H, st.binning.data_ptr(), st.bin_capacity, pl.data_ptr(), rg.data_ptr(),
                                   torch.cuda.current_stream(dev).cuda_stream)
     _lib.check(rc, "sks_export_lists")
-    nr = st.num_rendered_dev[:V]
-    if not nr.is_cuda:      # a lazily checked call: the counts went to the shape's pinned host buffer (see _lazy_check)
-        torch.cuda.current_stream(dev).synchronize()
-        nr = nr.clone()
+    # (a lazily checked call keeps its counts in a pinned host buffer, or nowhere: the ranges say the same -- a view's entries
+    # end where its last non-empty tile's list ends)
+    nr = rg[..., 1].amax(dim=1) if st.num_rendered_dev is None or not st.num_rendered_dev.is_cuda else st.num_rendered_dev[:V]
     return pl, rg, nr
 
 

@@ -696,6 +696,7 @@ def test_binned_capacity_lazy_check_has_no_sync_and_still_catches_overflow(devic
     assert o["R"] > 16
     col0, _, _, st0 = R.forward_views(views, *args, force_binned=True, bin_capacity=16, check_capacity="lazy")
     assert st0.bin_capacity == 16                      # nobody looked yet
+    torch.cuda.synchronize()                           # (the check never waits: it looks at calls the GPU has been through)
     with pytest.raises(RuntimeError, match="missed entries"):
         R.forward_views(views, *args, force_binned=True, check_capacity="lazy")
     col2, _, _, st2 = R.forward_views(views, *args, force_binned=True, check_capacity="lazy")     # default capacity = the grown hint
@@ -969,6 +970,7 @@ def test_workspace_replay_recovers_from_a_lazy_overflow(device):
     ws = R.Workspace()
     R.forward_views(views, *args, force_binned=True, workspace=ws)           # records the plan; nobody has looked yet
     assert "fwd" in ws._plans
+    torch.cuda.synchronize()           # (the probe never waits: it reads the counts of calls the GPU has been through)
     with pytest.raises(RuntimeError, match="missed entries"):
         R.forward_views(views, *args, force_binned=True, workspace=ws)       # replay + probe of call 1
     assert "fwd" not in ws._plans and R._BIN_CAP_HINT[key] >= o["R"]
