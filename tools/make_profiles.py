@@ -78,7 +78,8 @@ st = glob.glob(os.path.join(SRC, "frames_stats", "**", "*kernel_stats.csv"), rec
 if st:   # tools/bench_frames.py 16: the frame-batched loop (16 H36M frames per launch)
     shutil.copy(st[0], os.path.join(DST, f"{rnd}_kernel_stats_frames.csv"))
 for name in ("bench_ssim.txt", "ssim_pmc_fwd.txt", "ssim_pmc_train.txt", "sharded_world1_bench.json", "width_sweep.txt",
-             "frames.txt", "stress_traffic.txt", "stress_timeline.txt", "stress.log"):   # fused-SSIM timings and SQ counter passes, the sharded path at world 1, sweeps
+             "frames.txt", "stress_traffic.txt", "stress_timeline.txt", "stress.log",
+             "dropin_trace_fused.txt", "dropin_trace_tensor.txt"):   # fused-SSIM timings and SQ counter passes, the sharded path at world 1, sweeps
     src = os.path.join(SRC, name)
     if os.path.exists(src) and os.path.getsize(src):
         shutil.copy(src, os.path.join(DST, f"{rnd}_{name}"))

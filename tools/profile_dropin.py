@@ -9,7 +9,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from gaussian_renderer import render_functions
 from skelsplat_amd.heatmaps import generate_heatmaps
-from skelsplat_amd.ops import l2_loss_gaussian
+if "--tensor" in sys.argv:     # the reference's own tensor-op criterion (loss_utils.py:86-100 as restated in loop.py) instead of the fused one
+    from skelsplat_amd.loop import l2_loss_gaussian
+else:
+    from skelsplat_amd.ops import l2_loss_gaussian
 from skelsplat_amd.scene import SyntheticScene, GaussianModel
 
 dev = torch.device("cuda:0")
@@ -54,9 +57,12 @@ for sync in (False, True):
     tot = 1e6 * (time.perf_counter() - t0) / n
     print(f"sync={sync}: render {acc[0]/n:.0f} us, criterion {acc[1]/n:.0f} us, backward {acc[2]/n:.0f} us, optimizer {acc[3]/n:.0f} us; iteration {tot:.0f} us")
 
+if "--no-torch-profiler" in sys.argv:
+    sys.exit(0)
 from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
     for i in range(8):
         it(i)
     torch.cuda.synchronize()
 print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=22, max_name_column_width=48))
+print(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=22, max_name_column_width=60))

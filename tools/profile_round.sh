@@ -33,4 +33,8 @@ SKS_BENCH_FORCE_DIST=1 SKS_GRAPH_COLLECTIVES=1 python3 bench.py --steps 50 --war
 python3 tools/width_sweep2.py 1000,1002,1024,1920 0 > "$OUT/width_sweep.txt" 2>&1
 python3 tools/bench_frames.py 1 2 4 8 16 2>/dev/null | grep "frames/s" > "$OUT/frames.txt"
 FACTORED=0 ONLY_BATCH=1 python3 tools/bench_frames.py 16 2>/dev/null | grep "frames/s" | sed 's/^/planes (factored=False): /' >> "$OUT/frames.txt"
+# the literal drop-in iteration (render -> criterion -> loss.backward(), one view at a time): kernel averages + one iteration's timeline,
+# with the fused criterion and with the reference's tensor-op criterion (whose own ops are ~560 us of GPU time per iteration)
+bash tools/dropin_trace.sh "$OUT/dropin_trace_fused.txt" > /dev/null 2>&1
+bash tools/dropin_trace.sh --tensor "$OUT/dropin_trace_tensor.txt" > /dev/null 2>&1
 find "$OUT" -name "*.csv" | head -40
