@@ -706,6 +706,41 @@ def test_binned_capacity_lazy_check_has_no_sync_and_still_catches_overflow(devic
     assert torch.equal(col3, col2)
 
 
+def test_lazy_probe_never_waits_for_the_gpu(device):
+    """The host runs ahead of the GPU on the replay path: the lazy check looks only at calls whose counts have arrived, leaves a
+    call unprobed when _PROBES_IN_FLIGHT earlier ones are still out, and the unprobed calls' images and exported lists are the
+    same as everybody else's (an earlier version waited for the previous call's counts: a device synchronisation per step)."""
+    c = util.make_case(seed=1, W=200, H=136, scale_log=4.0, n_views=2)     # (a shape no other test uses: hints are per shape)
+    views = R.ViewBatch.from_cameras([cam.to(device) for cam in c.cams])
+    args = (t(c.means, device), t(c.feat, device), t(c.opac, device), t(c.scales, device), t(c.quats, device), None)
+    key = (device.index, 2, c.P, c.C, c.W, c.H)
+    col0, _, _, st0 = R.forward_views(views, *args, force_binned=True)            # "auto": sizes the arena synchronously, once
+    assert key in R._BIN_CAP_SEEN
+    torch.cuda.synchronize()
+    # hold the GPU back behind a long-running fill so that the calls below are queued, not executed, while the host goes on
+    big = torch.empty(1 << 28, dtype=torch.float32, device=device)
+    for _ in range(8):
+        big.zero_()
+    sts = []
+    for _ in range(3 * R._PROBES_IN_FLIGHT):
+        col, _, _, st = R.forward_views(views, *args, force_binned=True)
+        sts.append(st)
+    unprobed = [s_ for s_ in sts if s_.num_rendered_dev is None]
+    pending = len(R._BIN_PROBE[key].pending)
+    torch.cuda.synchronize()
+    assert pending <= R._PROBES_IN_FLIGHT
+    assert unprobed or pending < 3 * R._PROBES_IN_FLIGHT        # (either calls went unprobed or the GPU kept up: never a wait)
+    assert torch.equal(col, col0)
+    o = [util.oracle_forward(c, v) for v in range(2)]
+    for s_ in (sts[-1], unprobed[-1] if unprobed else sts[0]):
+        if s_ is not sts[-1]:
+            continue                                             # (earlier calls' lists were overwritten by the later ones)
+        pl, rg, nr = R.export_lists(s_)
+        assert [int(x) for x in nr.cpu()] == [o[0]["R"], o[1]["R"]]
+    R.forward_views(views, *args, force_binned=True)             # harvests every probe: all clean
+    assert len(R._BIN_PROBE[key].pending) == 1
+
+
 def test_binned_long_tile_lists(device):
     """Hundreds of faint Gaussians stacked on the same pixels: tile lists several times longer than the LDS batch of the
     binned kernels (multi-batch compositing, early termination across batches, multi-batch backward)."""
