@@ -363,9 +363,9 @@ int sks_backward(int V, int P, int C, int W, int H, const float* viewmatrix, con
         const unsigned magic_nt = (unsigned)(((1ull << 32) + (unsigned)NT - 1) / (unsigned)NT), magic_gx = (unsigned)(((1ull << 32) + (unsigned)gx - 1) / (unsigned)gx);
         const bool extra = bg != nullptr || dL_dout_invdepth != nullptr;
         ProfScope prof(1, st);
-        if (dfeat) hipLaunchKernelGGL((k_render_bwd_tile<true, true>), grid, dim3(256), 0, st, a, bv, gx, V, magic_nt, magic_gx, b.tlist, b.hdr);
-        else if (extra) hipLaunchKernelGGL((k_render_bwd_tile<false, true>), grid, dim3(256), 0, st, a, bv, gx, V, magic_nt, magic_gx, b.tlist, b.hdr);
-        else hipLaunchKernelGGL((k_render_bwd_tile<false, false>), grid, dim3(256), 0, st, a, bv, gx, V, magic_nt, magic_gx, b.tlist, b.hdr);
+        if (dfeat) hipLaunchKernelGGL((k_render_bwd_tile<true, true>), grid, dim3(BWD_TILE_THREADS), 0, st, a, bv, gx, V, magic_nt, magic_gx, b.tlist, b.hdr);
+        else if (extra) hipLaunchKernelGGL((k_render_bwd_tile<false, true>), grid, dim3(BWD_TILE_THREADS), 0, st, a, bv, gx, V, magic_nt, magic_gx, b.tlist, b.hdr);
+        else hipLaunchKernelGGL((k_render_bwd_tile<false, false>), grid, dim3(BWD_TILE_THREADS), 0, st, a, bv, gx, V, magic_nt, magic_gx, b.tlist, b.hdr);
         STAGE_CHECK("render-backward(binned)");
     }
     GeomBwdArgs ga{ P, C, W, H, flags, viewmatrix, projmatrix, means3D, opacities, scales, rotations, cov3D_precomp,

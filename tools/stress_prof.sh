@@ -2,6 +2,7 @@
 # Per-kernel averages + one forward/backward timeline of the binned stress config (GPU box):  bash tools/stress_prof.sh [outfile]
 root=$(cd "$(dirname "$0")/.." && pwd)
 out=${1:-$root/gpurun_out/stress_prof.txt}
+case "$out" in /*) ;; *) out="$PWD/$out" ;; esac
 mkdir -p "$(dirname "$out")"
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/sp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/sp -o t -- python3 "$root/tools/bench_stress.py" > /tmp/sp.log 2>&1
