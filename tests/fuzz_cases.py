@@ -1,0 +1,60 @@
+"""One randomised case of the binned path against the CPU oracle (shared by tests/test_fuzz_gpu.py and tools/fuzz_binned.py): image
+sizes that are not multiples of the tile, 1-3 views, 1-40 skeletons at random pitch and scale (tile lists from one entry to several
+hundred), one-hot or dense features, opacities below 1, clamp, antialiasing, a background, with and without the inverse-depth and the
+feature gradient.  Forward bit for bit (colour, inverse depth, contributor counts, final T, tile lists), gradients at the tests'
+tolerance."""
+import numpy as np
+import torch
+
+from tests import util
+from skelsplat_amd import rasterizer as R
+
+GR = (("means3D", "dL_dmeans3D"), ("means2D", "dL_dmeans2D"), ("opacities", "dL_dopacity"), ("scales", "dL_dscales"),
+      ("rotations", "dL_drotations"), ("cov3D", "dL_dcov3D"), ("features", "dL_dcolors"))
+
+
+def run_case(seed, dev, small_path_too=False):
+    """Raises AssertionError (its text names the case) when anything differs."""
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev) if a is not None else None
+    rng = np.random.default_rng(seed)
+    W, H = int(rng.integers(40, 260)), int(rng.integers(40, 200))
+    nv = int(rng.integers(1, 4))
+    nsk = int(rng.choice([1, 2, 6, 18, 40]))
+    kw = dict(seed=seed, W=W, H=H, n_views=nv, n_skeletons=nsk, scale_log=float(rng.uniform(2.5, 4.6)),
+              pitch=float(rng.uniform(20.0, 700.0)), onehot=bool(rng.integers(0, 2)),
+              opac=None if rng.integers(0, 2) else float(rng.choice([0.05, 0.3, 0.6, 1.0])), fxmul=float(rng.uniform(0.6, 1.6)))
+    aa, clamp = bool(rng.integers(0, 2)), bool(rng.integers(0, 3) == 0)
+    use_bg, use_inv, use_feat = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    c = util.make_case(**kw)
+    views = R.ViewBatch.from_cameras([cam.to(dev) for cam in c.cams])
+    args = (t(c.means), t(c.feat), t(c.opac), t(c.scales), t(c.quats), None)
+    tag = f"seed {seed}: {W}x{H} V={nv} P={c.P} aa={aa} clamp={clamp} bg={use_bg} inv={use_inv} feat={use_feat} {kw}"
+    try:
+        col, inv, radii, st, fT, nC = R.forward_views(views, *args, antialiasing=aa, want_aux=True, force_binned=True)
+        pl, rg, nr = R.export_lists(st)
+        outs = []
+        for v in range(nv):
+            o = util.oracle_forward(c, v, antialiasing=aa)
+            outs.append(o)
+            assert np.array_equal(col[v].cpu().numpy(), o["color"]), "color"
+            assert np.array_equal(inv[v, 0].cpu().numpy(), o["invdepth"].reshape(H, W)), "invdepth"
+            assert np.array_equal(nC[v].cpu().numpy().astype(np.uint32), o["n_contrib"]), "n_contrib"
+            assert np.array_equal(fT[v].cpu().numpy(), o["final_T"]), "final_T"
+            assert int(nr[v]) == o["R"] and np.array_equal(rg[v].cpu().numpy(), o["ranges"]), "ranges"
+            assert np.array_equal(pl[v, :o["R"]].cpu().numpy(), o["point_list"]), "point_list"
+        if clamp:
+            col2, _, _, st = R.forward_views(views, *args, antialiasing=aa, clamp01=True, force_binned=True)
+            for v in range(nv):
+                assert np.array_equal(col2[v].cpu().numpy(), np.clip(outs[v]["color"], 0.0, 1.0)), "clamped color"
+        bg = [0.3, 0.1, 0.7] + [0.0] * (c.C - 3) if use_bg else None
+        bgt = None if bg is None else torch.tensor(bg, device=dev)
+        g = R.backward_views(st, *args, t(c.dL_color), t(c.dL_inv) if use_inv else None, bg=bgt, want_dfeatures=use_feat)
+        if not clamp:   # (the oracle's backward has no clamp; the clamped path is held to torch autograd in tests/)
+            for v in range(nv):
+                b = util.oracle_backward(c, v, outs[v], antialiasing=aa, bg=bg, with_inv=use_inv)
+                for ours, theirs in GR:
+                    if g.get(ours) is None:
+                        continue
+                    util.assert_close(f"{theirs} view {v}", g[ours][v].cpu().numpy(), b[theirs].reshape(g[ours][v].shape))
+    except AssertionError as e:
+        raise AssertionError(f"{tag} -> {str(e)[:300]}") from None

@@ -1,0 +1,19 @@
+"""Randomised cases of the binned path against the CPU oracle (tests/fuzz_cases.py).  The sweep found what the hand-written cases
+had missed: a list longer than a wavefront whose first half-tile saturates early left its later entries without strip masks, and
+the backward skipped them in the other half (seeds 1017, 1033, 2034 below)."""
+import pytest
+
+from tests.fuzz_cases import run_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", [1007, 1017, 1033, 2034, 2110, 2135, 2164, 2173])
+def test_cases_the_sweep_once_failed(device, seed):
+    run_case(seed, device)
+
+
+@pytest.mark.parametrize("block", range(6))
+def test_random_binned_cases_match_the_oracle(device, block):
+    for seed in range(5000 + 25 * block, 5000 + 25 * (block + 1)):
+        run_case(seed, device)
