@@ -36,6 +36,7 @@ def run_case(seed, dev, small_path_too=False):
         for v in range(nv):
             o = util.oracle_forward(c, v, antialiasing=aa)
             outs.append(o)
+            assert np.array_equal(radii[v].cpu().numpy(), o["radii"]), "radii"
             assert np.array_equal(col[v].cpu().numpy(), o["color"]), "color"
             assert np.array_equal(inv[v, 0].cpu().numpy(), o["invdepth"].reshape(H, W)), "invdepth"
             assert np.array_equal(nC[v].cpu().numpy().astype(np.uint32), o["n_contrib"]), "n_contrib"
@@ -56,5 +57,17 @@ def run_case(seed, dev, small_path_too=False):
                     if g.get(ours) is None:
                         continue
                     util.assert_close(f"{theirs} view {v}", g[ours][v].cpu().numpy(), b[theirs].reshape(g[ours][v].shape))
+        if c.P <= 256:   # the small path (fill + sparse composite, wave-resident / gather backward) on the same case
+            col, inv, radii, st, fT, nC = R.forward_views(views, *args, antialiasing=aa, want_aux=True, clamp01=clamp)
+            for v in range(nv):
+                o = outs[v]
+                assert np.array_equal(col[v].cpu().numpy(), np.clip(o["color"], 0.0, 1.0) if clamp else o["color"]), "small: color"
+                assert np.array_equal(inv[v, 0].cpu().numpy(), o["invdepth"].reshape(H, W)), "small: invdepth"
+                assert np.array_equal(nC[v].cpu().numpy().astype(np.uint32), o["n_contrib"]), "small: n_contrib"
+                assert np.array_equal(fT[v].cpu().numpy(), o["final_T"]), "small: final_T"
+            g2 = R.backward_views(st, *args, t(c.dL_color), t(c.dL_inv) if use_inv else None, bg=bgt, want_dfeatures=use_feat)
+            for ours, theirs in GR:   # the two paths against each other (clamped or not), then against the oracle
+                if g.get(ours) is not None:
+                    util.assert_close(f"small vs binned {theirs}", g2[ours].cpu().numpy(), g[ours].cpu().numpy())
     except AssertionError as e:
         raise AssertionError(f"{tag} -> {str(e)[:300]}") from None
