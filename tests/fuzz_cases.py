@@ -71,3 +71,57 @@ def run_case(seed, dev, small_path_too=False):
                     util.assert_close(f"small vs binned {theirs}", g2[ours].cpu().numpy(), g[ours].cpu().numpy())
     except AssertionError as e:
         raise AssertionError(f"{tag} -> {str(e)[:300]}") from None
+
+
+def run_fused_loss_case(seed, dev):
+    """The production loop's step -- sks_geometry + sks_backward_fused_loss: no image, no dense gradient, the pseudo-GT as planes
+    or as separable factors -- against the dense device path sks_forward(clamp) -> sks_masked_l2 -> sks_backward on a random
+    scene: odd image sizes, 1-5 views, the skeleton displaced from its pseudo-GT, random Gaussian and heat-map scales."""
+    from skelsplat_amd.ops import masked_l2
+    from skelsplat_amd.scene import SyntheticScene, GaussianModel
+    from skelsplat_amd.heatmaps import generate_heatmaps, heatmap_factors
+    rng = np.random.default_rng(seed)
+    dataset = str(rng.choice(["h36m", "panoptic", "occlusion-person"]))
+    W, H = int(rng.integers(48, 300)), int(rng.integers(48, 220))
+    nv = int(rng.integers(1, 6))
+    scaling, hscale = float(rng.uniform(2.6, 4.6)), float(rng.uniform(0.7, 1.6))
+    fxm, shift = float(rng.uniform(0.7, 1.8)), float(rng.uniform(0.0, 60.0))
+    tag = f"fused-loss seed {seed}: {dataset} {W}x{H} V={nv} scaling={scaling:.2f} heat x{hscale:.2f} fx x{fxm:.2f} shift {shift:.0f} mm"
+    try:
+        sc = SyntheticScene(dataset, n_views=nv, seed=seed, W=W, H=H, ring=2500.0, fx=1145.0 * (W / 1000) * fxm, device=dev)
+        init = sc.pose_3d_init + rng.normal(0.0, shift, sc.pose_3d_init.shape)
+        gm = GaussianModel().create_from_points(init, sc.spatial_lr_scale, sc.n_joints, scaling=scaling, scene_type=dataset, device=dev)
+        gt3d = torch.tensor(sc.pose_3d_gt, device=dev).float()
+        p2d = torch.tensor(sc.poses_2d, device=dev)
+        hm = generate_heatmaps(gt3d, gm.get_scaling.detach() * hscale, gm._rotation.detach(), p2d, sc.cameras)
+        P, C = sc.n_points, sc.n_joints
+        with torch.no_grad():
+            args = (gm._xyz.detach(), gm.get_features.reshape(P, C), gm.get_opacity.detach(), gm.get_scaling.detach(),
+                    gm.get_rotation.detach(), None)
+        views = R.ViewBatch.from_cameras(sc.cameras)
+        color, inv, radii, st = R.forward_views(views, *args, clamp01=True)
+        dL, S, N = masked_l2(color, hm)
+        gd = R.backward_views(st, *args, dL)
+        stats = R.gt_tile_stats(hm)
+        st2 = R.geometry_views(views, args[0], C, args[2], args[3], args[4], None)
+        gs, sums = R.backward_fused_loss(st2, stats, *args)
+        assert torch.equal(st2.radii, radii), "radii"
+        assert torch.equal(sums[:, 1], N), ("mask counts", sums[:, 1], N)
+        assert ((sums[:, 0] - S).abs() <= 1e-5 * S.abs() + 1e-12).all(), ("loss sums", sums[:, 0], S)
+        for k in ("means3D", "means2D", "opacities", "scales", "rotations"):
+            util.assert_close(k, gs[k].cpu(), gd[k].cpu(), rtol=1e-4, atol_scale=1e-5)
+        fac = R.HeatmapFactors(nv, C, W, H, dev)
+        heatmap_factors(gt3d, gm.get_scaling.detach() * hscale, gm._rotation.detach(), p2d, sc.cameras, views=views, out=fac)
+        for v in range(nv):
+            assert torch.equal(fac.planes(v), hm[v]), "factor planes"
+        fst = R.GtStats()
+        fst.gt, fst.tile_S, fst.tile_N, fst.factors = None, None, None, fac
+        fst.totals = fac.totals(views, torch.empty((nv, 2), dtype=torch.float64, device=dev))
+        assert torch.equal(fst.totals[:, 1], stats.totals[:, 1]), "factor totals N"
+        gf, sums_f = R.backward_fused_loss(st2, fst, *args)
+        assert torch.equal(sums_f[:, 1], sums[:, 1]), "factor mask counts"
+        for k in ("means3D", "means2D", "opacities", "scales", "rotations"):
+            assert torch.equal(gf[k], gs[k]), f"factors vs planes {k}"
+        return dict(mask_pixels=float(N.min()), grad=float(gd["means3D"].abs().max()))   # (how much the case exercised)
+    except AssertionError as e:
+        raise AssertionError(f"{tag} -> {str(e)[:300]}") from None

@@ -17,3 +17,13 @@ def test_cases_the_sweep_once_failed(device, seed):
 def test_random_binned_cases_match_the_oracle(device, block):
     for seed in range(5000 + 25 * block, 5000 + 25 * (block + 1)):
         run_case(seed, device)
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_random_fused_loss_steps_match_the_dense_path(device, block):
+    from tests.fuzz_cases import run_fused_loss_case
+    live = 0
+    for seed in range(300 + 25 * block, 300 + 25 * (block + 1)):
+        r = run_fused_loss_case(seed, device)
+        live += r["mask_pixels"] > 100 and r["grad"] > 0
+    assert live >= 20     # (the cases are not vacuous)

@@ -1,5 +1,5 @@
 """Randomised parity sweep of the binned path against the CPU oracle (GPU box); the cases are tests/fuzz_cases.py's.
-    python tools/fuzz_binned.py [cases] [seed0]"""
+    python tools/fuzz_binned.py [cases] [seed0] [loss]     (loss: the sparse fused-loss step against the dense device path)"""
 import os
 import sys
 import time
@@ -7,17 +7,24 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
-from tests.fuzz_cases import run_case
+from tests.fuzz_cases import run_case, run_fused_loss_case
 
 dev = torch.device("cuda:0")
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
-bad, t0 = 0, time.time()
+bad, t0, seen = 0, time.time(), []
+which = run_fused_loss_case if len(sys.argv) > 3 and sys.argv[3] == "loss" else run_case
 for k in range(n_cases):
     try:
-        run_case(seed0 + k, dev)
+        seen.append(which(seed0 + k, dev))
     except AssertionError as e:
         bad += 1
         print("FAIL", str(e)[:500], flush=True)
 print(f"{n_cases} cases, {bad} failed, {time.time() - t0:.0f} s")
+seen = [x for x in seen if x]
+if seen:
+    import statistics
+    for key in seen[0]:
+        vals = sorted(x[key] for x in seen)
+        print(f"  {key}: min {vals[0]:.3g}, median {statistics.median(vals):.3g}, max {vals[-1]:.3g}; zero in {sum(v == 0 for v in vals)} cases")
 sys.exit(1 if bad else 0)
