@@ -125,3 +125,47 @@ def run_fused_loss_case(seed, dev):
         return dict(mask_pixels=float(N.min()), grad=float(gd["means3D"].abs().max()))   # (how much the case exercised)
     except AssertionError as e:
         raise AssertionError(f"{tag} -> {str(e)[:300]}") from None
+
+
+def run_loop_case(seed, dev):
+    """MultiViewLoop's production path (sparse fused step, device-side Adam tail, hipGraph) against its dense per-launch path (full
+    images, sks_masked_l2, dense backward, the same optimiser) on a random scene: 1-6 views under an accumulation_steps of 1-5 (quirk
+    Q8: V != accumulation_steps), odd image sizes, the three datasets, antialiasing, opacity on or off, 8-40 iterations."""
+    from skelsplat_amd.loop import MultiViewLoop
+    from skelsplat_amd.scene import SyntheticScene, GaussianModel
+    from skelsplat_amd.heatmaps import generate_heatmaps
+    rng = np.random.default_rng(seed)
+    dataset = str(rng.choice(["h36m", "panoptic", "occlusion-person"]))
+    W, H = int(rng.integers(64, 240)), int(rng.integers(64, 200))
+    nv, acc = int(rng.integers(1, 7)), int(rng.integers(1, 6))
+    iters = int(rng.integers(2, 9)) * acc + int(rng.integers(0, acc))
+    scaling, fxm = float(rng.uniform(3.0, 4.4)), float(rng.uniform(0.9, 1.7))
+    aa, op_on = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    lam = float(rng.choice([0.0, 1e-5, 1e-2]))
+    tag = f"loop seed {seed}: {dataset} {W}x{H} V={nv} acc={acc} iterations={iters} scaling={scaling:.2f} aa={aa} opacity={op_on} lambda={lam}"
+    try:
+        sc = SyntheticScene(dataset, n_views=nv, seed=seed, W=W, H=H, ring=2500.0, fx=1145.0 * (W / 1000) * fxm, device=dev)
+        outs = []
+        for sparse in (True, False):
+            gm = GaussianModel().create_from_points(sc.pose_3d_init, sc.spatial_lr_scale, sc.n_joints, scaling=scaling,
+                                                    opacity_on=op_on, scene_type=dataset, device=dev)
+            gm.training_setup()
+            hm = generate_heatmaps(gm._xyz.detach(), gm.get_scaling.detach(), gm._rotation.detach(),
+                                   torch.tensor(sc.poses_2d, device=dev), sc.cameras)
+            loop = MultiViewLoop(gm, sc.cameras, hm, dataset=dataset, accumulation_steps=acc, lambda_consistency=lam,
+                                 antialiasing=aa, sparse=sparse, use_graph=sparse)
+            assert loop.sparse == sparse
+            loop.run(iters)
+            outs.append((gm._xyz.detach().cpu().clone(), gm._scaling.detach().cpu().clone(), gm._opacity.detach().cpu().clone()))
+        init = torch.tensor(sc.pose_3d_init).float()
+        moved = (outs[1][0] - init).norm(dim=1).mean().item()
+        diff = (outs[0][0] - outs[1][0]).norm(dim=1).max().item()
+        assert diff <= 2e-3 * max(moved, 0.05) + 1e-4, ("joints", diff, moved)
+        util.assert_close("scaling", outs[0][1], outs[1][1], rtol=1e-4, atol_scale=1e-4)
+        fin = torch.isfinite(outs[1][2])
+        assert torch.equal(fin, torch.isfinite(outs[0][2])), "opacity finiteness"
+        if fin.any():
+            util.assert_close("opacity", outs[0][2][fin], outs[1][2][fin], rtol=1e-4, atol_scale=1e-4)
+        return dict(moved_mm=moved, steps=iters // acc)
+    except AssertionError as e:
+        raise AssertionError(f"{tag} -> {str(e)[:300]}") from None

@@ -27,3 +27,12 @@ def test_random_fused_loss_steps_match_the_dense_path(device, block):
         r = run_fused_loss_case(seed, device)
         live += r["mask_pixels"] > 100 and r["grad"] > 0
     assert live >= 20     # (the cases are not vacuous)
+
+
+@pytest.mark.parametrize("block", range(3))
+def test_random_production_loops_match_the_dense_loop(device, block):
+    from tests.fuzz_cases import run_loop_case
+    live = 0
+    for seed in range(100 + 20 * block, 100 + 20 * (block + 1)):
+        live += run_loop_case(seed, device)["moved_mm"] > 1.0    # (one camera: scene extent 0, the joints do not move)
+    assert live >= 12
