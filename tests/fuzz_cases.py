@@ -169,3 +169,57 @@ def run_loop_case(seed, dev):
         return dict(moved_mm=moved, steps=iters // acc)
     except AssertionError as e:
         raise AssertionError(f"{tag} -> {str(e)[:300]}") from None
+
+
+def run_frames_case(seed, dev):
+    """FrameBatchLoop (F frames per launch, planes or factors, hipGraph or not) against MultiViewLoops running the frames one by
+    one: every frame's parameters, Adam moments, V-slot buffers and counters BIT FOR BIT, on a random scene (1-8 frames, 1-9 views,
+    odd image sizes, the three datasets, dropped heat-map planes)."""
+    from skelsplat_amd.loop import MultiViewLoop, FrameBatchLoop
+    from skelsplat_amd.scene import SyntheticScene, GaussianModel
+    from skelsplat_amd.heatmaps import generate_heatmaps
+    rng = np.random.default_rng(seed)
+    dataset = str(rng.choice(["h36m", "panoptic", "occlusion-person"]))
+    W, H = int(rng.integers(64, 220)), int(rng.integers(64, 180))
+    F, V = int(rng.integers(1, 9)), int(rng.integers(1, 10))
+    F = min(F, 64 // V)          # (SKS_MAX_VIEWS views per launch)
+    iters = 4 * int(rng.integers(1, 8)) + int(rng.integers(0, 4))
+    use_graph, factored = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    gpg = int(rng.integers(1, 5))
+    tag = f"frames seed {seed}: {dataset} {W}x{H} F={F} V={V} iterations={iters} graph={use_graph}/{gpg} factored={factored}"
+    try:
+        sc = SyntheticScene(dataset, n_views=V, seed=seed, W=W, H=H, ring=2500.0, fx=1145.0 * (W / 1000) * 1.5, device=dev)
+
+        def model():
+            gm = GaussianModel().create_from_points(sc.pose_3d_init, sc.spatial_lr_scale, sc.n_joints, scaling=3.9,
+                                                    scene_type=dataset, device=dev)
+            gm.training_setup()
+            return gm
+        cams, J = sc.cameras, sc.n_joints
+        base3, base2 = np.asarray(sc.pose_3d_init, np.float32), np.asarray(sc.poses_2d, np.float32)
+        pts = np.stack([base3 + rng.normal(0, 25.0 * (f + 1), base3.shape) for f in range(F)]).astype(np.float32)
+        p2d = np.stack([base2 + rng.normal(0, 2.0 * (f + 1), base2.shape) for f in range(F)]).astype(np.float32)
+        drop = torch.tensor(rng.random((F, V, J)) < 0.04)
+        fb = FrameBatchLoop(model(), cams, F, dataset=dataset, use_graph=use_graph, factored=factored)
+        fb.new_scenes(pts, poses_2d=p2d, drop_masks=drop)
+        out = fb.run(iters, groups_per_graph=gpg).clone()
+        for f in range(F):
+            gm = model()
+            hm0 = torch.zeros((V, J, H, W), device=dev)
+            loop = MultiViewLoop(gm, cams, hm0, dataset=dataset, sparse=True, use_graph=use_graph, fused_tail=True)
+            gm.reset_from_points(pts[f])
+            for slots, vb, gt, stats, idx in loop.size_groups:
+                generate_heatmaps(gm._xyz.detach(), gm.get_scaling.detach(), gm._rotation.detach(),
+                                  torch.tensor(p2d[f][slots], device=dev), [cams[k] for k in slots], out=gt, views=vb,
+                                  totals=stats.totals, drop_mask=drop[f][slots])
+            loop.run(iters, groups_per_graph=gpg)
+            assert torch.equal(out[f], gm._xyz.detach()), f"xyz of frame {f}"
+            assert torch.equal(fb.scaling[f], gm._scaling.detach()) and torch.equal(fb.rotation[f], gm._rotation.detach()), f"frame {f}"
+            assert torch.equal(fb.opacity[f], gm._opacity.detach()), f"opacity of frame {f}"
+            assert torch.equal(fb.exp_avg[f], loop.exp_avg) and torch.equal(fb.exp_avg_sq[f], loop.exp_avg_sq), f"moments of frame {f}"
+            assert torch.equal(fb.accumulated_grads[f], loop.accumulated_grads), f"slots of frame {f}"
+            assert torch.equal(fb.counters[f], loop.counters), f"counters of frame {f}"
+        moved = float((out - torch.tensor(pts, device=dev)).norm(dim=2).mean())
+        return dict(moved_mm=moved, frames=F)
+    except AssertionError as e:
+        raise AssertionError(f"{tag} -> {str(e)[:300]}") from None

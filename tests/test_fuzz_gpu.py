@@ -36,3 +36,12 @@ def test_random_production_loops_match_the_dense_loop(device, block):
     for seed in range(100 + 20 * block, 100 + 20 * (block + 1)):
         live += run_loop_case(seed, device)["moved_mm"] > 1.0    # (one camera: scene extent 0, the joints do not move)
     assert live >= 12
+
+
+@pytest.mark.parametrize("block", range(2))
+def test_random_frame_batches_equal_separate_loops_bit_for_bit(device, block):
+    from tests.fuzz_cases import run_frames_case
+    live = 0
+    for seed in range(100 + 20 * block, 100 + 20 * (block + 1)):
+        live += run_frames_case(seed, device)["moved_mm"] > 1.0
+    assert live >= 12
