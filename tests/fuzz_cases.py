@@ -18,6 +18,8 @@ def run_case(seed, dev, small_path_too=False):
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev) if a is not None else None
     rng = np.random.default_rng(seed)
     W, H = int(rng.integers(40, 260)), int(rng.integers(40, 200))
+    if seed % 8 == 0:    # wide and flat: the row-aligned fill mode (W % 32 == 0, >= 90 % of a 1024-pixel chunk) and its neighbours
+        W, H = int(rng.choice([928, 960, 1000, 1002, 1024, 1056, 1990, 2048])), int(rng.integers(20, 70))
     nv = int(rng.integers(1, 4))
     nsk = int(rng.choice([1, 2, 6, 18, 40]))
     kw = dict(seed=seed, W=W, H=H, n_views=nv, n_skeletons=nsk, scale_log=float(rng.uniform(2.5, 4.6)),
@@ -221,5 +223,62 @@ def run_frames_case(seed, dev):
             assert torch.equal(fb.counters[f], loop.counters), f"counters of frame {f}"
         moved = float((out - torch.tensor(pts, device=dev)).norm(dim=2).mean())
         return dict(moved_mm=moved, frames=F)
+    except AssertionError as e:
+        raise AssertionError(f"{tag} -> {str(e)[:300]}") from None
+
+
+def run_dropin_case(seed, dev):
+    """The drop-in surface: gaussian_renderer.render_* -> GaussianRasterizer -> autograd, with the model's LEAF parameters handed
+    to the kernels (FAST_ACTIVATIONS: sigmoid / exp / normalize and their Jacobians in-kernel) against the literal path (torch
+    activations around the call), on a random model: image, radii, and the gradients of every leaf."""
+    import types
+    import gaussian_renderer
+    from gaussian_renderer import render_functions
+    from skelsplat_amd.scene import SyntheticScene, GaussianModel, DATASETS
+    from skelsplat_amd.loop import l2_loss_gaussian
+    rng = np.random.default_rng(seed)
+    dataset = str(rng.choice(["h36m", "panoptic", "occlusion-person"]))
+    W, H = int(rng.integers(48, 260)), int(rng.integers(48, 200))
+    aa = bool(rng.integers(0, 2))
+    smod = float(rng.choice([1.0, 1.25, 0.8]))
+    tag = f"drop-in seed {seed}: {dataset} {W}x{H} aa={aa} scaling_modifier={smod}"
+    try:
+        sc = SyntheticScene(dataset, n_views=2, seed=seed, W=W, H=H, ring=2500.0, fx=1145.0 * (W / 1000) * float(rng.uniform(0.8, 1.7)),
+                            device=dev)
+        res = []
+        torch.manual_seed(seed)
+        J = sc.n_joints
+        d_scale = torch.randn(J, 3, device=dev) * 0.3
+        d_rot = torch.randn(J, 4, device=dev) * 0.5
+        d_op = torch.randn(J, 1, device=dev)
+        gt = torch.rand(J, H, W, device=dev) * (torch.rand(J, H, W, device=dev) > 0.8)
+        for fast in (True, False):
+            gm = GaussianModel().create_from_points(sc.pose_3d_init, sc.spatial_lr_scale, J, scaling=float(3.0 + (seed % 7) * 0.2),
+                                                    opacity_on=True, scene_type=dataset, device=dev)
+            with torch.no_grad():
+                gm._scaling += d_scale
+                gm._rotation += d_rot
+                gm._opacity.copy_(d_op)
+            gm.training_setup()
+            old = gaussian_renderer.FAST_ACTIVATIONS
+            gaussian_renderer.FAST_ACTIVATIONS = fast
+            try:
+                pipe = types.SimpleNamespace(debug=False, antialiasing=aa, compute_cov3D_python=False, convert_SHs_python=False)
+                pkg = render_functions[DATASETS[dataset]["rendering"]](sc.cameras[seed % 2], gm, pipe, torch.zeros(3, device=dev),
+                                                                       scaling_modifier=smod)
+                loss, _ = l2_loss_gaussian(pkg["render"], gt)
+                loss.backward()
+            finally:
+                gaussian_renderer.FAST_ACTIVATIONS = old
+            res.append(dict(render=pkg["render"].detach().cpu().numpy(), radii=pkg["radii"].cpu().numpy(),
+                            xyz=gm._xyz.grad.cpu().numpy(), scaling=gm._scaling.grad.cpu().numpy(),
+                            rotation=gm._rotation.grad.cpu().numpy(), opacity=gm._opacity.grad.cpu().numpy(),
+                            screen=pkg["viewspace_points"].grad.cpu().numpy()))
+        a, b = res
+        assert np.array_equal(a["radii"], b["radii"]), "radii"
+        util.assert_close("render", a["render"], b["render"], rtol=1e-5, atol_scale=1e-6)
+        for k in ("xyz", "scaling", "rotation", "opacity", "screen"):
+            util.assert_close(k, a[k], b[k], rtol=2e-4, atol_scale=1e-5)
+        return dict(visible=float((a["radii"] > 0).sum()), grad=float(np.abs(b["xyz"]).max()))
     except AssertionError as e:
         raise AssertionError(f"{tag} -> {str(e)[:300]}") from None

@@ -45,3 +45,10 @@ def test_random_frame_batches_equal_separate_loops_bit_for_bit(device, block):
     for seed in range(100 + 20 * block, 100 + 20 * (block + 1)):
         live += run_frames_case(seed, device)["moved_mm"] > 1.0
     assert live >= 12
+
+
+@pytest.mark.parametrize("block", range(2))
+def test_random_models_through_the_drop_in_surface_fast_vs_literal_activations(device, block):
+    from tests.fuzz_cases import run_dropin_case
+    for seed in range(100 + 25 * block, 100 + 25 * (block + 1)):
+        assert run_dropin_case(seed, device)["visible"] > 0
