@@ -282,3 +282,58 @@ def run_dropin_case(seed, dev):
         return dict(visible=float((a["radii"] > 0).sum()), grad=float(np.abs(b["xyz"]).max()))
     except AssertionError as e:
         raise AssertionError(f"{tag} -> {str(e)[:300]}") from None
+
+
+def run_ops_case(seed, dev):
+    """The smaller ops on random shapes against plain torch: fused masked L2 (any element count, 1-6 views), fused SSIM against the
+    conv2d form (any image size), the 3-NN mean distance against brute force (both searches)."""
+    import torch.nn.functional as Fn
+    from skelsplat_amd import ops
+    rng = np.random.default_rng(seed)
+    g = torch.Generator(device=dev).manual_seed(seed)
+    try:
+        # masked L2
+        V, C, H, W = int(rng.integers(1, 7)), int(rng.integers(1, 20)), int(rng.integers(1, 90)), int(rng.integers(1, 130))
+        dens = float(rng.choice([0.0, 0.02, 0.5, 1.0]))
+        r = torch.rand((V, C, H, W), device=dev, generator=g) * (torch.rand((V, C, H, W), device=dev, generator=g) < dens)
+        t_ = torch.rand((V, C, H, W), device=dev, generator=g) * (torch.rand((V, C, H, W), device=dev, generator=g) < dens)
+        dL, S, N = ops.masked_l2(r, t_)
+        m = (t_ > 0) | (r > 0)
+        assert torch.equal(N, m.sum(dim=(1, 2, 3)).double()), f"masked_l2 {V}x{C}x{H}x{W} density {dens}: N"
+        wantS = (((r - t_).double() ** 2) * m).sum(dim=(1, 2, 3))
+        assert ((S - wantS).abs() <= 1e-5 * wantS.abs() + 1e-12).all(), f"masked_l2 {V}x{C}x{H}x{W}: S {S} vs {wantS}"
+        assert torch.equal(dL, 2.0 * (r - t_) * m), f"masked_l2 {V}x{C}x{H}x{W}: dL"
+        # 3-NN mean squared distance
+        P = int(rng.choice([1, 2, 3, 4, 5, 17, 19, 64, 300, 2500]))
+        pts = torch.randn((P, 3), device=dev, generator=g) * float(rng.uniform(0.1, 1000.0))
+        d2 = torch.cdist(pts.double(), pts.double()) ** 2
+        d2.fill_diagonal_(float("inf"))
+        k = min(3, P - 1)
+        if P >= 4:
+            want = d2.topk(3, largest=False).values.mean(dim=1).float()
+            for method in ("allpairs", "grid"):
+                got = ops.distCUDA2(pts, method=method)
+                assert torch.allclose(got, want, rtol=2e-4, atol=1e-6 * float(want.max())), f"knn P={P} {method}"
+        # fused SSIM
+        B, Cs, Hs, Ws = int(rng.integers(1, 4)), int(rng.integers(1, 6)), int(rng.integers(1, 120)), int(rng.integers(1, 150))
+        a = torch.rand((B, Cs, Hs, Ws), device=dev, generator=g).requires_grad_(True)
+        b = torch.rand((B, Cs, Hs, Ws), device=dev, generator=g)
+        from fused_ssim import fused_ssim
+        got = fused_ssim(a, b)
+        got.backward()
+        ga = a.grad.clone()
+        a2 = a.detach().clone().requires_grad_(True)
+        win = torch.tensor([0.001028380123898387, 0.0075987582094967365, 0.036000773310661316, 0.10936068743467331,
+                            0.21300552785396576, 0.26601171493530273, 0.21300552785396576, 0.10936068743467331,
+                            0.036000773310661316, 0.0075987582094967365, 0.001028380123898387], device=dev)
+        w2 = (win[:, None] * win[None, :]).expand(Cs, 1, 11, 11).contiguous()
+        conv = lambda x: Fn.conv2d(x, w2, padding=5, groups=Cs)
+        mu1, mu2 = conv(a2), conv(b)
+        s1, s2, s12 = conv(a2 * a2) - mu1 * mu1, conv(b * b) - mu2 * mu2, conv(a2 * b) - mu1 * mu2
+        ref = (((2 * mu1 * mu2 + 0.01 ** 2) * (2 * s12 + 0.03 ** 2)) / ((mu1 * mu1 + mu2 * mu2 + 0.01 ** 2) * (s1 + s2 + 0.03 ** 2))).mean()
+        ref.backward()
+        assert abs(got.item() - ref.item()) <= 2e-5 * abs(ref.item()) + 1e-6, f"ssim {B}x{Cs}x{Hs}x{Ws}: {got.item()} vs {ref.item()}"
+        assert torch.allclose(ga, a2.grad, rtol=2e-3, atol=2e-5 * float(a2.grad.abs().max()) + 1e-9), f"ssim grad {B}x{Cs}x{Hs}x{Ws}"
+        return dict(mask=float(N.sum()), points=float(P))
+    except AssertionError as e:
+        raise AssertionError(f"ops seed {seed} -> {str(e)[:300]}") from None

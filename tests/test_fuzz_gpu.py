@@ -52,3 +52,10 @@ def test_random_models_through_the_drop_in_surface_fast_vs_literal_activations(d
     from tests.fuzz_cases import run_dropin_case
     for seed in range(100 + 25 * block, 100 + 25 * (block + 1)):
         assert run_dropin_case(seed, device)["visible"] > 0
+
+
+@pytest.mark.parametrize("block", range(2))
+def test_random_shapes_through_the_smaller_ops(device, block):
+    from tests.fuzz_cases import run_ops_case
+    for seed in range(100 + 30 * block, 100 + 30 * (block + 1)):
+        run_ops_case(seed, device)
