@@ -39,9 +39,9 @@ CASES = {
     # name: config file, dataset key of the synthetic scene, V, W, H, iterations, overrides
     "h36m_small": dict(cfg="h36m", dataset="h36m", V=4, W=64, H=48, iters=40, fx=1145.0 * 0.064 * 1.5, ring=2500.0),
     "h36m_mid": dict(cfg="h36m", dataset="h36m", V=4, W=112, H=96, iters=500, fx=1145.0 * 0.112 * 1.5, ring=2500.0),
-    "h36m_full": dict(cfg="h36m", dataset="h36m", V=4, W=1000, H=1000, iters=100),
+    "h36m_full": dict(cfg="h36m", dataset="h36m", V=4, W=1000, H=1000, iters=400),
     "h36m_mixed": dict(cfg="h36m", dataset="h36m", V=4, W=1000, H=1000, iters=40, widths=[1002, 1000, 1000, 1002]),
-    "panoptic_full": dict(cfg="panoptic", dataset="panoptic", V=31, W=1920, H=1080, iters=62,
+    "panoptic_full": dict(cfg="panoptic", dataset="panoptic", V=31, W=1920, H=1080, iters=186,
                           over={"dataset.nviews": 31, "training.accumulation_steps": 31}),
     # round 4: the shipped configs and loop quirks the five cases above do not touch
     "op_720p": dict(cfg="occlusion-person", dataset="occlusion-person", V=4, W=1280, H=720, iters=48),   # -op package, C = 15,

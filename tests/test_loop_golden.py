@@ -7,10 +7,11 @@ Adam(eps=1e-15) -- over the reference's own GaussianModel, Camera, generate_heat
 oracle/sks_oracle.c standing in for the CUDA module.  Held to it here:
   * CPU: tests/ref_loop.py (the restated loop the other loop tests compare with) on the small case;
   * GPU: MultiViewLoop on the production path (HIP heat-maps, sparse fused step, hipGraphs) at 64x48, 112x96 (a whole
-    500-iteration scene), BASELINE config 2 at 1000x1000 (100 iterations = 25 optimiser steps) and with H36M's 1002-wide
-    sensor mix (40), and Panoptic's 31 views at 1920x1080 (two accumulation groups).  (The full-size runs are as long as
-    the build container's memory allows: the reference's loop keeps every iteration's autograd graph alive --
-    `accumulated_grads[idx] = grads_xyz` with create_graph=True, train.py:161,175 -- ~150 MB per iteration at 1000x1000.)
+    500-iteration scene), BASELINE config 2 at 1000x1000 (400 iterations = 100 optimiser steps) and with H36M's 1002-wide
+    sensor mix (40), and Panoptic's 31 views at 1920x1080 (186 iterations = six accumulation groups).  (The full-size runs are as
+    long as the build container's memory allows: the reference's loop keeps every iteration's autograd graph alive --
+    `accumulated_grads[idx] = grads_xyz` with create_graph=True, train.py:161,175 -- ~100 MB per iteration at 1000x1000, ~200 MB at
+    1920x1080: 36 GB at the end of the Panoptic run.)
 Bars: joints within 0.5 mm and MPJPE within 0.5 mm of the reference's (north_star), and within 2 % of the distance the
 joints moved; log-scales to 1e-3 of their change + 1e-4.  Rotations are compared where they mean something -- through the
 covariances R S^2 R^T the rasterizer sees (5e-4 of the largest variance) --, not component by component: with the initial
