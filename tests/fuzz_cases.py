@@ -7,6 +7,7 @@ import numpy as np
 import torch
 
 from tests import util
+from oracle import oracle as orc_mod
 from skelsplat_amd import rasterizer as R
 
 GR = (("means3D", "dL_dmeans3D"), ("means2D", "dL_dmeans2D"), ("opacities", "dL_dopacity"), ("scales", "dL_dscales"),
@@ -27,16 +28,23 @@ def run_case(seed, dev, small_path_too=False):
               opac=None if rng.integers(0, 2) else float(rng.choice([0.05, 0.3, 0.6, 1.0])), fxmul=float(rng.uniform(0.6, 1.6)))
     aa, clamp = bool(rng.integers(0, 2)), bool(rng.integers(0, 3) == 0)
     use_bg, use_inv, use_feat = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    smod = float(rng.choice([1.0, 1.0, 1.25, 0.7]))             # raster_settings.scale_modifier
+    precomp = bool(rng.integers(0, 4) == 0)                      # pipe.compute_cov3D_python: six numbers per Gaussian, no scales / rotations
     c = util.make_case(**kw)
     views = R.ViewBatch.from_cameras([cam.to(dev) for cam in c.cams])
-    args = (t(c.means), t(c.feat), t(c.opac), t(c.scales), t(c.quats), None)
-    tag = f"seed {seed}: {W}x{H} V={nv} P={c.P} aa={aa} clamp={clamp} bg={use_bg} inv={use_inv} feat={use_feat} {kw}"
+    cov = None
+    if precomp:
+        cov = orc_mod.forward(c.means, c.feat, c.opac, c.scales, c.quats, None, c.ocams[0], scale_modifier=smod)["cov3D"].astype(np.float32)
+    o_args = (c.means, c.feat, c.opac, None, None, cov) if precomp else (c.means, c.feat, c.opac, c.scales, c.quats, None)
+    args = tuple(t(x) for x in o_args)
+    tag = (f"seed {seed}: {W}x{H} V={nv} P={c.P} aa={aa} clamp={clamp} bg={use_bg} inv={use_inv} feat={use_feat} "
+           f"scale_modifier={smod} cov3D_precomp={precomp} {kw}")
     try:
-        col, inv, radii, st, fT, nC = R.forward_views(views, *args, antialiasing=aa, want_aux=True, force_binned=True)
+        col, inv, radii, st, fT, nC = R.forward_views(views, *args, scale_modifier=smod, antialiasing=aa, want_aux=True, force_binned=True)
         pl, rg, nr = R.export_lists(st)
         outs = []
         for v in range(nv):
-            o = util.oracle_forward(c, v, antialiasing=aa)
+            o = orc_mod.forward(*o_args, c.ocams[v], scale_modifier=smod, antialiasing=aa)
             outs.append(o)
             assert np.array_equal(radii[v].cpu().numpy(), o["radii"]), "radii"
             assert np.array_equal(col[v].cpu().numpy(), o["color"]), "color"
@@ -46,7 +54,7 @@ def run_case(seed, dev, small_path_too=False):
             assert int(nr[v]) == o["R"] and np.array_equal(rg[v].cpu().numpy(), o["ranges"]), "ranges"
             assert np.array_equal(pl[v, :o["R"]].cpu().numpy(), o["point_list"]), "point_list"
         if clamp:
-            col2, _, _, st = R.forward_views(views, *args, antialiasing=aa, clamp01=True, force_binned=True)
+            col2, _, _, st = R.forward_views(views, *args, scale_modifier=smod, antialiasing=aa, clamp01=True, force_binned=True)
             for v in range(nv):
                 assert np.array_equal(col2[v].cpu().numpy(), np.clip(outs[v]["color"], 0.0, 1.0)), "clamped color"
         bg = [0.3, 0.1, 0.7] + [0.0] * (c.C - 3) if use_bg else None
@@ -54,13 +62,14 @@ def run_case(seed, dev, small_path_too=False):
         g = R.backward_views(st, *args, t(c.dL_color), t(c.dL_inv) if use_inv else None, bg=bgt, want_dfeatures=use_feat)
         if not clamp:   # (the oracle's backward has no clamp; the clamped path is held to torch autograd in tests/)
             for v in range(nv):
-                b = util.oracle_backward(c, v, outs[v], antialiasing=aa, bg=bg, with_inv=use_inv)
+                b = orc_mod.backward(outs[v], *o_args, c.ocams[v], c.dL_color[v], c.dL_inv[v] if use_inv else None, bg=bg,
+                                     scale_modifier=smod, antialiasing=aa)
                 for ours, theirs in GR:
-                    if g.get(ours) is None:
+                    if g.get(ours) is None or (precomp and ours in ("scales", "rotations")):
                         continue
                     util.assert_close(f"{theirs} view {v}", g[ours][v].cpu().numpy(), b[theirs].reshape(g[ours][v].shape))
         if c.P <= 256:   # the small path (fill + sparse composite, wave-resident / gather backward) on the same case
-            col, inv, radii, st, fT, nC = R.forward_views(views, *args, antialiasing=aa, want_aux=True, clamp01=clamp)
+            col, inv, radii, st, fT, nC = R.forward_views(views, *args, scale_modifier=smod, antialiasing=aa, want_aux=True, clamp01=clamp)
             for v in range(nv):
                 o = outs[v]
                 assert np.array_equal(col[v].cpu().numpy(), np.clip(o["color"], 0.0, 1.0) if clamp else o["color"]), "small: color"
@@ -69,7 +78,7 @@ def run_case(seed, dev, small_path_too=False):
                 assert np.array_equal(fT[v].cpu().numpy(), o["final_T"]), "small: final_T"
             g2 = R.backward_views(st, *args, t(c.dL_color), t(c.dL_inv) if use_inv else None, bg=bgt, want_dfeatures=use_feat)
             for ours, theirs in GR:   # the two paths against each other (clamped or not), then against the oracle
-                if g.get(ours) is not None:
+                if g.get(ours) is not None and g2.get(ours) is not None:
                     util.assert_close(f"small vs binned {theirs}", g2[ours].cpu().numpy(), g[ours].cpu().numpy())
     except AssertionError as e:
         raise AssertionError(f"{tag} -> {str(e)[:300]}") from None
