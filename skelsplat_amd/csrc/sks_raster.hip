@@ -212,6 +212,10 @@ void launch_bwd_small(const BwdArgs& a, const ViewTan& vt, const ViewOff& vo, in
 
 }  // namespace
 
+#ifndef SKS_GEOM_BINNED_THREADS
+#define SKS_GEOM_BINNED_THREADS 256
+#endif
+
 extern "C" {
 
 const char* sks_last_error(void) { return g_err; }
@@ -271,7 +275,8 @@ int sks_forward(int V, int P, int C, int W, int H, const float* viewmatrix, cons
         if (!(flags & SKS_BIN_CLEAN)) HIP_TRY(hipMemsetAsync(b.hdr, 0, 256 + (size_t)V * NT * 4, st));
     }
     if (!small) g.cover = nullptr;   // (the binned path's cover rows come from k_bin_scan)
-    hipLaunchKernelGGL(k_geom_fwd, dim3((P + 255) / 256, V), dim3(256), 0, st, P, W, H, vt, viewmatrix, projmatrix,
+    const int gthreads = small ? 256 : SKS_GEOM_BINNED_THREADS;
+    hipLaunchKernelGGL(k_geom_fwd, dim3((P + gthreads - 1) / gthreads, V), dim3(gthreads), 0, st, P, W, H, vt, viewmatrix, projmatrix,
                        means3D, opacities, scales, rotations, cov3D_precomp, scale_modifier, flags, g, radii, 0,
                        small ? (uint32_t*)nullptr : b.count, small ? (uint32_t*)nullptr : b.touched, features, C,
                        small ? (uint2*)nullptr : b.fmask, small ? (uint32_t*)nullptr : b.hdr);
