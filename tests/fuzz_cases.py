@@ -15,7 +15,8 @@ GR = (("means3D", "dL_dmeans3D"), ("means2D", "dL_dmeans2D"), ("opacities", "dL_
 
 
 def run_case(seed, dev, small_path_too=False):
-    """Raises AssertionError (its text names the case) when anything differs."""
+    """Raises AssertionError (its text names the case) when anything differs.  (check_capacity=True: the raw entry point's default
+    sizes the binning arena once per shape and checks later calls lazily -- two random scenes of one shape would trip it.)"""
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev) if a is not None else None
     rng = np.random.default_rng(seed)
     W, H = int(rng.integers(40, 260)), int(rng.integers(40, 200))
@@ -40,7 +41,7 @@ def run_case(seed, dev, small_path_too=False):
     tag = (f"seed {seed}: {W}x{H} V={nv} P={c.P} aa={aa} clamp={clamp} bg={use_bg} inv={use_inv} feat={use_feat} "
            f"scale_modifier={smod} cov3D_precomp={precomp} {kw}")
     try:
-        col, inv, radii, st, fT, nC = R.forward_views(views, *args, scale_modifier=smod, antialiasing=aa, want_aux=True, force_binned=True)
+        col, inv, radii, st, fT, nC = R.forward_views(views, *args, scale_modifier=smod, antialiasing=aa, want_aux=True, force_binned=True, check_capacity=True)
         pl, rg, nr = R.export_lists(st)
         outs = []
         for v in range(nv):
@@ -54,7 +55,7 @@ def run_case(seed, dev, small_path_too=False):
             assert int(nr[v]) == o["R"] and np.array_equal(rg[v].cpu().numpy(), o["ranges"]), "ranges"
             assert np.array_equal(pl[v, :o["R"]].cpu().numpy(), o["point_list"]), "point_list"
         if clamp:
-            col2, _, _, st = R.forward_views(views, *args, scale_modifier=smod, antialiasing=aa, clamp01=True, force_binned=True)
+            col2, _, _, st = R.forward_views(views, *args, scale_modifier=smod, antialiasing=aa, clamp01=True, force_binned=True, check_capacity=True)
             for v in range(nv):
                 assert np.array_equal(col2[v].cpu().numpy(), np.clip(outs[v]["color"], 0.0, 1.0)), "clamped color"
         bg = [0.3, 0.1, 0.7] + [0.0] * (c.C - 3) if use_bg else None
