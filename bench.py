@@ -595,7 +595,7 @@ def extra_stress(args, torch, dev, sync):
     ws = R.Workspace()
 
     def step():
-        color, inv, radii, st = R.forward_views(views, *params, None, bin_capacity=400000, workspace=ws)
+        color, inv, radii, st = R.forward_views(views, *params, None, bin_capacity=400000, workspace=ws, check_capacity="auto")
         return R.backward_views(st, *params, None, dL, workspace=ws)["means3D"]
     n = max(10, args.steps // 10)
     _lib.prof_enable(True, every=1)
@@ -613,7 +613,7 @@ def extra_stress(args, torch, dev, sync):
     # byte models and PMC traffic (profiles/traffic.json: separate rocprofv3 --pmc passes over tools/bench_stress.py, the same
     # scene).  Forward: every plane is written once.  Backward: dL/d(colour, inverse depth) is read where a tile's list is not
     # empty -- at most (C+1) planes of the covered tiles; channels no entry of the list has a feature for are skipped.
-    st = R.forward_views(views, *params, None, bin_capacity=400000)[3]
+    st = R.forward_views(views, *params, None, bin_capacity=400000, check_capacity="auto")[3]
     pl, rg, nr = R.export_lists(st)
     covered = int((rg[..., 1] > rg[..., 0]).sum())
     out["covered_tiles"] = covered

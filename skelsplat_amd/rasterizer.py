@@ -181,16 +181,15 @@ class ForwardState:
 
 def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotations, cov3D_precomp,
                   scale_modifier=1.0, antialiasing=False, clamp01=False, debug=False, force_binned=False,
-                  bin_capacity=None, want_aux=False, tune_flags=0, check_capacity="auto", workspace=None):
+                  bin_capacity=None, want_aux=False, tune_flags=0, check_capacity=True, workspace=None):
     """Raw batched forward.  Returns (color (V,C,H,W), invdepth (V,1,H,W), radii (V,P) int32, state[, final_T, n_contrib]).
     `workspace`: a Workspace whose tensors receive the outputs (see there).  `check_capacity` (binned path, P > 256):
-    True = read the pair count back every call (one host sync, like the reference: rasterizer_impl.cu:283-288) and redo the
-    forward with a larger arena when it was too small -- never a wrong image; this is what the autograd / drop-in path
-    uses; "lazy" = never synchronise, detect an overflowed arena at a LATER call of the shape, as soon as the GPU has been through
-    the overflowed one (that call raises: the image
-    before it missed entries; the arena has been grown for the calls after it); "auto" (the default of this raw entry
-    point, for loops that own their error handling) = True for the first call of a shape, which also sizes the arena with
-    50 % headroom over that call's count, lazy afterwards; False = no check."""
+    True (the default) = read the pair count back every call (one host sync, like the reference: rasterizer_impl.cu:283-288) and
+    redo the forward with a larger arena when it was too small -- never a wrong image; "lazy" = never synchronise, detect an
+    overflowed arena at a LATER call of the shape, as soon as the GPU has been through the overflowed one (that call raises: the
+    image before it missed entries; the arena has been grown for the calls after it); "auto" (what loops that own their error
+    handling ask for: bench.py's stress step) = True for the first call of a shape, which also sizes the arena with 50 % headroom
+    over that call's count, lazy afterwards; False = no check."""
     lib = _lib.load()
     key = None
     if workspace is not None and not want_aux:

@@ -714,7 +714,7 @@ def test_lazy_probe_never_waits_for_the_gpu(device):
     views = R.ViewBatch.from_cameras([cam.to(device) for cam in c.cams])
     args = (t(c.means, device), t(c.feat, device), t(c.opac, device), t(c.scales, device), t(c.quats, device), None)
     key = (device.index, 2, c.P, c.C, c.W, c.H)
-    col0, _, _, st0 = R.forward_views(views, *args, force_binned=True)            # "auto": sizes the arena synchronously, once
+    col0, _, _, st0 = R.forward_views(views, *args, force_binned=True, check_capacity="auto")   # sizes the arena synchronously, once
     assert key in R._BIN_CAP_SEEN
     torch.cuda.synchronize()
     # hold the GPU back behind a long-running fill so that the calls below are queued, not executed, while the host goes on
@@ -723,7 +723,7 @@ def test_lazy_probe_never_waits_for_the_gpu(device):
         big.zero_()
     sts = []
     for _ in range(3 * R._PROBES_IN_FLIGHT):
-        col, _, _, st = R.forward_views(views, *args, force_binned=True)
+        col, _, _, st = R.forward_views(views, *args, force_binned=True, check_capacity="auto")
         sts.append(st)
     unprobed = [s_ for s_ in sts if s_.num_rendered_dev is None]
     pending = len(R._BIN_PROBE[key].pending)
@@ -737,7 +737,7 @@ def test_lazy_probe_never_waits_for_the_gpu(device):
             continue                                             # (earlier calls' lists were overwritten by the later ones)
         pl, rg, nr = R.export_lists(s_)
         assert [int(x) for x in nr.cpu()] == [o[0]["R"], o[1]["R"]]
-    R.forward_views(views, *args, force_binned=True)             # harvests every probe: all clean
+    R.forward_views(views, *args, force_binned=True, check_capacity="auto")   # harvests every probe: all clean
     assert len(R._BIN_PROBE[key].pending) == 1
 
 
@@ -1003,14 +1003,14 @@ def test_workspace_replay_recovers_from_a_lazy_overflow(device):
     R._BIN_CAP_HINT[key] = 16          # as if an earlier, smaller scene of this shape had sized the arena
     R._BIN_CAP_SEEN.add(key)           # "auto" is lazy from now on
     ws = R.Workspace()
-    R.forward_views(views, *args, force_binned=True, workspace=ws)           # records the plan; nobody has looked yet
+    R.forward_views(views, *args, force_binned=True, workspace=ws, check_capacity="auto")   # records the plan; nobody has looked yet
     assert "fwd" in ws._plans
     torch.cuda.synchronize()           # (the probe never waits: it reads the counts of calls the GPU has been through)
     with pytest.raises(RuntimeError, match="missed entries"):
-        R.forward_views(views, *args, force_binned=True, workspace=ws)       # replay + probe of call 1
+        R.forward_views(views, *args, force_binned=True, workspace=ws, check_capacity="auto")   # replay + probe of call 1
     assert "fwd" not in ws._plans and R._BIN_CAP_HINT[key] >= o["R"]
     for _ in range(3):                                                       # validating path with the grown arena, then replays
-        col, _, _, st = R.forward_views(views, *args, force_binned=True, workspace=ws)
+        col, _, _, st = R.forward_views(views, *args, force_binned=True, workspace=ws, check_capacity="auto")
         assert st.bin_capacity >= o["R"] and np.array_equal(col[0].cpu().numpy(), o["color"])
 
 

@@ -20,7 +20,7 @@ dL = torch.randn((V, C, H, W), device=dev)
 color, inv, radii, st = R.forward_views(views, *args, bin_capacity=400000, check_capacity=True)
 print("P", P, "num_rendered per view", st.num_rendered_dev[:V].cpu().tolist(), "visible", int((radii > 0).sum()) / V)
 ws = R.Workspace()     # what a loop does: the same buffers every step (no allocation, no clearing launch: SKS_BIN_CLEAN)
-fwd = lambda: R.forward_views(views, *args, bin_capacity=400000, workspace=ws)
+fwd = lambda: R.forward_views(views, *args, bin_capacity=400000, workspace=ws, check_capacity="auto")
 st = fwd()[3]
 for name, fn in (("forward", fwd),
                  ("backward", lambda: R.backward_views(st, *args, dL, workspace=ws)),
@@ -40,7 +40,7 @@ if "--floor" not in sys.argv:
     sys.exit(0)
 far = (torch.tensor([[0.0, 0.0, 1e9]], device=dev).repeat(P, 1),) + args[1:]
 c2, i2, r2, st2 = R.forward_views(views, *far, force_binned=True, bin_capacity=400000)
-for name, fn in (("forward, all tiles empty", lambda: R.forward_views(views, *far, force_binned=True, bin_capacity=400000)),
+for name, fn in (("forward, all tiles empty", lambda: R.forward_views(views, *far, force_binned=True, bin_capacity=400000, check_capacity="auto")),
                  ("backward, all tiles empty", lambda: R.backward_views(st2, *far, dL))):
     for _ in range(3): fn()
     torch.cuda.synchronize(); t0 = time.perf_counter()
