@@ -157,14 +157,29 @@ def run_loop_case(seed, dev):
     tag = f"loop seed {seed}: {dataset} {W}x{H} V={nv} acc={acc} iterations={iters} scaling={scaling:.2f} aa={aa} opacity={op_on} lambda={lam}"
     try:
         sc = SyntheticScene(dataset, n_views=nv, seed=seed, W=W, H=H, ring=2500.0, fx=1145.0 * (W / 1000) * fxm, device=dev)
+        cams = sc.cameras
+        mixed = nv > 1 and seed % 3 == 0     # two sensor widths in one accumulation group (H36M's 1000 / 1002, quirk Q11)
+        if mixed:
+            from skelsplat_amd.scene import Camera
+            cams = []
+            for v, cam in enumerate(sc.cameras):
+                Wv = W + (2 if v % 2 else 0)
+                K = cam.K.copy()
+                K[0, 2] += (Wv - W) / 2
+                cams.append(Camera(cam.uid, cam.R, cam.T, K, Wv, H, device=dev))
+            tag += " mixed widths"
         outs = []
         for sparse in (True, False):
             gm = GaussianModel().create_from_points(sc.pose_3d_init, sc.spatial_lr_scale, sc.n_joints, scaling=scaling,
                                                     opacity_on=op_on, scene_type=dataset, device=dev)
             gm.training_setup()
-            hm = generate_heatmaps(gm._xyz.detach(), gm.get_scaling.detach(), gm._rotation.detach(),
-                                   torch.tensor(sc.poses_2d, device=dev), sc.cameras)
-            loop = MultiViewLoop(gm, sc.cameras, hm, dataset=dataset, accumulation_steps=acc, lambda_consistency=lam,
+            p2d = torch.tensor(sc.poses_2d, device=dev)
+            if mixed:
+                hm = [generate_heatmaps(gm._xyz.detach(), gm.get_scaling.detach(), gm._rotation.detach(), p2d[v:v + 1], [cams[v]])[0]
+                      for v in range(nv)]
+            else:
+                hm = generate_heatmaps(gm._xyz.detach(), gm.get_scaling.detach(), gm._rotation.detach(), p2d, cams)
+            loop = MultiViewLoop(gm, cams, hm, dataset=dataset, accumulation_steps=acc, lambda_consistency=lam,
                                  antialiasing=aa, sparse=sparse, use_graph=sparse)
             assert loop.sparse == sparse
             loop.run(iters)
