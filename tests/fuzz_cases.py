@@ -32,6 +32,18 @@ def run_case(seed, dev, small_path_too=False):
     smod = float(rng.choice([1.0, 1.0, 1.25, 0.7]))             # raster_settings.scale_modifier
     precomp = bool(rng.integers(0, 4) == 0)                      # pipe.compute_cov3D_python: six numbers per Gaussian, no scales / rotations
     c = util.make_case(**kw)
+    extreme = seed % 5 == 0
+    if extreme:    # Gaussians behind a camera / far off screen, pin-point and image-sized, transparent and opaque, flat as a sheet
+        P = c.P
+        pick = lambda frac: rng.random(P) < frac
+        c.means = c.means.copy(); c.scales = c.scales.copy(); c.opac = c.opac.copy()
+        m = pick(0.08); c.means[m] += rng.normal(0.0, 4000.0, (int(m.sum()), 3)).astype(np.float32)      # anywhere, also behind the cameras
+        m = pick(0.06); c.scales[m] *= 1e-3                                                                 # sub-pixel
+        m = pick(0.04); c.scales[m] *= 30.0                                                                 # covers the image
+        m = pick(0.05); c.scales[m, rng.integers(0, 3, int(m.sum()))] *= 1e-4                               # flat
+        m = pick(0.05); c.opac[m] = 0.0
+        m = pick(0.05); c.opac[m] = 1.0
+        m = pick(0.03); c.opac[m] = 1.0 / 255.0
     views = R.ViewBatch.from_cameras([cam.to(dev) for cam in c.cams])
     cov = None
     if precomp:
@@ -39,7 +51,7 @@ def run_case(seed, dev, small_path_too=False):
     o_args = (c.means, c.feat, c.opac, None, None, cov) if precomp else (c.means, c.feat, c.opac, c.scales, c.quats, None)
     args = tuple(t(x) for x in o_args)
     tag = (f"seed {seed}: {W}x{H} V={nv} P={c.P} aa={aa} clamp={clamp} bg={use_bg} inv={use_inv} feat={use_feat} "
-           f"scale_modifier={smod} cov3D_precomp={precomp} {kw}")
+           f"scale_modifier={smod} cov3D_precomp={precomp} extreme={extreme} {kw}")
     try:
         col, inv, radii, st, fT, nC = R.forward_views(views, *args, scale_modifier=smod, antialiasing=aa, want_aux=True, force_binned=True, check_capacity=True)
         pl, rg, nr = R.export_lists(st)
@@ -68,7 +80,12 @@ def run_case(seed, dev, small_path_too=False):
                 for ours, theirs in GR:
                     if g.get(ours) is None or (precomp and ours in ("scales", "rotations")):
                         continue
-                    util.assert_close(f"{theirs} view {v}", g[ours][v].cpu().numpy(), b[theirs].reshape(g[ours][v].shape))
+                    # (`extreme`: an image-sized needle's gradients are sums of thousands of pixel terms that cancel to 1e-5 of
+                    # their size -- in fp32 the order of summation alone moves them by percents, in the oracle's pixel-serial
+                    # sum as much as in the kernels' per-tile sums, contracted or not (NOTES_experiments.md): held to 5 %, which
+                    # still catches a missing tile; the forward stays bit for bit)
+                    util.assert_close(f"{theirs} view {v}", g[ours][v].cpu().numpy(), b[theirs].reshape(g[ours][v].shape),
+                                      rtol=5e-2 if extreme else 1e-3, atol_scale=5e-2 if extreme else 1e-5)
         if c.P <= 256:   # the small path (fill + sparse composite, wave-resident / gather backward) on the same case
             col, inv, radii, st, fT, nC = R.forward_views(views, *args, scale_modifier=smod, antialiasing=aa, want_aux=True, clamp01=clamp)
             for v in range(nv):
@@ -80,7 +97,8 @@ def run_case(seed, dev, small_path_too=False):
             g2 = R.backward_views(st, *args, t(c.dL_color), t(c.dL_inv) if use_inv else None, bg=bgt, want_dfeatures=use_feat)
             for ours, theirs in GR:   # the two paths against each other (clamped or not), then against the oracle
                 if g.get(ours) is not None and g2.get(ours) is not None:
-                    util.assert_close(f"small vs binned {theirs}", g2[ours].cpu().numpy(), g[ours].cpu().numpy())
+                    util.assert_close(f"small vs binned {theirs}", g2[ours].cpu().numpy(), g[ours].cpu().numpy(),
+                                      rtol=5e-2 if extreme else 1e-3, atol_scale=5e-2 if extreme else 1e-5)
     except AssertionError as e:
         raise AssertionError(f"{tag} -> {str(e)[:300]}") from None
 
