@@ -230,7 +230,7 @@ int sks_scratch_bytes(int V, int P, int C, int W, int H, size_t bin_capacity, si
     if (int rc = check_common(V, P, C, W, H)) return rc;
     const int NT = ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
     if (geom) *geom = geom_bytes(V, P > 0 ? P : 1, W, H);
-    if (binning) *binning = bin_bytes(V, P, NT, bin_capacity);
+    if (binning) *binning = bin_bytes(V, P, NT, bin_capacity, C + 1, (size_t)((H + TILE - 1) / TILE) * cover_cw(W));
     if (accum) *accum = (size_t)V * (P > 0 ? P : 1) * BWD_SPLITS * (NACC + C) * sizeof(float);
     return 0;
 }
@@ -283,7 +283,7 @@ int sks_forward(int V, int P, int C, int W, int H, const float* viewmatrix, cons
     STAGE_CHECK("geometry");
 
     FwdArgs a{ P, C, W, H, flags, g, features, out_color, out_invdepth, final_T, n_contrib, composite_slots(flags, V, P),
-               ((1u << 20) + (unsigned)C) / (unsigned)(C + 1), 0,
+               ((1u << 20) + (unsigned)C) / (unsigned)(C + 1), 0, small ? 0 : 1,
                (W >= 2 && W < 16384) ? (unsigned)(((1ull << 32) + (unsigned)W - 1) / (unsigned)W) : 0u };
     const int cg = pick_cg(C);
     if (small) {
@@ -299,16 +299,16 @@ int sks_forward(int V, int P, int C, int W, int H, const float* viewmatrix, cons
         STAGE_CHECK("render(small)");
         return 0;
     }
-    uint32_t* cover = geom_cover_ptr(geom, V, P);
+    uint32_t* cover = b.coverp;   // a row per (view, plane, band)
     const int cw = cover_cw(W);
     {
         const int bpc = gx >= SCAN_T * 8 ? 1 : (SCAN_T * 8) / gx;   // whole tile bands per scan block (<= SCAN_T * SCAN_IPT tiles)
         const int nchunk_t = (gy + bpc - 1) / bpc, nchunk_g = (P + SCAN_G - 1) / SCAN_G;
         hipLaunchKernelGGL(k_bin_scan, dim3(nchunk_t + nchunk_g, V), dim3(SCAN_T), (size_t)bpc * cw * 4, st, P, gx, gy, cw, bpc,
-                           nchunk_t, bin_capacity, b, cover, num_rendered_dev, V);
+                           nchunk_t, bin_capacity, b, cover, num_rendered_dev, V, C + 1);
     }
     hipLaunchKernelGGL(k_bin_scatter, dim3((P * BIN_SUB + 255) / 256, V), dim3(256), 0, st, P, NT, gx, bin_capacity, g, b);
-    hipLaunchKernelGGL(k_bin_sort_long, dim3(SORT_LONG_BLOCKS), dim3(256), 0, st, V, P, NT, gx, bin_capacity, g, b);
+    hipLaunchKernelGGL(k_bin_sort_long, dim3(SORT_LONG_BLOCKS), dim3(256), 0, st, V, P, NT, gx, bin_capacity, g, b, C, gy, cw);
     STAGE_CHECK("binning");
     BinView bv = bin_view(b, NT, bin_capacity);
     {

