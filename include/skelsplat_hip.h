@@ -68,9 +68,10 @@ int sks_version(void);
 /* Scratch sizes in bytes for one call (replaces the resizeFunctional callbacks, DGR/rasterize_points.cu:27-33).
  * geom: per-view per-Gaussian records kept for backward ("geomBuffer");
  * binning: the binned path's state ("binningBuffer" + "imgBuffer" of the reference), only used when P > SKS_SMALL_P or with
- *          SKS_FORCE_BINNED; bin_capacity = max (Gaussian, tile) pairs per view it must hold.  Since sks_version 7 it holds, per
+ *          SKS_FORCE_BINNED; bin_capacity = max (Gaussian, tile) pairs per view it must hold.  Since sks_version 8 it holds, per
  *          view: 48 B of entry records + 64 B of backward rows per pair of capacity (128 B in version 6), per 16x16 tile 2 KB of
- *          {final T, last contributor} for the backward + counters, range and descriptors (~150 B), per Gaussian 8 B -- e.g.
+ *          {final T, last contributor} for the backward + counters, range, descriptors, channel mask (~160 B) and a few KB of
+ *          per-plane cover rows, per Gaussian 8 B -- e.g.
  *          0.65 GB for 8 views at 2048x2048 with a capacity of 400 000 pairs.  Sizes and layout are private to a library version:
  *          always ask the library that will be called;
  * accum:  backward partial-sum slots (plain scratch: no initialisation needed, contents undefined afterwards). */
