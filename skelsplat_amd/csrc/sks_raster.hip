@@ -229,7 +229,7 @@ int sks_scratch_bytes(int V, int P, int C, int W, int H, size_t bin_capacity, si
 {
     if (int rc = check_common(V, P, C, W, H)) return rc;
     const int NT = ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
-    if (geom) *geom = geom_bytes(V, P > 0 ? P : 1, W, H);
+    if (geom) *geom = geom_bytes(V, P > 0 ? P : 1, W, H, C);
     if (binning) *binning = bin_bytes(V, P, NT, bin_capacity, C + 1, (size_t)((H + TILE - 1) / TILE) * cover_cw(W));
     if (accum) *accum = (size_t)V * (P > 0 ? P : 1) * BWD_SPLITS * (NACC + C) * sizeof(float);
     return 0;
@@ -279,11 +279,11 @@ int sks_forward(int V, int P, int C, int W, int H, const float* viewmatrix, cons
     hipLaunchKernelGGL(k_geom_fwd, dim3((P + gthreads - 1) / gthreads, V), dim3(gthreads), 0, st, P, W, H, vt, viewmatrix, projmatrix,
                        means3D, opacities, scales, rotations, cov3D_precomp, scale_modifier, flags, g, radii, 0,
                        small ? (uint32_t*)nullptr : b.count, small ? (uint32_t*)nullptr : b.touched, features, C,
-                       small ? (uint2*)nullptr : b.fmask, small ? (uint32_t*)nullptr : b.hdr);
+                       small ? (uint2*)nullptr : b.fmask, small ? (uint32_t*)nullptr : b.hdr, (small && cover_per_plane(P, W, H, C)) ? 1 : 0);
     STAGE_CHECK("geometry");
 
     FwdArgs a{ P, C, W, H, flags, g, features, out_color, out_invdepth, final_T, n_contrib, composite_slots(flags, V, P),
-               ((1u << 20) + (unsigned)C) / (unsigned)(C + 1), 0, small ? 0 : 1,
+               ((1u << 20) + (unsigned)C) / (unsigned)(C + 1), 0, (!small || (g.cover && cover_per_plane(P, W, H, C))) ? 1 : 0,
                (W >= 2 && W < 16384) ? (unsigned)(((1ull << 32) + (unsigned)W - 1) / (unsigned)W) : 0u };
     const int cg = pick_cg(C);
     if (small) {
@@ -474,7 +474,7 @@ int sks_geometry(int V, int P, int C, int W, int H, const float* viewmatrix, con
     if (!fill_views(vt, nullptr, V, C, W, H, tanfovx, tanfovy, view_wh, nullptr))
         return fail(-1, "view_wh: every view's size must be within [1, W] x [1, H] (pass the largest as W, H)");
     Geom g = geom_from(geom, V, P, W, H);
-    if (view_wh) g.cover = nullptr;   // the cover rows serve the dense forward, which needs one image size
+    g.cover = nullptr;   // (the cover rows serve the dense forward: sks_forward makes its own)
     hipLaunchKernelGGL(k_geom_fwd, dim3((P + 255) / 256, V), dim3(256), 0, st, P, W, H, vt, viewmatrix, projmatrix,
                        means3D, opacities, scales, rotations, cov3D_precomp, scale_modifier, flags, g, radii,
                        frames > 1 ? V / frames : 0);
