@@ -275,7 +275,7 @@ int sks_forward(int V, int P, int C, int W, int H, const float* viewmatrix, cons
         if (!(flags & SKS_BIN_CLEAN)) HIP_TRY(hipMemsetAsync(b.hdr, 0, 256 + (size_t)V * NT * 4, st));
     }
     if (!small) g.cover = nullptr;   // (the binned path's cover rows are per plane: Bin::coverp, k_bin_scan + k_bin_sort_long)
-    const int gthreads = small ? 256 : SKS_GEOM_BINNED_THREADS;
+    const int gthreads = small ? ((g.cover && cover_per_plane(P, W, H, C)) ? SKS_GEOM_COVER_THREADS : 256) : SKS_GEOM_BINNED_THREADS;
     hipLaunchKernelGGL(k_geom_fwd, dim3((P + gthreads - 1) / gthreads, V), dim3(gthreads), 0, st, P, W, H, vt, viewmatrix, projmatrix,
                        means3D, opacities, scales, rotations, cov3D_precomp, scale_modifier, flags, g, radii, 0,
                        small ? (uint32_t*)nullptr : b.count, small ? (uint32_t*)nullptr : b.touched, features, C,
