@@ -44,6 +44,8 @@ def run_case(seed, dev, small_path_too=False):
         m = pick(0.05); c.opac[m] = 0.0
         m = pick(0.05); c.opac[m] = 1.0
         m = pick(0.03); c.opac[m] = 1.0 / 255.0
+        c.feat = c.feat.copy()
+        m = pick(0.06); c.feat[m] = 0.0                                                                      # no colour at all: only inverse depth
     views = R.ViewBatch.from_cameras([cam.to(dev) for cam in c.cams])
     cov = None
     if precomp:
