@@ -15,9 +15,14 @@ seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 bad, t0, seen = 0, time.time(), []
 mode = sys.argv[3] if len(sys.argv) > 3 else "raster"
 which = {"raster": run_case, "loss": run_fused_loss_case, "loop": run_loop_case, "frames": run_frames_case, "dropin": run_dropin_case, "ops": run_ops_case}[mode]
+trace = bool(os.environ.get("FUZZ_TRACE"))   # print every seed first and synchronise after it: finds the case behind a GPU fault
 for k in range(n_cases):
     try:
+        if trace:
+            print("seed", seed0 + k, flush=True)
         seen.append(which(seed0 + k, dev))
+        if trace:
+            torch.cuda.synchronize()
     except AssertionError as e:
         bad += 1
         print("FAIL", str(e)[:500], flush=True)
