@@ -290,7 +290,7 @@ def run_single(args, torch, dev, wl):
         # sample is made up by untimed steps behind it, every launch bracketed (the kernel's duration does not depend on it)
         have = _lib.prof_count(0)
         if have < ROOF_MIN_LAUNCHES:
-            _lib.prof_enable(True, every=1, kinds=(0,), keep=True)
+            _lib.prof_enable(True, every=1, kinds=(0,))
             for _ in range(ROOF_MIN_LAUNCHES - have):
                 step()
             sync()

@@ -27,11 +27,33 @@ from diff_gaussian_rasterization_op import GaussianRasterizer as GaussianRasteri
 FAST_ACTIVATIONS = os.environ.get("SKS_RENDER_FAST", "1") != "0"
 
 
+_STOCK = {}     # model class -> are its three getters the reference's?
+
+
+def _stock_getters(cls):
+    """True when cls.get_opacity / get_scaling / get_rotation are properties that do what the reference's do and nothing else --
+    `return self.<x>_activation(self._<x>)` (scene/gaussian_model.py:102-108,128-130): judged from the getter's code object (the
+    two names it touches, no constants, no closure), so a subclass that filters its scales or masks its opacity in the getter, but
+    keeps the stock activation attributes, takes the literal path and its getters (and their autograd) run."""
+    hit = _STOCK.get(cls)
+    if hit is None:
+        def stock(name, act, leaf):
+            p = getattr(cls, name, None)
+            f = getattr(p, "fget", None) if isinstance(p, property) else None
+            co = getattr(f, "__code__", None)
+            return (co is not None and co.co_argcount == 1 and co.co_names == (act, leaf) and not co.co_freevars
+                    and not f.__closure__ and all(k is None or isinstance(k, str) for k in co.co_consts))
+        hit = _STOCK[cls] = (stock("get_opacity", "opacity_activation", "_opacity") and stock("get_scaling", "scaling_activation", "_scaling")
+                             and stock("get_rotation", "rotation_activation", "_rotation"))
+    return hit
+
+
 def _leaves_of(pc):
-    """(_opacity, _scaling, _rotation) if pc's three activations are exactly the reference's, else None."""
+    """(_opacity, _scaling, _rotation) if pc's three activations AND the getters through them are exactly the reference's, else
+    None (the literal call: activated tensors, autograd through the model's own getters)."""
     try:
         if (pc.opacity_activation is torch.sigmoid and pc.scaling_activation is torch.exp
-                and pc.rotation_activation is torch.nn.functional.normalize):
+                and pc.rotation_activation is torch.nn.functional.normalize and _stock_getters(type(pc))):
             return pc._opacity, pc._scaling, pc._rotation
     except AttributeError:
         pass

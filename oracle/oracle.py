@@ -125,7 +125,10 @@ def forward(means3D, features, opacities, scales, rotations, cov3D_precomp, cam,
 
 
 def backward(fwd, means3D, features, opacities, scales, rotations, cov3D_precomp, cam, dL_dcolor, dL_dinvdepth=None,
-             bg=None, scale_modifier=1.0, antialiasing=False):
+             bg=None, scale_modifier=1.0, antialiasing=False, bounds=False):
+    """bounds=True: the result also carries "bound" = {gradient name: float64 array of its shape}, the rounding scale of every
+    gradient element (sum of |terms| over all pixels and all paths of the geometry backward, orc_render_bwd's abs_sums through
+    orc_preprocess_bwd_bound): two fp32 evaluations may differ by a few dozen x 2**-24 x bound whatever the gradient's size."""
     means3D, features = _f32(means3D), _f32(features)
     P, Cn = features.shape
     W, H = cam.W, cam.H
@@ -141,10 +144,11 @@ def backward(fwd, means3D, features, opacities, scales, rotations, cov3D_precomp
     dcol = np.zeros((P, Cn), np.float32)
     dinv = np.zeros(P, np.float32) if dL_dinvdepth is not None else None
     plist = fwd["point_list"] if fwd["R"] else np.zeros(1, np.uint32)
+    absr = np.zeros(P * (3 + 4 + 1 + Cn + 1), np.float64) if bounds else None
     lib().orc_render_bwd(C.c_int(P), C.c_int(W), C.c_int(H), C.c_int(Cn), _p(fwd["ranges"]), _p(plist), _p(bgC),
                          _p(fwd["xy"]), _p(fwd["conic_opacity"]), _p(features), _p(fwd["depths"]),
                          _p(fwd["final_T"]), _p(fwd["n_contrib"]), _p(dL_dcolor), _p(dL_dinvdepth),
-                         _p(dm2), _p(dcon), _p(dop), _p(dcol), _p(dinv))
+                         _p(dm2), _p(dcon), _p(dop), _p(dcol), _p(dinv), _p(absr))
     dmeans = np.zeros((P, 3), np.float32)
     dcov = np.zeros((P, 6), np.float32)
     scales, rotations = _f32(scales), _f32(rotations)
@@ -156,8 +160,26 @@ def backward(fwd, means3D, features, opacities, scales, rotations, cov3D_precomp
         _p(fwd["cov3D"]), _p(cam.view), _p(cam.proj), C.c_int(W), C.c_int(H), C.c_float(cam.tanfovx),
         C.c_float(cam.tanfovy), _p(_f32(opacities).reshape(-1)), C.c_int(int(antialiasing)), _p(dm2), _p(dcon),
         _p(dinv), _p(dop_geo), _p(dmeans), _p(dcov), _p(dsc), _p(drot))
-    return dict(dL_dmeans2D=dm2, dL_dconic=dcon, dL_dopacity=dop_geo, dL_dcolors=dcol, dL_dinvdepths=dinv,
-                dL_dmeans3D=dmeans, dL_dcov3D=dcov, dL_dscales=dsc, dL_drotations=drot)
+    out = dict(dL_dmeans2D=dm2, dL_dconic=dcon, dL_dopacity=dop_geo, dL_dcolors=dcol, dL_dinvdepths=dinv,
+               dL_dmeans3D=dmeans, dL_dcov3D=dcov, dL_dscales=dsc, dL_drotations=drot)
+    if bounds:
+        A_m2 = absr[:3 * P].reshape(P, 3)
+        A_con = absr[3 * P:7 * P].reshape(P, 4)
+        A_op = absr[7 * P:8 * P]
+        A_col = absr[8 * P:8 * P + P * Cn].reshape(P, Cn)
+        A_inv = absr[8 * P + P * Cn:] if dL_dinvdepth is not None else None
+        B_op, B_means, B_cov = np.zeros(P), np.zeros((P, 3)), np.zeros((P, 6))
+        B_sc = np.zeros((P, 3)) if scales is not None else None
+        B_rot = np.zeros((P, 4)) if scales is not None else None
+        lib().orc_preprocess_bwd_bound(
+            C.c_int(P), _p(means3D), _p(fwd["radii"]), _p(scales), _p(rotations), C.c_float(scale_modifier),
+            _p(fwd["cov3D"]), _p(cam.view), _p(cam.proj), C.c_int(W), C.c_int(H), C.c_float(cam.tanfovx),
+            C.c_float(cam.tanfovy), _p(_f32(opacities).reshape(-1)), C.c_int(int(antialiasing)), _p(np.ascontiguousarray(A_m2)),
+            _p(np.ascontiguousarray(A_con)), _p(None if A_inv is None else np.ascontiguousarray(A_inv)),
+            _p(np.ascontiguousarray(A_op)), _p(B_op), _p(B_means), _p(B_cov), _p(B_sc), _p(B_rot))
+        out["bound"] = dict(dL_dmeans2D=A_m2.copy(), dL_dopacity=B_op.reshape(P, 1), dL_dcolors=A_col.copy(), dL_dmeans3D=B_means,
+                            dL_dcov3D=B_cov, dL_dscales=B_sc, dL_drotations=B_rot)
+    return out
 
 
 def mark_visible(means3D, cam):

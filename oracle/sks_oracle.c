@@ -357,13 +357,25 @@ void orc_render_bwd(int P, int W, int H, int C, const uint32_t* ranges, const ui
                     const float* depths, const float* final_Ts, const uint32_t* n_contrib,
                     const float* dL_dpixels, const float* dL_invdepths,
                     float* dL_dmean2D /*P*3*/, float* dL_dconic2D /*P*4*/, float* dL_dopacity /*P*/,
-                    float* dL_dcolors /*P*C*/, float* dL_dinvdepths /*P or NULL*/)
+                    float* dL_dcolors /*P*C*/, float* dL_dinvdepths /*P or NULL*/,
+                    double* abs_sums /* NULL, or P*(3+4+1+C+1) doubles [mean2D 3P | conic 4P | opacity P | colors P*C |
+                    invdepth P]: beside every sum, the sum of the ABSOLUTE values of what goes into it, every difference
+                    inside a pixel's term taken as a sum too (c - accum_rec -> |c| + |accum_rec| ...): the scale on which
+                    two fp32 evaluations of the same sum may differ by rounding and order alone (tests/fuzz_cases.py) */)
 {
     const int gx = (W + BLOCK_X - 1) / BLOCK_X;
     const size_t nacc = (size_t)P * (size_t)(3 + 4 + 1 + C + 1);
     double* acc = (double*)calloc(nacc, sizeof(double));
     double* a_m2d = acc, *a_con = a_m2d + 3 * (size_t)P, *a_op = a_con + 4 * (size_t)P,
            *a_col = a_op + P, *a_inv = a_col + (size_t)P * C;
+    double* b_m2d = NULL, *b_con = NULL, *b_op = NULL, *b_col = NULL, *b_inv = NULL;
+    float* abs_rec = NULL;    /* the blend of |colour| behind the entry in hand (accum_rec's counterpart) */
+    if (abs_sums) {
+        memset(abs_sums, 0, nacc * sizeof(double));
+        b_m2d = abs_sums; b_con = b_m2d + 3 * (size_t)P; b_op = b_con + 4 * (size_t)P; b_col = b_op + P;
+        b_inv = b_col + (size_t)P * C;
+        abs_rec = (float*)malloc(sizeof(float) * (C + 1));
+    }
     float* accum_rec = (float*)malloc(sizeof(float) * C);
     float* last_color = (float*)malloc(sizeof(float) * C);
     float* dL_dpixel = (float*)malloc(sizeof(float) * C);
@@ -387,6 +399,8 @@ void orc_render_bwd(int P, int W, int H, int C, const uint32_t* ranges, const ui
                 dL_dpixel[i] = dL_dpixels[(size_t)i * H * W + pix_id];
             }
             if (dL_invdepths) dL_invdepth = dL_invdepths[pix_id];
+            if (abs_sums) for (int i = 0; i <= C; i++) abs_rec[i] = 0;
+            float abs_last_invdepth = 0;
 
             for (uint32_t e = r1; e-- > r0;) {
                 contributor--;
@@ -403,6 +417,26 @@ void orc_render_bwd(int P, int W, int H, int C, const uint32_t* ranges, const ui
                 T = T / (1.f - alpha);
                 const float dchannel_dcolor = alpha * T;
                 float dL_dalpha = 0.0f;
+                double abs_dalpha = 0.0;
+                if (abs_sums) {   /* (before last_color / last_alpha move on to this entry) */
+                    for (int ch = 0; ch < C; ch++) {
+                        abs_rec[ch] = last_alpha * fabsf(last_color[ch]) + (1.f - last_alpha) * abs_rec[ch];
+                        const double ad = fabs((double)dL_dpixel[ch]);
+                        abs_dalpha += ((double)fabsf(colors[gid * C + ch]) + abs_rec[ch]) * ad;
+                        b_col[(size_t)gid * C + ch] += (double)dchannel_dcolor * ad;
+                    }
+                    if (dL_dinvdepths) {
+                        const float invd = 1.f / depths[gid];
+                        abs_rec[C] = last_alpha * abs_last_invdepth + (1.f - last_alpha) * abs_rec[C];
+                        abs_last_invdepth = fabsf(invd);
+                        abs_dalpha += ((double)fabsf(invd) + abs_rec[C]) * fabs((double)dL_invdepth);
+                        b_inv[gid] += (double)dchannel_dcolor * fabs((double)dL_invdepth);
+                    }
+                    abs_dalpha *= T;
+                    double abs_bg = 0;
+                    for (int i = 0; i < C; i++) abs_bg += fabs((double)bg[i] * dL_dpixel[i]);
+                    abs_dalpha += fabs((double)T_final / (1.0 - alpha)) * abs_bg;
+                }
                 for (int ch = 0; ch < C; ch++) {
                     const float c = colors[gid * C + ch];
                     accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
@@ -434,6 +468,16 @@ void orc_render_bwd(int P, int W, int H, int C, const uint32_t* ranges, const ui
                 a_con[4 * gid + 1] += (double)(-0.5f * gdx * dy * dL_dG);
                 a_con[4 * gid + 3] += (double)(-0.5f * gdy * dy * dL_dG);
                 a_op[gid] += (double)(G * dL_dalpha);
+                if (abs_sums) {
+                    const double adG = fabs((double)co[3]) * abs_dalpha;
+                    const double agx = fabs((double)gdx), agy = fabs((double)gdy);
+                    b_m2d[3 * gid + 0] += adG * (agx * fabs((double)co[0]) + agy * fabs((double)co[1])) * ddelx_dx;
+                    b_m2d[3 * gid + 1] += adG * (agy * fabs((double)co[2]) + agx * fabs((double)co[1])) * ddely_dy;
+                    b_con[4 * gid + 0] += 0.5 * agx * fabs((double)dx) * adG;
+                    b_con[4 * gid + 1] += 0.5 * agx * fabs((double)dy) * adG;
+                    b_con[4 * gid + 3] += 0.5 * agy * fabs((double)dy) * adG;
+                    b_op[gid] += (double)G * abs_dalpha;
+                }
             }
         }
     for (size_t i = 0; i < 3 * (size_t)P; i++) dL_dmean2D[i] = (float)a_m2d[i];
@@ -441,7 +485,7 @@ void orc_render_bwd(int P, int W, int H, int C, const uint32_t* ranges, const ui
     for (int i = 0; i < P; i++) dL_dopacity[i] = (float)a_op[i];
     for (size_t i = 0; i < (size_t)P * C; i++) dL_dcolors[i] = (float)a_col[i];
     if (dL_dinvdepths) for (int i = 0; i < P; i++) dL_dinvdepths[i] = (float)a_inv[i];
-    free(acc); free(accum_rec); free(last_color); free(dL_dpixel);
+    free(acc); free(accum_rec); free(last_color); free(dL_dpixel); free(abs_rec);
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -592,6 +636,144 @@ void orc_preprocess_bwd(int P, const float* means3D, const int* radii, const flo
             dq[2] = 2 * x * (dMt.m[1][0] + dMt.m[0][1]) + 2 * r * (dMt.m[2][0] - dMt.m[0][2]) + 2 * z * (dMt.m[1][2] + dMt.m[2][1]) - 4 * y * (dMt.m[2][2] + dMt.m[0][0]);
             dq[3] = 2 * r * (dMt.m[0][1] - dMt.m[1][0]) + 2 * x * (dMt.m[2][0] + dMt.m[0][2]) + 2 * y * (dMt.m[1][2] + dMt.m[2][1]) - 4 * z * (dMt.m[1][1] + dMt.m[0][0]);
             for (int k = 0; k < 4; k++) dL_drots[4 * idx + k] = dq[k];
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Rounding scale of orc_preprocess_bwd's outputs (tests/fuzz_cases.py): the same chain of     */
+/* formulas evaluated on the ABSOLUTE values -- inputs A_* = orc_render_bwd's abs_sums, every  */
+/* coefficient |.|, every difference a sum, divisors at their forward values -- so that        */
+/* B_out >= sum over all paths of |path product| >= |J| A_in.  Two fp32 evaluations of the     */
+/* backward that differ in summation order, contraction or reciprocal may differ by about      */
+/* (a few dozen) x 2^-24 x B_out, however small the gradient itself comes out by cancellation. */
+/* Not a restatement of reference code: test arithmetic.                                       */
+/* ------------------------------------------------------------------------------------------ */
+static inline double dsq(double x) { return x * x; }
+
+void orc_preprocess_bwd_bound(int P, const float* means3D, const int* radii, const float* scales,
+                              const float* rotations, float scale_modifier, const float* cov3Ds,
+                              const float* viewmatrix, const float* projmatrix, int W, int H,
+                              float tan_fovx, float tan_fovy, const float* opacities, int antialiasing,
+                              const double* A_mean2D /*P*3*/, const double* A_conics /*P*4*/,
+                              const double* A_invdepth /*P or NULL*/, const double* A_opacity /*P*/,
+                              double* B_opacity /*P*/, double* B_means /*P*3*/, double* B_cov /*P*6*/,
+                              double* B_scales /*P*3 or NULL*/, double* B_rots /*P*4 or NULL*/)
+{
+    const float h_y = H / (2.0f * tan_fovy);
+    const float h_x = W / (2.0f * tan_fovx);
+    for (int idx = 0; idx < P; idx++) {
+        B_opacity[idx] = 0;
+        for (int i = 0; i < 3; i++) B_means[3 * idx + i] = 0;
+        for (int i = 0; i < 6; i++) B_cov[6 * idx + i] = 0;
+        if (B_scales) for (int i = 0; i < 3; i++) B_scales[3 * idx + i] = 0;
+        if (B_rots) for (int i = 0; i < 4; i++) B_rots[4 * idx + i] = 0;
+        if (!(radii[idx] > 0)) continue;
+        const float* cov3D = cov3Ds + 6 * idx;
+        const float* mean = means3D + 3 * idx;
+        const double Ac[3] = { A_conics[4 * idx], A_conics[4 * idx + 1], A_conics[4 * idx + 3] };
+        Cov2DCtx c;
+        cov2d_ctx(mean, h_x, h_y, tan_fovx, tan_fovy, cov3D, viewmatrix, &c);
+        const float* t = c.t;
+        const double x_grad_mul = (c.txtz < -c.limx || c.txtz > c.limx) ? 0 : 1;
+        const double y_grad_mul = (c.tytz < -c.limy || c.tytz > c.limy) ? 0 : 1;
+        double Ta[3][3], Wa[3][3], Va[3][3];
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+            Ta[i][j] = fabs((double)c.T.m[i][j]); Wa[i][j] = fabs((double)c.W.m[i][j]); Va[i][j] = fabs((double)c.Vrk.m[i][j]);
+        }
+        double c_xx = c.cov.m[0][0], c_xy = c.cov.m[0][1], c_yy = c.cov.m[1][1];
+        const double h_var = 0.3;
+        double d_inside_root = 0;
+        double Bop = A_opacity[idx];
+        if (antialiasing) {
+            const double det_cov = c_xx * c_yy - c_xy * c_xy;
+            c_xx += h_var; c_yy += h_var;
+            const double det2 = c_xx * c_yy - c_xy * c_xy;
+            const double hcs = sqrt(fmax(0.000025, det_cov / det2));
+            d_inside_root = (det_cov / det2) <= 0.000025 ? 0.0 : A_opacity[idx] * fabs((double)opacities[idx]) / (2 * hcs);
+            Bop = A_opacity[idx] * hcs;
+        } else { c_xx += h_var; c_yy += h_var; }
+        B_opacity[idx] = Bop;
+        const double axx = fabs(c_xx), ayy = fabs(c_yy), axy = fabs(c_xy);
+        double Bxx = 0, Bxy = 0, Byy = 0;
+        if (antialiasing) {
+            const double x = c_xx, y = c_yy, z = c_xy, w = h_var;
+            const double denom_f = d_inside_root / dsq(w * w + w * (x + y) + x * y - z * z);
+            Bxx = w * (w * ayy + ayy * ayy + z * z) * denom_f;
+            Byy = w * (w * axx + axx * axx + z * z) * denom_f;
+            Bxy = 2. * w * axy * (w + axx + ayy) * denom_f;
+        }
+        const double denom = c_xx * c_yy - c_xy * c_xy;
+        const double denom2inv = 1.0 / ((denom * denom) + 0.0000001);
+        const double admx = fabs(denom) + axx * ayy;          /* |denom - c_xx c_yy| as a sum */
+        double* dcov = B_cov + 6 * idx;
+        if ((float)(1.0f / (((float)denom * (float)denom) + 0.0000001f)) != 0) {
+            Bxx += denom2inv * (ayy * ayy * Ac[0] + 2 * axy * ayy * Ac[1] + admx * Ac[2]);
+            Byy += denom2inv * (axx * axx * Ac[2] + 2 * axx * axy * Ac[1] + admx * Ac[0]);
+            Bxy += denom2inv * 2 * (axy * ayy * Ac[0] + (fabs(denom) + 2 * axy * axy) * Ac[1] + axx * axy * Ac[2]);
+            dcov[0] = Ta[0][0] * Ta[0][0] * Bxx + Ta[0][0] * Ta[1][0] * Bxy + Ta[1][0] * Ta[1][0] * Byy;
+            dcov[3] = Ta[0][1] * Ta[0][1] * Bxx + Ta[0][1] * Ta[1][1] * Bxy + Ta[1][1] * Ta[1][1] * Byy;
+            dcov[5] = Ta[0][2] * Ta[0][2] * Bxx + Ta[0][2] * Ta[1][2] * Bxy + Ta[1][2] * Ta[1][2] * Byy;
+            dcov[1] = 2 * Ta[0][0] * Ta[0][1] * Bxx + (Ta[0][0] * Ta[1][1] + Ta[0][1] * Ta[1][0]) * Bxy + 2 * Ta[1][0] * Ta[1][1] * Byy;
+            dcov[2] = 2 * Ta[0][0] * Ta[0][2] * Bxx + (Ta[0][0] * Ta[1][2] + Ta[0][2] * Ta[1][0]) * Bxy + 2 * Ta[1][0] * Ta[1][2] * Byy;
+            dcov[4] = 2 * Ta[0][2] * Ta[0][1] * Bxx + (Ta[0][1] * Ta[1][2] + Ta[0][2] * Ta[1][1]) * Bxy + 2 * Ta[1][1] * Ta[1][2] * Byy;
+        }
+        double TV[2][3];   /* sum_k |T[i][k]| |Vrk[j][k]| */
+        for (int i = 0; i < 2; i++) for (int j = 0; j < 3; j++)
+            TV[i][j] = Ta[i][0] * Va[j][0] + Ta[i][1] * Va[j][1] + Ta[i][2] * Va[j][2];
+        const double BT0[3] = { 2 * TV[0][0] * Bxx + TV[1][0] * Bxy, 2 * TV[0][1] * Bxx + TV[1][1] * Bxy, 2 * TV[0][2] * Bxx + TV[1][2] * Bxy };
+        const double BT1[3] = { 2 * TV[1][0] * Byy + TV[0][0] * Bxy, 2 * TV[1][1] * Byy + TV[0][1] * Bxy, 2 * TV[1][2] * Byy + TV[0][2] * Bxy };
+        const double BJ00 = Wa[0][0] * BT0[0] + Wa[0][1] * BT0[1] + Wa[0][2] * BT0[2];
+        const double BJ02 = Wa[2][0] * BT0[0] + Wa[2][1] * BT0[1] + Wa[2][2] * BT0[2];
+        const double BJ11 = Wa[1][0] * BT1[0] + Wa[1][1] * BT1[1] + Wa[1][2] * BT1[2];
+        const double BJ12 = Wa[2][0] * BT1[0] + Wa[2][1] * BT1[1] + Wa[2][2] * BT1[2];
+        const double tz = fabs(1.0 / t[2]), tz2 = tz * tz, tz3 = tz2 * tz;
+        const double Btx = x_grad_mul * h_x * tz2 * BJ02;
+        const double Bty = y_grad_mul * h_y * tz2 * BJ12;
+        double Btz = h_x * tz2 * BJ00 + h_y * tz2 * BJ11 + fabs(2. * h_x * t[0]) * tz3 * BJ02 + fabs(2. * h_y * t[1]) * tz3 * BJ12;
+        if (A_invdepth) Btz += A_invdepth[idx] / ((double)t[2] * t[2]);
+        const float* V = viewmatrix;
+        double Bm[3] = {
+            fabs((double)V[0]) * Btx + fabs((double)V[1]) * Bty + fabs((double)V[2]) * Btz,
+            fabs((double)V[4]) * Btx + fabs((double)V[5]) * Bty + fabs((double)V[6]) * Btz,
+            fabs((double)V[8]) * Btx + fabs((double)V[9]) * Bty + fabs((double)V[10]) * Btz };
+        const float* proj = projmatrix;
+        const float* m = mean;
+        float m_hom[4];
+        transformPoint4x4(m, proj, m_hom);
+        const double m_w = fabs(1.0 / ((double)m_hom[3] + 0.0000001));
+        const double mul1 = (fabs((double)proj[0] * m[0]) + fabs((double)proj[4] * m[1]) + fabs((double)proj[8] * m[2]) + fabs((double)proj[12])) * m_w * m_w;
+        const double mul2 = (fabs((double)proj[1] * m[0]) + fabs((double)proj[5] * m[1]) + fabs((double)proj[9] * m[2]) + fabs((double)proj[13])) * m_w * m_w;
+        const double g2x = A_mean2D[3 * idx], g2y = A_mean2D[3 * idx + 1];
+        for (int k = 0; k < 3; k++)
+            B_means[3 * idx + k] = Bm[k] + (fabs((double)proj[4 * k]) * m_w + fabs((double)proj[4 * k + 3]) * mul1) * g2x +
+                                   (fabs((double)proj[4 * k + 1]) * m_w + fabs((double)proj[4 * k + 3]) * mul2) * g2y;
+        if (scales && B_scales && B_rots) {
+            const float* q = rotations + 4 * idx;
+            const double r = fabs((double)q[0]), x = fabs((double)q[1]), y = fabs((double)q[2]), z = fabs((double)q[3]);
+            double R[3][3];     /* |entries| of the rotation as sums (glm layout m[c][r] as in orc_preprocess_bwd) */
+            R[0][0] = 1. + 2. * (y * y + z * z); R[0][1] = 2. * (x * y + r * z); R[0][2] = 2. * (x * z + r * y);
+            R[1][0] = 2. * (x * y + r * z); R[1][1] = 1. + 2. * (x * x + z * z); R[1][2] = 2. * (y * z + r * x);
+            R[2][0] = 2. * (x * z + r * y); R[2][1] = 2. * (y * z + r * x); R[2][2] = 1. + 2. * (x * x + y * y);
+            const double s[3] = { fabs((double)scale_modifier * scales[3 * idx]), fabs((double)scale_modifier * scales[3 * idx + 1]),
+                                  fabs((double)scale_modifier * scales[3 * idx + 2]) };
+            double M[3][3], dS[3][3], dM[3][3];
+            /* M = S * R in mat3_mul's convention: o.m[c][r] = sum_k a.m[k][r] b.m[c][k], S diagonal */
+            for (int cc = 0; cc < 3; cc++) for (int rr = 0; rr < 3; rr++) M[cc][rr] = 2.0 * s[rr] * R[cc][rr];
+            dS[0][0] = dcov[0]; dS[0][1] = 0.5 * dcov[1]; dS[0][2] = 0.5 * dcov[2];
+            dS[1][0] = 0.5 * dcov[1]; dS[1][1] = dcov[3]; dS[1][2] = 0.5 * dcov[4];
+            dS[2][0] = 0.5 * dcov[2]; dS[2][1] = 0.5 * dcov[4]; dS[2][2] = dcov[5];
+            for (int cc = 0; cc < 3; cc++) for (int rr = 0; rr < 3; rr++)
+                dM[cc][rr] = M[0][rr] * dS[cc][0] + M[1][rr] * dS[cc][1] + M[2][rr] * dS[cc][2];
+            double dMt[3][3], Rt[3][3];
+            for (int cc = 0; cc < 3; cc++) for (int rr = 0; rr < 3; rr++) { dMt[cc][rr] = dM[rr][cc]; Rt[cc][rr] = R[rr][cc]; }
+            for (int k = 0; k < 3; k++)
+                B_scales[3 * idx + k] = Rt[k][0] * dMt[k][0] + Rt[k][1] * dMt[k][1] + Rt[k][2] * dMt[k][2];
+            for (int k = 0; k < 3; k++) for (int rr = 0; rr < 3; rr++) dMt[k][rr] *= s[k];
+            B_rots[4 * idx + 0] = 2 * z * (dMt[0][1] + dMt[1][0]) + 2 * y * (dMt[2][0] + dMt[0][2]) + 2 * x * (dMt[1][2] + dMt[2][1]);
+            B_rots[4 * idx + 1] = 2 * y * (dMt[1][0] + dMt[0][1]) + 2 * z * (dMt[2][0] + dMt[0][2]) + 2 * r * (dMt[1][2] + dMt[2][1]) + 4 * x * (dMt[2][2] + dMt[1][1]);
+            B_rots[4 * idx + 2] = 2 * x * (dMt[1][0] + dMt[0][1]) + 2 * r * (dMt[2][0] + dMt[0][2]) + 2 * z * (dMt[1][2] + dMt[2][1]) + 4 * y * (dMt[2][2] + dMt[0][0]);
+            B_rots[4 * idx + 3] = 2 * r * (dMt[0][1] + dMt[1][0]) + 2 * x * (dMt[2][0] + dMt[0][2]) + 2 * y * (dMt[1][2] + dMt[2][1]) + 4 * z * (dMt[1][1] + dMt[0][0]);
         }
     }
 }

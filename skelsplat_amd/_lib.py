@@ -120,9 +120,9 @@ def prof_count(kind):
     return n.value
 
 
-def prof_enable(on, every=1, kinds=(0, 1), keep=False, recorded=False):
+def prof_enable(on, every=1, kinds=(0, 1), recorded=False):
     """Bracket the forward (kind 0) / backward (kind 1) compositor launches with hipEvents: every `every`-th launch of each
-    kind in `kinds`.  (`keep`: documentation only -- what was collected so far always stays until it is read.)"""
+    kind in `kinds`.  What was collected so far stays until it is read (a caller may change the stride mid-collection)."""
     skip = sum(1 << (16 + k) for k in (0, 1) if k not in kinds)
     check(load().sks_prof_enable((min(0xffff, max(1, int(every))) | skip | ((1 << 18) if recorded else 0)) if on else 0),
           "sks_prof_enable")

@@ -382,6 +382,7 @@ int sks_backward(int V, int P, int C, int W, int H, const float* viewmatrix, con
         ga.goff = b.goff;
         ga.part = b.part;
         ga.cap = bin_capacity;
+        ga.bin_hdr = b.hdr;
     }
     if (dL_dmeans3D_mean && V * P <= 256 && small) {   // (the binned path's k_geom_bwd also re-arms the work cursors)
         hipLaunchKernelGGL(k_geom_bwd_all, dim3(1), dim3(256), 0, st, ga, vt, V, dL_dmeans3D_mean);

@@ -68,6 +68,8 @@ class Workspace:
     def __init__(self):
         self._t = {}
         self._plans = {}     # "fwd" / "bwd" -> the last call's recorded C-ABI argument list (see _plan_key)
+        self._bin_clean = {}   # binning buffer (data_ptr) -> the layout (V, P, C, W, H, capacity) whose last sks_forward COMPLETED
+                               # on it and left its tile counters zero: only then may a replay carry SKS_BIN_CLEAN
 
     def get(self, name, shape, dtype, device):
         key = (name, tuple(shape), dtype, device)
@@ -209,10 +211,19 @@ def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotati
                     raise
                 args[23] = None if host is None else host.data_ptr()
                 result[3].num_rendered_dev = host
+            if args[21] is not None:
+                # the recorded flags carry SKS_BIN_CLEAN ("the buffer is as this layout's last completed forward left it"): true
+                # only while nothing else -- another layout of the same byte size, a call that failed half-way -- has been through
+                # the buffer since.  The token is taken off for the duration of the call: a failure leaves the buffer "dirty"
+                layout = (args[0], args[1], args[2], args[3], args[4], args[22])
+                clean = workspace._bin_clean.pop(args[21], None) == layout
+                args[16] = (args[16] | _lib.SKS_BIN_CLEAN) if clean else (args[16] & ~_lib.SKS_BIN_CLEAN)
             rc = _replay(lib.sks_forward, args, dev_index)
             if rc != 0:
-                del workspace._plans["fwd"]     # (the recorded call promises a binning buffer a completed call left behind)
+                del workspace._plans["fwd"]
             _lib.check(rc, "sks_forward")
+            if args[21] is not None:
+                workspace._bin_clean[args[21]] = layout
             if cap_check is None:
                 return result
             nr, pcap, ckey = cap_check
@@ -270,7 +281,7 @@ def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotati
     if lazy:
         # the pair counts go straight to pinned host memory (k_bin_scan stores them there: no copy launch, no event): they are
         # looked at when the NEXT call of the shape comes in -- first the previous call's, which may raise
-        nrend = _lazy_probe(cap_key, cap)     # (None while enough probes are in flight: this call then goes unprobed)
+        nrend = _lazy_probe(cap_key, cap)     # (None only inside a hipGraph capture)
     else:
         nrend = new("nrend", (V + 1,), torch.int32) if binned else None   # [0, V): written by k_bin_scan
     final_T = torch.empty((V, H, W), dtype=torch.float32, device=dev) if want_aux else None
@@ -280,7 +291,11 @@ def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotati
             _lib.ptr(rotations), _lib.ptr(cov3D_precomp), float(scale_modifier), flags,
             color.data_ptr(), invdepth.data_ptr(), _lib.ptr(radii), geom.data_ptr(),
             _lib.ptr(binning), cap, _lib.ptr(nrend), _lib.ptr(final_T), _lib.ptr(n_contrib), None]
+    if binned and workspace is not None:
+        workspace._bin_clean.pop(args[21], None)     # (this call clears the counters itself; dirty until it has completed)
     _lib.check(_replay(lib.sks_forward, args, dev.index), "sks_forward")
+    if binned and workspace is not None:
+        workspace._bin_clean[args[21]] = (V, P, C, W, H, cap)
     if binned and check_capacity:
         # The reference reads the pair count back on EVERY forward to size its buffers (rasterizer_impl.cu:283-288: a
         # blocking D2H copy between the scan and the duplication).  Here the arena is persistent and the count stays on
@@ -310,10 +325,10 @@ def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotati
         keep = (means3D, feat2, opacities, scales, rotations, cov3D_precomp)
         cap_check = None
         if binned:
-            # the replayed call finds the binning buffer as this call leaves it: its tile counters are zero again, so the
-            # clearing launch in front of the binning kernels is skipped (include/skelsplat_hip.h: SKS_BIN_CLEAN)
+            # a replayed call that finds the binning buffer as this layout's last completed call left it -- tile counters zero
+            # again -- skips the clearing launch in front of the binning kernels (SKS_BIN_CLEAN, decided per replay from
+            # workspace._bin_clean)
             args = list(args)
-            args[16] = flags | _lib.SKS_BIN_CLEAN
             if check_capacity is True:
                 cap_check = (nrend, cap, cap_key)
             elif check_capacity:
@@ -335,7 +350,7 @@ class _Probes:
         self.pending, self.free = [], []      # pending: [(pinned int32 tensor, its numpy view, capacity of that call)], oldest first
 
 
-_PROBES_IN_FLIGHT = 8
+_PROBES_IN_FLIGHT = 1024     # calls of one shape the host may be ahead of the GPU by (36 bytes of pinned memory each)
 
 
 def _lazy_probe(cap_key, cap):
@@ -344,8 +359,9 @@ def _lazy_probe(cap_key, cap):
     launch, no event).  Called in front of every lazy call of the shape: looks at the buffers of EARLIER calls that the GPU has
     been through by now (they complete in call order; -1 = not written yet), raises if one of them needed more pairs than its
     arena held -- that image missed entries; the arena has been grown for the calls to come --, and returns a buffer for this
-    call, or None when _PROBES_IN_FLIGHT calls are still waiting to be looked at (the host runs hundreds of microseconds ahead
-    of the GPU on this path: waiting for the previous call's counts, as an earlier version did, stalled every step)."""
+    call: EVERY eager call is probed (the host runs hundreds of microseconds ahead of the GPU on this path, so up to
+    _PROBES_IN_FLIGHT buffers wait to be looked at; waiting for the previous call's counts, as an earlier version did, stalled
+    every step).  None only inside a hipGraph capture.  The gradients of an overflowed call are NaN (k_geom_bwd_binned)."""
     V = cap_key[1]
     st = _BIN_PROBE.get(cap_key)
     if st is None:
@@ -361,8 +377,11 @@ def _lazy_probe(cap_key, cap):
             raise RuntimeError(f"skelsplat_amd: a previous binned forward of this shape needed {pneed} (Gaussian, tile) pairs "
                                f"per view but its arena held {pcap}: that image missed entries.  The arena has been grown; "
                                "call again (check_capacity=True checks every call synchronously).")
-    if torch.cuda.is_current_stream_capturing() or len(st.pending) >= _PROBES_IN_FLIGHT:
+    if torch.cuda.is_current_stream_capturing():
         return None
+    if len(st.pending) >= _PROBES_IN_FLIGHT:     # (never reached by a loop that synchronises now and then: every call is probed)
+        torch.cuda.synchronize()
+        return _lazy_probe(cap_key, cap)
     if st.free:
         host, view = st.free.pop()
     else:

@@ -632,3 +632,60 @@ def test_direct_rccl_exchange_is_off_without_rccl():
         assert DirectGather.create(torch.device("cpu")) is None      # gloo
     finally:
         dist.destroy_process_group()
+
+
+def test_fast_activations_only_for_the_reference_getters():
+    """gaussian_renderer hands the LEAF parameters to the kernels (activations in-kernel) only when the model's activations and
+    its get_opacity / get_scaling / get_rotation are the reference's (scene/gaussian_model.py:39-47,102-108,128-130): a model
+    that overrides a getter but keeps the stock activation attributes must take the literal path, or its getter never runs."""
+    import gaussian_renderer as G
+    from skelsplat_amd.scene import GaussianModel
+
+    class Clamped(GaussianModel):
+        @property
+        def get_scaling(self):
+            return self.scaling_activation(self._scaling).clamp(max=5.0)
+
+    class Halved(GaussianModel):
+        @property
+        def get_opacity(self):
+            return self.opacity_activation(self._opacity) * 0.5
+
+    class Documented(GaussianModel):
+        @property
+        def get_rotation(self):
+            "the reference's getter, with a docstring"
+            return self.rotation_activation(self._rotation)
+
+    pts = np.zeros((17, 3), np.float32)
+    for cls, fast in ((GaussianModel, True), (Clamped, False), (Halved, False), (Documented, True)):
+        gm = cls().create_from_points(pts, 1.0, 17, scene_type="h36m", device="cpu")
+        assert (G._leaves_of(gm) is not None) == fast, cls.__name__
+    gm = GaussianModel().create_from_points(pts, 1.0, 17, scene_type="h36m", device="cpu")
+    gm.scaling_activation = lambda x: torch.exp(x)          # another activation object: literal path
+    assert G._leaves_of(gm) is None
+
+
+def test_oracle_rounding_scale_dominates_the_gradients():
+    """oracle.backward(bounds=True): beside every gradient the sum of |terms| over every pixel and every path of the geometry
+    backward (what tests/fuzz_cases.py's `extreme` cases take their allowance from).  It must dominate the gradient itself
+    (|sum| <= sum of |terms|) and scale linearly with the upstream gradient."""
+    c = util.make_case(5, 96, 72, n_views=1, n_skeletons=2)
+    for aa, inv, bg in ((False, True, [0.3, 0.1, 0.7] + [0.0] * 14), (True, False, None)):
+        o = util.oracle_forward(c, 0, antialiasing=aa)
+        b = orc.backward(o, c.means, c.feat, c.opac, c.scales, c.quats, None, c.ocams[0], c.dL_color[0], c.dL_inv[0] if inv else None,
+                         bg=bg, antialiasing=aa, bounds=True)
+        b3 = orc.backward(o, c.means, c.feat, c.opac, c.scales, c.quats, None, c.ocams[0], 3.0 * c.dL_color[0],
+                          3.0 * c.dL_inv[0] if inv else None, bg=bg, antialiasing=aa, bounds=True)
+        for k, B in b["bound"].items():
+            g = np.abs(b[k].reshape(B.shape).astype(np.float64))
+            assert (g <= B * (1 + 1e-5) + 1e-30).all(), k
+            assert B.max() > 0 and np.allclose(b3["bound"][k], 3.0 * B, rtol=1e-5), k
+        # a gradient held to itself passes, one with a tile's worth of a sum missing does not
+        k = "dL_dmeans3D"
+        util.assert_close_bound(k, b[k], b[k], b["bound"][k])
+        worst = np.unravel_index(np.argmax(b["bound"][k]), b["bound"][k].shape)
+        bad = b[k].astype(np.float64).copy()
+        bad[worst] += 1e-2 * b["bound"][k][worst]
+        with pytest.raises(AssertionError):
+            util.assert_close_bound(k, bad, b[k], b["bound"][k])

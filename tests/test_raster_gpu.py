@@ -707,9 +707,9 @@ def test_binned_capacity_lazy_check_has_no_sync_and_still_catches_overflow(devic
 
 
 def test_lazy_probe_never_waits_for_the_gpu(device):
-    """The host runs ahead of the GPU on the replay path: the lazy check looks only at calls whose counts have arrived, leaves a
-    call unprobed when _PROBES_IN_FLIGHT earlier ones are still out, and the unprobed calls' images and exported lists are the
-    same as everybody else's (an earlier version waited for the previous call's counts: a device synchronisation per step)."""
+    """The host runs ahead of the GPU on the replay path: the lazy check looks only at calls whose counts have arrived and never
+    waits for the others -- and EVERY call carries a probe (an earlier version left calls unprobed once eight were out: an
+    overflow in one of those would have gone unnoticed)."""
     c = util.make_case(seed=1, W=200, H=136, scale_log=4.0, n_views=2)     # (a shape no other test uses: hints are per shape)
     views = R.ViewBatch.from_cameras([cam.to(device) for cam in c.cams])
     args = (t(c.means, device), t(c.feat, device), t(c.opac, device), t(c.scales, device), t(c.quats, device), None)
@@ -722,23 +722,77 @@ def test_lazy_probe_never_waits_for_the_gpu(device):
     for _ in range(8):
         big.zero_()
     sts = []
-    for _ in range(3 * R._PROBES_IN_FLIGHT):
+    for _ in range(24):
         col, _, _, st = R.forward_views(views, *args, force_binned=True, check_capacity="auto")
         sts.append(st)
-    unprobed = [s_ for s_ in sts if s_.num_rendered_dev is None]
+    assert all(s_.num_rendered_dev is not None for s_ in sts)     # every call probed
     pending = len(R._BIN_PROBE[key].pending)
     torch.cuda.synchronize()
-    assert pending <= R._PROBES_IN_FLIGHT
-    assert unprobed or pending < 3 * R._PROBES_IN_FLIGHT        # (either calls went unprobed or the GPU kept up: never a wait)
+    assert 1 <= pending <= 24
     assert torch.equal(col, col0)
     o = [util.oracle_forward(c, v) for v in range(2)]
-    for s_ in (sts[-1], unprobed[-1] if unprobed else sts[0]):
-        if s_ is not sts[-1]:
-            continue                                             # (earlier calls' lists were overwritten by the later ones)
-        pl, rg, nr = R.export_lists(s_)
-        assert [int(x) for x in nr.cpu()] == [o[0]["R"], o[1]["R"]]
+    pl, rg, nr = R.export_lists(sts[-1])
+    assert [int(x) for x in nr.cpu()] == [o[0]["R"], o[1]["R"]]
     R.forward_views(views, *args, force_binned=True, check_capacity="auto")   # harvests every probe: all clean
     assert len(R._BIN_PROBE[key].pending) == 1
+
+
+def test_gradients_of_an_overflowed_arena_are_nan_not_stale_rows(device):
+    """check_capacity=False on an arena that is too small: k_bin_scatter drops the entries beyond it, the compositing backward
+    never writes their partial-sum rows, and k_geom_bwd_binned would add whatever an earlier step left there.  The gradients of
+    such a call are NaN for every visible Gaussian -- never plausible numbers (the synchronous check, the default, redoes the
+    forward with a larger arena instead and never gets here)."""
+    c = util.make_case(seed=0, W=176, H=120, scale_log=4.0, n_views=2)
+    views = R.ViewBatch.from_cameras([cam.to(device) for cam in c.cams])
+    args = (t(c.means, device), t(c.feat, device), t(c.opac, device), t(c.scales, device), t(c.quats, device), None)
+    dL = t(c.dL_color, device)
+    need = max(util.oracle_forward(c, v)["R"] for v in range(2))
+    ws = R.Workspace()
+    # a good step first: its rows stay behind in the workspace's binning buffer
+    col, _, radii, st = R.forward_views(views, *args, force_binned=True, bin_capacity=need + 8, check_capacity=False, workspace=ws)
+    good = {k: v.clone() for k, v in R.backward_views(st, *args, dL, workspace=ws).items() if v is not None}
+    assert all(torch.isfinite(v).all() for v in good.values())
+    small = R.Workspace()
+    col, _, radii, st = R.forward_views(views, *args, force_binned=True, bin_capacity=need // 2, check_capacity=False, workspace=small)
+    g = R.backward_views(st, *args, dL, workspace=small)
+    vis = radii > 0
+    assert vis.any()
+    for k in ("means3D", "means2D", "opacities", "cov3D", "scales", "rotations"):
+        assert torch.isnan(g[k][vis]).all(), k
+    # ... and the arena that holds everything is unaffected by the flag
+    col, _, radii, st = R.forward_views(views, *args, force_binned=True, bin_capacity=need + 8, check_capacity=False, workspace=ws)
+    again = R.backward_views(st, *args, dL, workspace=ws)
+    for k, v in good.items():
+        assert torch.equal(again[k], v), k
+
+
+def test_bin_clean_is_only_promised_for_the_layout_that_left_the_buffer(device):
+    """A Workspace's replayed binned forward skips the counter-clearing launch (SKS_BIN_CLEAN) -- only while the buffer is as THIS
+    layout's last completed forward left it.  Two layouts that share one byte-sized buffer, and a replay after a failed call,
+    must clear (stale counters would corrupt the tile ranges silently)."""
+    c = util.make_case(seed=2, W=184, H=120, scale_log=4.0, n_views=1)
+    views = R.ViewBatch.from_cameras([cam.to(device) for cam in c.cams])
+    args = (t(c.means, device), t(c.feat, device), t(c.opac, device), t(c.scales, device), t(c.quats, device), None)
+    o = util.oracle_forward(c, 0)
+    ws = R.Workspace()
+    kw = dict(force_binned=True, bin_capacity=o["R"] + 64, check_capacity=False, workspace=ws)
+    R.forward_views(views, *args, **kw)
+    col, _, _, st = R.forward_views(views, *args, **kw)            # replay, clean
+    plan = ws._plans["fwd"]
+    bptr = plan[2][21]
+    assert ws._bin_clean[bptr] == (1, c.P, c.C, c.W, c.H, o["R"] + 64)
+    assert np.array_equal(col[0].cpu().numpy(), o["color"])
+    # somebody else writes into the buffer (what another layout of the same byte size would do): the token is gone, the
+    # next replay must not trust the counters
+    ws._t[next(k for k in ws._t if k[0] == ("fwd", "binning"))].fill_(0x5a)
+    ws._bin_clean.pop(bptr)
+    col, _, _, st = R.forward_views(views, *args, **kw)
+    assert np.array_equal(col[0].cpu().numpy(), o["color"])
+    pl, rg, nr = R.export_lists(st)
+    assert np.array_equal(rg[0].cpu().numpy(), o["ranges"]) and np.array_equal(pl[0, :o["R"]].cpu().numpy(), o["point_list"])
+    assert ws._bin_clean[bptr] == (1, c.P, c.C, c.W, c.H, o["R"] + 64)    # promised again from here on
+    col, _, _, st = R.forward_views(views, *args, **kw)
+    assert np.array_equal(col[0].cpu().numpy(), o["color"])
 
 
 def test_binned_long_tile_lists(device):
