@@ -113,18 +113,22 @@ class ApiStep:
       "all_gather": the per-view gradients land in the rank's rows of a shard, all_gather_into_tensor, then sks_mean_views sums
                     the V rows in VIEW order: bit-identical to one GPU (what MultiViewLoop does, which needs the rows)."""
 
-    def __init__(self, views, params, dL, V_total=None, exchange=None):
+    def __init__(self, views, params, dL, V_total=None, exchange=None, one_call=None):
         import torch
         from skelsplat_amd import rasterizer as R
         self.R, self.views, self.params, self.dL = R, views, params, dL
         self.exchange = exchange          # None, or (world, rank, group)
         self.mode = None
+        # one_call: forward + backward through sks_forward_backward -- dL is resident, so the backward (which reads the forward's
+        # geometry records, not its image) runs on a second stream beside the dense forward; False: sks_forward, then sks_backward
+        self.one_call = (os.environ.get("SKS_BENCH_TWO_CALLS") != "1") if one_call is None else bool(one_call)
         if exchange is not None:
             world, rank, _ = exchange
             dev, P = params[0].device, params[0].shape[0]
             vmax = (V_total + world - 1) // world
             self.shard = torch.zeros((vmax, P, 3), device=dev)      # pad rows stay zero
-            self.allg = torch.empty((world * vmax, P, 3), device=dev)
+            self.allg = torch.zeros((world * vmax, P, 3), device=dev)
+            self.allg_dst = self.allg     # (rank_step_8gpu: the rows a communicator of ONE rank fills, allg[:vmax])
             self.mean_out = torch.empty((P, 3), device=dev)
             self.local_mean = torch.zeros((P, 3), device=dev)      # (a rank without views contributes zeros with weight 0)
             self.V_total = V_total
@@ -157,28 +161,66 @@ class ApiStep:
             self.mode = "all_gather"
         return self.mode
 
+    def fwd_bwd(self, join=True, **kw):
+        """This process's views forward + backward; the gradients dict.  join=False (one call only): the gradients are ordered on
+        the workspace's second stream, not yet on the current one (see __call__)."""
+        R = self.R
+        if self.one_call:
+            return R.forward_backward_views(self.views, *self.params, None, self.dL, workspace=self.ws, join=join, **kw)[4]
+        color, inv, radii, st = R.forward_views(self.views, *self.params, None, workspace=self.ws)
+        return R.backward_views(st, *self.params, None, self.dL, workspace=self.ws, **kw)
+
+    wire_us = 0.0       # rank_step_8gpu only: a one-wavefront idle kernel of this length in front of the collective stands in for
+                        # the xGMI hop a communicator of ONE rank does not make (sks_prof_spin)
+    no_collective = False   # rank_step_8gpu only: the step without its exchange (forward + backward into the shard)
+
     def __call__(self):
+        import torch
         import torch.distributed as dist
         R = self.R
         if self.exchange is None:
-            color, inv, radii, st = R.forward_views(self.views, *self.params, None, workspace=self.ws)
-            g = R.backward_views(st, *self.params, None, self.dL, workspace=self.ws, want_mean=True)
-            return g["means3D_mean"]     # the mean over the views comes out of the backward's own last launch
-        if self.mode == "all_reduce":
-            local = self.local_mean
-            if self.views is not None:
-                color, inv, radii, st = R.forward_views(self.views, *self.params, None, workspace=self.ws)
-                local = R.backward_views(st, *self.params, None, self.dL, workspace=self.ws, want_mean=True)["means3D_mean"]
-            self.direct.all_reduce_weighted(self.mean_out, local, self.weight)
-            return self.mean_out
+            return self.fwd_bwd(want_mean=True)["means3D_mean"]     # the mean over the views comes out of the backward's own last launch
+        # Sharded.  One call: the joint gradients are ready ~40 us into the step, on the second stream, while the dense forward
+        # streams for another ~70 us on the first -- the step's ONE collective (and the mean behind it) is enqueued behind the
+        # backward on that second stream, so its latency hides under the forward as well; the first stream joins at the end.
+        hide = self.one_call and self.views is not None
+        dev = self.params[0].device
+        aux = self.ws.aux_stream(dev.index) if hide else None
+        reduce_mode = self.mode == "all_reduce"
         if self.views is not None:       # this rank's views; their joint gradients land in its rows of the shard
-            color, inv, radii, st = R.forward_views(self.views, *self.params, None, workspace=self.ws)
-            R.backward_views(st, *self.params, None, self.dL, workspace=self.ws, out_means3D=self.shard[:self.views.V])
-        if self.direct is not None:
-            self.direct.all_gather_into_tensor(self.allg, self.shard)
+            if reduce_mode:
+                local = self.fwd_bwd(join=not hide, want_mean=True)["means3D_mean"]
+            else:
+                self.fwd_bwd(join=not hide, out_means3D=self.shard[:self.views.V])
         else:
-            dist.all_gather_into_tensor(self.allg, self.shard, group=self.exchange[2])
-        return R.mean_views(self.allg, self.V_total, self.exchange[0], out=self.mean_out)   # reads the gathered rows in place
+            local = self.local_mean
+        if self.no_collective:
+            if hide:
+                self.ws.join(dev.index)
+            return self.shard
+        with torch.cuda.stream(aux) if hide else _nullcontext():
+            if self.wire_us:
+                from skelsplat_amd import _lib
+                _lib.check(_lib.load().sks_prof_spin(float(self.wire_us), torch.cuda.current_stream(dev).cuda_stream), "sks_prof_spin")
+            if reduce_mode:
+                self.direct.all_reduce_weighted(self.mean_out, local, self.weight)
+            else:
+                if self.direct is not None:
+                    self.direct.all_gather_into_tensor(self.allg_dst, self.shard)
+                else:
+                    dist.all_gather_into_tensor(self.allg_dst, self.shard, group=self.exchange[2])
+                R.mean_views(self.allg, self.V_total, self.exchange[0], out=self.mean_out)   # reads the gathered rows in place
+        if hide:
+            self.ws.join(dev.index)
+        return self.mean_out
+
+
+class _nullcontext:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
 
 
 def timed(fn, steps, warmup, sync):
@@ -220,6 +262,22 @@ def roofline_entry(alg_bytes, prof_fwd, wl_name, launches, kernel="k_render_fwd_
             "frac_median": alg_bytes / (fwd_q[1] * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "avg_launch_us": avg_s * 1e6, "launch_us_p10_p50_p90": [round(1e3 * x, 2) for x in fwd_q],
             "launches_timed": fwd_n, "launches": launches, "algorithmic_bytes_per_launch": alg_bytes}
+
+
+def zero_fill_us(torch, n_floats, dev, sync):
+    """The box's own ceiling for a forward's bytes, in the same run: median duration of tensor.zero_() of a buffer that size."""
+    try:
+        zbuf = torch.empty(int(n_floats), device=dev)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(12)]
+        for a_, b_ in evs:
+            a_.record()
+            zbuf.zero_()
+            b_.record()
+        sync()
+        zt = sorted(a_.elapsed_time(b_) for a_, b_ in evs[2:])
+        return 1e3 * zt[len(zt) // 2]
+    except Exception:
+        return None
 
 
 def make_scene(torch, wl, dev, seed=0):
@@ -269,49 +327,41 @@ def run_single(args, torch, dev, wl):
     W, H, P, C = scene.W, scene.H, scene.n_points, scene.n_joints
     views = R.ViewBatch.from_cameras(scene.cameras)
     dL = torch.randn((V, C, H, W), device=dev, generator=torch.Generator(device=dev).manual_seed(0))
-    step = ApiStep(views, params, dL)
+    step = ApiStep(views, params, dL)                      # forward + backward as ONE C-ABI call (sks_forward_backward)
+    step2 = ApiStep(views, params, dL, one_call=False)     # ... and as the two calls, for the roofline's kernel and for comparison
     prof = not args.no_prof
     for _ in range(args.warmup):
         step()
+    for _ in range(max(3, args.warmup // 4)):
+        step2()
     sync()
+    dt, out = timed(step, args.steps, 0, sync)             # THE timed region: K steps, nothing bracketed inside
+    # The dominant kernel's duration comes from the two-call form of the same step, timed right behind: in the one-call form the
+    # backward runs beside the forward on a second stream and an event pair around the forward would time the two together (its
+    # own duration there: ~51 us instead of ~46, profiles/r05_one_call_timeline.txt).  The compositor launches of every n-th step
+    # carry a hipEvent pair (hipExtLaunchKernelGGL: stamped from the kernel's own dispatch, on the launch stream); a bracketed
+    # step costs ~13 us of queue time, so the sample is 5 .. 25 launches of the K steps and the rest is made up behind them.
     if prof:
-        # the compositor launches of every n-th step of the timed region carry a hipEvent pair (hipExtLaunchKernelGGL: the
-        # pair is stamped from the kernel's own dispatch, on the launch stream).  A bracketed step costs ~13 us of queue
-        # time (measured: 68.4 us per step without, 69.7 bracketing every 8th, 74-80 every 2nd, 82-85 every step), so the
-        # sample is 5 .. 25 launches: every 8th step at the default 200 steps, every 4th at 20
-        # ... and only the forward compositor (the roofline's kernel) inside the timed region
         _lib.prof_enable(True, every=int(os.environ.get("SKS_PROF_EVERY", "0")) or prof_stride(args.steps), kinds=(0,))
         _lib.prof_read(0), _lib.prof_read(1)
-    dt, out = timed(step, args.steps, 0, sync)
+    dt2, out2 = timed(step2, args.steps, 0, sync)
+    assert torch.equal(out, out2)                          # (bit for bit the same gradients either way)
     pf = pb = None
     zero_us = None
     if prof:
-        # at least ROOF_MIN_LAUNCHES forward launches carry an event pair whatever --steps is: what the timed region did not
-        # sample is made up by untimed steps behind it, every launch bracketed (the kernel's duration does not depend on it)
+        # at least ROOF_MIN_LAUNCHES forward launches carry an event pair whatever --steps is: what the timed steps did not
+        # sample is made up by untimed steps behind them, every launch bracketed (the kernel's duration does not depend on it)
         have = _lib.prof_count(0)
         if have < ROOF_MIN_LAUNCHES:
             _lib.prof_enable(True, every=1, kinds=(0,))
             for _ in range(ROOF_MIN_LAUNCHES - have):
-                step()
+                step2()
             sync()
         pf = _lib.prof_read_quantiles(0)
-        # the box's own ceiling for these bytes, in the same run: tensor.zero_() of a buffer the size of the forward's planes
-        try:
-            zbuf = torch.empty((V * (C + 1), H, W), device=dev)
-            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(12)]
-            for a_, b_ in evs:
-                a_.record()
-                zbuf.zero_()
-                b_.record()
-            sync()
-            zt = sorted(a_.elapsed_time(b_) for a_, b_ in evs[2:])
-            zero_us = 1e3 * zt[len(zt) // 2]
-            del zbuf
-        except Exception:
-            zero_us = None
+        zero_us = zero_fill_us(torch, V * (C + 1) * H * W, dev, sync)
         _lib.prof_enable(True, every=1, kinds=(1,))     # the backward compositor: a few untimed steps behind the timed region
         for _ in range(10):
-            step()
+            step2()
         sync()
         pb = _lib.prof_read_quantiles(1)
         _lib.prof_enable(False)
@@ -321,11 +371,15 @@ def run_single(args, torch, dev, wl):
         "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": wl["name"], "views_per_step": V, "P": P, "C": C, "W": W, "H": H, "parallelism": "single GPU",
-                   "path": "C ABI sks_forward + sks_backward (incl. the mean over the views), eager launches, outputs in a "
-                           "reused workspace"},
+                   "path": "C ABI sks_forward_backward: forward + backward (incl. the mean over the views) of the resident dL as one "
+                           "call -- the backward reads the forward's geometry records, not its image, and runs on a second stream "
+                           "beside the dense forward; eager launches, outputs in a reused workspace"},
+        # the same step as the two separate calls (sks_forward, then sks_backward on the same stream), K steps timed the same way
+        "two_call_step": {"ms_per_step": 1e3 * dt2 / args.steps, "views_per_s": V * args.steps / dt2},
     }
     if pf and pf[1]:
         res["roofline"] = roofline_entry(4.0 * H * W * (C + 1) * V, pf, wl["name"], args.steps)
+        res["roofline"]["timed_in"] = "the two-call form of the step, same run (see two_call_step)"
         if zero_us:
             res["roofline"]["zero_fill_same_bytes_us"] = zero_us
             res["roofline"]["frac_of_zero_fill"] = zero_us / (1e3 * pf[2][1])     # (median launch against the median zero_())
@@ -553,21 +607,30 @@ def extra_panoptic(args, torch, dev, sync):
     V, W, H, C = wl["V"], scene.W, scene.H, scene.n_joints
     views = R.ViewBatch.from_cameras(scene.cameras)
     dL = torch.randn((V, C, H, W), device=dev)
-    step = ApiStep(views, params, dL)
+    step = ApiStep(views, params, dL)                # one call (the backward beside the forward)
+    step2 = ApiStep(views, params, dL, one_call=False)
     n = max(10, args.steps // 10)
     dt, _ = timed(step, n, 3, sync)                 # the step itself: no event brackets inside the timed region
+    dt2, _ = timed(step2, n, 3, sync)
     _lib.prof_enable(True, every=1)                 # (marker-packet events on this path: ~3 us of queue time per bracket)
     _lib.prof_read(0), _lib.prof_read(1)
-    timed(step, n, 0, sync)
+    timed(step2, n, 0, sync)                        # kernel durations from the two-call form (run_single explains)
     pf, pb = _lib.prof_read_quantiles(0), _lib.prof_read_quantiles(1)
     _lib.prof_enable(False)
-    out = {"workload": wl["name"], "ms_per_step": 1e3 * dt / n, "views_per_s": V * n / dt}
+    out = {"workload": wl["name"], "ms_per_step": 1e3 * dt / n, "views_per_s": V * n / dt,
+           "two_call_step": {"ms_per_step": 1e3 * dt2 / n, "views_per_s": V * n / dt2}}
     if pf[1]:
         alg = 4.0 * H * W * (C + 1) * V
         out["fwd_kernel_us"] = pf[0] * 1e3 / pf[1]
+        out["fwd_kernel_us_p10_p50_p90"] = [round(1e3 * x, 1) for x in pf[2]]
         out["fwd_frac_of_hbm_peak"] = alg / (pf[0] * 1e-3 / pf[1]) / 1e9 / HBM_PEAK_GBS
+        zus = zero_fill_us(torch, V * (C + 1) * H * W, dev, sync)
+        if zus:
+            out["zero_fill_same_bytes_us"] = zus
+            out["frac_of_zero_fill"] = zus / (1e3 * pf[2][1])
     if pb[1]:
         out["bwd_kernel_us"] = pb[0] * 1e3 / pb[1]
+    del step2
     del step, dL
     gm.training_setup()
     hm = generate_heatmaps(gm._xyz.detach(), gm.get_scaling.detach(), gm._rotation.detach(),
@@ -594,19 +657,42 @@ def extra_stress(args, torch, dev, sync):
     dL = torch.randn((V, C, H, W), device=dev)
     ws = R.Workspace()
 
-    def step():
+    wsd = R.Workspace()
+
+    def step():      # the arena checked lazily: counts in pinned host memory, looked at when the next call comes in
         color, inv, radii, st = R.forward_views(views, *params, None, bin_capacity=400000, workspace=ws, check_capacity="auto")
         return R.backward_views(st, *params, None, dL, workspace=ws)["means3D"]
+
+    def step_default():     # the library's default: the pair count of EVERY forward is checked before the call returns
+        color, inv, radii, st = R.forward_views(views, *params, None, bin_capacity=400000, workspace=wsd)
+        return R.backward_views(st, *params, None, dL, workspace=wsd)["means3D"]
     n = max(10, args.steps // 10)
+    for fn in (step, step_default):
+        for _ in range(3):
+            fn()
+    reps = {"auto": [], "default": []}
+    for _ in range(5):       # interleaved: the two modes see the same box state
+        for tag, fn in (("auto", step), ("default", step_default)):
+            dtr, _ = timed(fn, n, 0, sync)
+            reps[tag].append(1e3 * dtr / n)
+    med = {k: sorted(v)[len(v) // 2] for k, v in reps.items()}
     _lib.prof_enable(True, every=1)
     _lib.prof_read(0), _lib.prof_read(1)
-    dt, _ = timed(step, n, 3, sync)
+    timed(step, n, 0, sync)
     pf, pb = _lib.prof_read_quantiles(0), _lib.prof_read_quantiles(1)
     _lib.prof_enable(False)
-    out = {"workload": "stress_256skeletons_8view_2048x2048_P4352_C17", "ms_per_step": 1e3 * dt / n, "views_per_s": V * n / dt}
+    out = {"workload": "stress_256skeletons_8view_2048x2048_P4352_C17", "ms_per_step": med["default"], "views_per_s": V / med["default"] * 1e3,
+           "mode": "check_capacity=True (the library's default: every forward's pair count is checked before the call returns)",
+           "ms_per_step_check_capacity_auto": med["auto"], "default_over_auto": med["default"] / med["auto"],
+           "ms_per_step_reps": {k: [round(x, 4) for x in v] for k, v in reps.items()}}
     if pf[1]:
         out["fwd_kernel_us"] = pf[0] * 1e3 / pf[1]
+        out["fwd_kernel_us_p10_p50_p90"] = [round(1e3 * x, 1) for x in pf[2]]
         out["fwd_frac_of_hbm_peak"] = 4.0 * H * W * (C + 1) * V / (pf[0] * 1e-3 / pf[1]) / 1e9 / HBM_PEAK_GBS
+        zus = zero_fill_us(torch, V * (C + 1) * H * W, dev, sync)
+        if zus:
+            out["zero_fill_same_bytes_us"] = zus
+            out["frac_of_zero_fill"] = zus / (1e3 * pf[2][1])
     if pb[1]:
         out["bwd_kernel_us"] = pb[0] * 1e3 / pb[1]
         out["bwd_kernel_us_p10_p50_p90"] = [round(1e3 * x, 1) for x in pb[2]]
@@ -635,11 +721,13 @@ def extra_stress(args, torch, dev, sync):
 
 
 def extra_rank_step(args, torch, dev, sync):
-    """What ONE rank of the 8-GPU run (BASELINE configs[3]) does per step, measured on this one GPU: forward + backward of
-    its 4 of the 31 Panoptic views into its all_gather shard, the RCCL all_gather_into_tensor (a communicator of ONE rank:
-    the collective's launch and local copy are in, the xGMI hop is not), sks_mean_views over the gathered rank-major rows.
-    predicted_8gpu_speedup = this GPU's 31-view step / that: what `bench.py --gpus 8` should report as strong-scaling
-    speed-up if the exchange over xGMI costs what it costs here."""
+    """What ONE rank of the 8-GPU run (BASELINE configs[3]) does per step, measured on this one GPU: forward + backward of its 4 of
+    the 31 Panoptic views into its all_gather shard, the step's collective on a communicator of ONE rank (its launch and local copy
+    are in; the xGMI hop is not -- a one-wavefront idle kernel of 10 / 20 / 30 us in front of it stands in for the wire), the mean
+    over the gathered rank-major rows.  Two forms: "two_calls" (sks_forward, sks_backward, collective, all on one stream) and
+    "one_call" (what `bench.py --gpus N` runs: sks_forward_backward with the backward AND the collective on a second stream, beside
+    the dense forward).  Every figure is the median of >= 50 repetitions of a short loop, the variants interleaved round-robin on
+    this box; p10 / p90 beside it.  predicted speed-up = this GPU's 31-view step (same form) / the rank step."""
     import torch.distributed as dist
     from skelsplat_amd import rasterizer as R
     wl = WORKLOADS["panoptic"]
@@ -657,56 +745,57 @@ def extra_rank_step(args, torch, dev, sync):
     try:
         views = R.ViewBatch.from_cameras([scene.cameras[v] for v in local])
         dL = torch.randn((len(local), C, H, W), device=dev)
-        ws = R.Workspace()
-        shard = torch.zeros((vmax, P, 3), device=dev)
-        allg = torch.zeros((world * vmax, P, 3), device=dev)
-        mean_out = torch.empty((P, 3), device=dev)
-
-        from skelsplat_amd.rccl_direct import DirectGather
-        direct = DirectGather.create(dev)
-
-        def rank_step():
-            color, inv, radii, st = R.forward_views(views, *params, None, workspace=ws)
-            R.backward_views(st, *params, None, dL, workspace=ws, out_means3D=shard[:len(local)])
-            if direct is not None:                                        # (world 1: this rank's rows; the others stay zero)
-                direct.all_gather_into_tensor(allg[:vmax], shard)
-            else:
-                dist.all_gather_into_tensor(allg[:vmax], shard)
-            return R.mean_views(allg, V, world, out=mean_out)
-
-        def rank_step_allreduce():     # the form `bench.py --gpus 8` uses when the direct communicator exists (ApiStep)
-            color, inv, radii, st = R.forward_views(views, *params, None, workspace=ws)
-            lm = R.backward_views(st, *params, None, dL, workspace=ws, want_mean=True)["means3D_mean"]
-            direct.all_reduce_weighted(mean_out, lm, len(local) / V)
-            return mean_out
-
-        def no_exchange():
-            color, inv, radii, st = R.forward_views(views, *params, None, workspace=ws)
-            return R.backward_views(st, *params, None, dL, workspace=ws, out_means3D=shard[:len(local)])
-        n = max(20, args.steps // 2)
-        dt, _ = timed(rank_step, n, 10, sync)
-        dt0, _ = timed(no_exchange, n, 10, sync)
-        dta = None
-        if direct is not None:
-            dta, _ = timed(rank_step_allreduce, n, 10, sync)
-        full = ApiStep(R.ViewBatch.from_cameras(scene.cameras), params, torch.randn((V, C, H, W), device=dev))
-        nf = max(20, args.steps // 10)
-        dtf, _ = timed(full, nf, 5, sync)    # (the first calls allocate the 5 GB workspace)
-        best = min(dt, dta) if dta is not None else dt
-        out = {"rank_step_4views_panoptic_ms": 1e3 * best / n, "rank_step_all_gather_ms": 1e3 * dt / n,
-               "rank_step_all_reduce_ms": None if dta is None else 1e3 * dta / n, "rank_step_without_exchange_ms": 1e3 * dt0 / n,
-               "one_gpu_31views_ms": 1e3 * dtf / nf, "predicted_8gpu_speedup": (dtf / nf) / (best / n),
-               "ideal_speedup": V / vmax, "target": 6.0,
-               # what real xGMI latency would leave of it: the exchange measured here crosses no link (a communicator of ONE rank)
-               "predicted_8gpu_speedup_at_exchange_us": {str(us): (dtf / nf) / (dt0 / n + us * 1e-6) for us in (0, 10, 20, 30)},
-               "status": "PREDICTION from one GPU, not a measurement: no multi-GPU run was available to this build",
-               "gather": "ncclAllGather on the launch stream (rccl_direct)" if direct is not None else "torch.distributed",
-               "note": "rank 0 of 8: 4 views fwd+bwd + the step's one collective on a 1-rank RCCL communicator: all_gather of the "
-                       "per-view rows + sks_mean_views, or (what --gpus N uses when it can) the local mean from the backward's own "
-                       "launch + one all-reduce with a pre-multiplied sum"}
-
-        # the loop's own sharded steps the same way (MultiViewLoop with the exchange branch on the 1-rank communicator
-        # cannot emulate 8 ranks' shard layout; the API step above is what `value` of the --gpus N line measures)
+        dL_all = torch.randn((V, C, H, W), device=dev)
+        views_all = R.ViewBatch.from_cameras(scene.cameras)
+        variants = {}
+        for form, oc in (("two_calls", False), ("one_call", True)):
+            st = ApiStep(views, params, dL, V_total=V, exchange=(world, 0, None), one_call=oc)
+            st.allg_dst = st.allg[:vmax]
+            for us in (None, 0, 10, 20, 30):
+                def fn(st=st, us=us):
+                    st.no_collective, st.wire_us = us is None, float(us or 0)
+                    return st()
+                variants[(form, "no_exchange" if us is None else f"exchange_{us}us")] = fn
+            full = ApiStep(views_all, params, dL_all, one_call=oc)
+            variants[(form, "one_gpu_31views")] = full
+        inner = {k: (4 if k[1] == "one_gpu_31views" else 16) for k in variants}
+        for k, fn in variants.items():      # allocations, recorded calls, the communicator
+            for _ in range(3):
+                fn()
+        sync()
+        reps = max(50, min(200, args.steps // 2))
+        samples = {k: [] for k in variants}
+        for _ in range(reps):
+            for k, fn in variants.items():
+                sync()
+                t0 = time.perf_counter()
+                for _ in range(inner[k]):
+                    fn()
+                sync()
+                samples[k].append(1e3 * (time.perf_counter() - t0) / inner[k])
+        q = lambda xs, f: sorted(xs)[min(len(xs) - 1, int(f * (len(xs) - 1) + 0.5))]
+        out = {"status": "PREDICTION from one GPU, not a measurement: no multi-GPU run was available to this build",
+               "repetitions": reps, "ideal_speedup": V / vmax, "target": 6.0,
+               "gather": "torch.distributed all_gather_into_tensor on a 1-rank RCCL communicator + sks_mean_views",
+               "wire": "exchange_Nus = an idle one-wavefront kernel of N us in front of the collective (sks_prof_spin): the xGMI hop "
+                       "a one-rank communicator does not make"}
+        for form in ("two_calls", "one_call"):
+            base = q(samples[(form, "one_gpu_31views")], 0.5)
+            blk = {"one_gpu_31views_ms": round(base, 5)}
+            for (f2, name), xs in samples.items():
+                if f2 != form or name == "one_gpu_31views":
+                    continue
+                med = q(xs, 0.5)
+                blk[name] = {"rank_step_ms": round(med, 5), "p10_p90_ms": [round(q(xs, 0.1), 5), round(q(xs, 0.9), 5)],
+                             "predicted_8gpu_speedup": round(base / med, 3)}
+            # self-consistency of the table: the step without its exchange is never slower than with it (0.5 % of timer noise)
+            blk["consistent"] = bool(blk["no_exchange"]["rank_step_ms"] <= 1.005 * blk["exchange_0us"]["rank_step_ms"]
+                                     and blk["exchange_0us"]["rank_step_ms"] <= 1.005 * blk["exchange_30us"]["rank_step_ms"])
+            out[form] = blk
+        best = out["one_call"]
+        out["rank_step_4views_panoptic_ms"] = best["exchange_0us"]["rank_step_ms"]
+        out["predicted_8gpu_speedup"] = best["exchange_0us"]["predicted_8gpu_speedup"]
+        out["predicted_8gpu_speedup_at_30us_wire"] = best["exchange_30us"]["predicted_8gpu_speedup"]
         return out
     finally:
         if own:
@@ -747,6 +836,7 @@ def run_sharded(args, torch, dist, dev, wl, world, rank):
     dt_full, _ = timed(full, n_ref, 3, sync)
     dt_full = max_over_ranks(dt_full)
     one_gpu_ms = 1e3 * dt_full / n_ref
+    ref_mean = full().clone()     # what the sharded step must reproduce: the mean over all V views' joint gradients
     del full
     # (B) the timed region: the same V views, view v on rank v % world, one all_gather of the joint gradients per step
     lviews = R.ViewBatch.from_cameras([scene.cameras[v] for v in local]) if local else None
@@ -760,17 +850,30 @@ def run_sharded(args, torch, dist, dev, wl, world, rank):
         step()
     sync()
     prof = not args.no_prof and bool(local)
-    if prof:
-        _lib.prof_enable(True, every=prof_stride(args.steps))
-        _lib.prof_read(0), _lib.prof_read(1)
-    dt, out = timed(step, args.steps, 0, sync)
+    dt, out = timed(step, args.steps, 0, sync)      # THE timed region: K steps, nothing bracketed inside
     dt = max_over_ranks(dt)
     pf = None
     if prof:
+        # the dominant kernel's duration: from the two-call form of this rank's forward + backward, right behind the timed region
+        # (in the one-call form the backward and the collective run beside the forward: a pair around it would time all three)
+        step2 = ApiStep(lviews, params, dL, one_call=False)
+        for _ in range(3):
+            step2()
+        _lib.prof_enable(True, every=1, kinds=(0,))
+        _lib.prof_read(0), _lib.prof_read(1)
+        for _ in range(ROOF_MIN_LAUNCHES):
+            step2()
+        torch.cuda.synchronize()
         pf = _lib.prof_read_quantiles(0)
         _lib.prof_enable(False)
+        del step2
     assert torch.isfinite(out).all()
+    # all_gather: the V rows are summed in view order on every rank -- bit for bit the one-GPU mean; all_reduce re-associates
+    same = bool(torch.equal(out, ref_mean)) if exchange_mode == "all_gather" else \
+        bool(torch.allclose(out, ref_mean, rtol=1e-5, atol=1e-6 * float(ref_mean.abs().max())))
+    assert same, "the sharded step's mean differs from the one-GPU mean"
     used_direct = step.direct is not None
+    step_one_call = step.one_call
     del step, dL
     ms = 1e3 * dt / args.steps
     vmax = (V + world - 1) // world
@@ -789,18 +892,22 @@ def run_sharded(args, torch, dist, dev, wl, world, rank):
         "config": {"workload": wl["name"], "views_total": V, "views_on_rank0": len(local), "P": P, "C": C, "W": W, "H": H,
                    "parallelism": f"views sharded v % {world} over {world} ranks; {what} per step ({coll})",
                    "exchange": exchange_mode,
-                   "path": "C ABI sks_forward + sks_backward, eager launches"},
+                   "path": "C ABI sks_forward_backward (the backward beside the dense forward on a second stream) with the step's "
+                           "collective and the mean behind the backward on that second stream: hidden under the forward; eager "
+                           "launches" if step_one_call else "C ABI sks_forward + sks_backward + collective on one stream, eager launches"},
         # the SAME 31-view step on one GPU alone, measured in this run (all ranks side by side, no communication): the
         # reference point for this line's `value` (the N = 1 line of bench.py times a different workload, BASELINE configs[1])
         "one_gpu_same_workload_views_per_s": V * n_ref / dt_full,
         "one_gpu_same_workload_ms_per_step": one_gpu_ms,
         "speedup_vs_one_gpu_same_workload": one_gpu_ms / ms,
+        "mean_equals_one_gpu": "bit for bit" if exchange_mode == "all_gather" else "rtol 1e-5",
         "weak_scaling_views_per_s": world * V * n_ref / dt_full,
     }
     if pf and pf[1]:
         res["roofline"] = roofline_entry(4.0 * H * W * (C + 1) * len(local), pf, wl["name"], args.steps,
                                          traffic_scale=len(local) / V)
         res["roofline"]["note"] = f"rank 0's launch: its {len(local)} local views"
+        res["roofline"]["timed_in"] = "the two-call form of this rank's forward + backward, right behind the timed region"
     if not args.no_extras:
         # (C, D) the loop's own step -- render + masked-L2 + backward + [all_gather] + Adam (train.py:130-222): dense and
         # sparse fused, each alone on one GPU (shard_views=False, all ranks side by side) and sharded over the ranks

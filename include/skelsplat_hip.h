@@ -118,6 +118,33 @@ int sks_backward(int V, int P, int C, int W, int H,
                  train.py:215-217); for V * P <= 256 it comes out of the same launch as the geometry backward */,
                  void* stream);
 
+/* sks_forward + sks_backward of the same inputs as ONE call, for a caller whose upstream gradient does not depend on the image
+ * this call renders (dL_dout_color / dL_dout_invdepth complete in `stream` order when the call is made: a known gradient, or the
+ * previous evaluation's).  On the small path (P <= SKS_SMALL_P) the backward needs the forward's geometry records, not its image,
+ * so with a second stream it runs BESIDE the dense forward instead of behind it: k_geom_fwd on `stream`; the backward's launches on
+ * `aux_stream`, ordered behind the geometry kernel by an event; the fill + composite launch on `stream`; `stream` then waits for
+ * the backward -- outputs and gradients are the caller's in `stream` order, exactly as after the two separate calls, and bit for
+ * bit the same numbers.  The latency-bound backward (a few thousand short workgroups) hides under the HBM-bound forward: the H36M
+ * step 67 -> ~57 us.  aux_stream NULL (or == stream, or the binned path, whose backward starts from what the forward's
+ * compositor left per pixel): the two calls one after the other.  Arguments as for sks_forward (without the two debug outputs)
+ * followed by sks_backward's.  The library keeps two hipEvents per host thread for the hand-over (created by the first call).
+ * fb_flags: SKS_FB_NO_JOIN = `stream` does NOT wait for the backward at the end: the caller has more to enqueue behind the
+ * gradients on aux_stream -- a view-sharded step's collective on the joint gradients, which then also hides under the forward --
+ * and makes `stream` wait for aux_stream itself (an event recorded on aux_stream, hipStreamWaitEvent on stream). */
+#define SKS_FB_NO_JOIN 1u
+int sks_forward_backward(int V, int P, int C, int W, int H,
+                         const float* viewmatrix, const float* projmatrix,
+                         const float* tanfovx /*HOST V*/, const float* tanfovy /*HOST V*/,
+                         const float* means3D, const float* features, const float* opacities,
+                         const float* scales, const float* rotations, const float* cov3D_precomp,
+                         float scale_modifier, unsigned flags,
+                         float* out_color, float* out_invdepth, int* radii,
+                         void* geom, void* binning, size_t bin_capacity, int* num_rendered_dev,
+                         const float* bg, const float* dL_dout_color, const float* dL_dout_invdepth, void* accum,
+                         float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dopacity,
+                         float* dL_dscales, float* dL_drotations, float* dL_dcov3D, float* dL_dfeatures,
+                         float* dL_dmeans3D_mean, void* stream, void* aux_stream, unsigned fb_flags);
+
 /* xyz.grad = accumulated_grads.mean(dim=0) (train.py:215-217) on its own: mean over the V views of (V,P,3) joint gradients,
  * summed in view order.  shard_world = N > 1: the rows are where all_gather_into_tensor leaves them when view v is local view
  * v / N of rank v % N and every rank contributes ceil(V / N) rows (see sks_loop_adam_step) -- the exchange step of a
@@ -309,6 +336,9 @@ int sks_loop_fused_step(int V, int P, int C, int W, int H, const float* viewmatr
  * sampling keeps the measured loop undisturbed); bits 16-17: kinds to leave OUT (bit 16: kind 0, bit 17: kind 1).  sks_prof_read waits for the recorded events, returns
  * the summed kernel time in milliseconds and the number of BRACKETED launches since the last read, and resets them. */
 int sks_prof_enable(int on);
+/* Enqueues ONE wavefront that idles for `microseconds` (wall clock) on `stream`: a stand-in for the wire time of a latency-bound
+ * collective, so that one GPU can measure what a rank of many sees when the exchange takes that long (bench.py rank_step_8gpu). */
+int sks_prof_spin(double microseconds, void* stream);
 /* bracketed launches of one kind collected since the last read (sks_prof_enable does not reset them: a caller may change the
  * sampling stride in the middle of a collection) */
 int sks_prof_count(int kind, long long* launches);

@@ -21,6 +21,7 @@ SKS_NO_NT_STORES = 16
 SKS_RAW_PARAMS = 32
 SKS_BIN_CLEAN = 64
 SKS_RAW_GRADS = 128
+SKS_FB_NO_JOIN = 1
 SKS_SSIM_SCRATCH_BYTES = 64 * 8
 
 _vp, _i, _u, _f, _sz = C.c_void_p, C.c_int, C.c_uint, C.c_float, C.c_size_t
@@ -34,6 +35,9 @@ SIGNATURES = {
                          _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
     "sks_backward": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _u,
                           _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sks_forward_backward": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _u,
+                                  _vp, _vp, _vp, _vp, _vp, _sz, _vp,
+                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u]),
     "sks_mark_visible": (_i, [_i, _vp, _vp, _vp, _vp, _vp]),
     "sks_mean_views": (_i, [_i, _i, _vp, _i, _vp, _vp]),
     "sks_export_lists": (_i, [_i, _i, _i, _vp, _sz, _vp, _vp, _vp]),
@@ -60,6 +64,7 @@ SIGNATURES = {
                                  _vp, C.c_ulonglong, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp,
                                  _i, _vp, _vp]),
     "sks_prof_enable": (_i, [_i]),
+    "sks_prof_spin": (_i, [C.c_double, _vp]),
     "sks_prof_read": (_i, [_i, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     "sks_prof_count": (_i, [_i, C.POINTER(C.c_longlong)]),
     "sks_prof_read_quantiles": (_i, [_i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),

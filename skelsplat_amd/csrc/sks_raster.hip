@@ -210,6 +210,27 @@ void launch_bwd_small(const BwdArgs& a, const ViewTan& vt, const ViewOff& vo, in
     else SKS_LAUNCH(prof, (k_render_bwd_gather<CG, false>), grid, dim3(256), lds, st, a);
 }
 
+// sks_prof_spin: one wavefront that does nothing for a given time (the 100 MHz wall clock) -- stands in for the wire time of a
+// latency-bound collective when one GPU measures what a rank of many would see (bench.py)
+__global__ void k_spin_us(unsigned long long ticks)
+{
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
+// sks_forward_backward: the backward's launches go to a second stream between the geometry kernel and the dense forward (see the
+// entry point).  sks_forward finds this record (per host thread) and calls it right behind k_geom_fwd.
+struct FusedBackward {
+    int (*run)(void* ctx);
+    void* ctx;
+    hipEvent_t geom_done;   // rides on k_geom_fwd's own dispatch (hipExtLaunchKernelGGL): no marker packet in the caller's queue
+};
+thread_local FusedBackward* tl_fused_bwd = nullptr;
+struct FbEvents {   // created by a thread's first combined call, reused by every later one
+    hipEvent_t geom = nullptr, done = nullptr;
+};
+thread_local FbEvents tl_fb_events;
+
 }  // namespace
 
 #ifndef SKS_GEOM_BINNED_THREADS
@@ -276,11 +297,22 @@ int sks_forward(int V, int P, int C, int W, int H, const float* viewmatrix, cons
     }
     if (!small) g.cover = nullptr;   // (the binned path's cover rows are per plane: Bin::coverp, k_bin_scan + k_bin_sort_long)
     const int gthreads = small ? ((g.cover && cover_per_plane(P, W, H, C)) ? SKS_GEOM_COVER_THREADS : 256) : SKS_GEOM_BINNED_THREADS;
+    if (tl_fused_bwd && small && tl_fused_bwd->geom_done)
+        hipExtLaunchKernelGGL(k_geom_fwd, dim3((P + gthreads - 1) / gthreads, V), dim3(gthreads), 0, st, nullptr, tl_fused_bwd->geom_done, 0,
+                              P, W, H, vt, viewmatrix, projmatrix, means3D, opacities, scales, rotations, cov3D_precomp, scale_modifier,
+                              flags, g, radii, 0, (uint32_t*)nullptr, (uint32_t*)nullptr, features, C, (uint2*)nullptr, (uint32_t*)nullptr,
+                              cover_per_plane(P, W, H, C) ? 1 : 0);
+    else
     hipLaunchKernelGGL(k_geom_fwd, dim3((P + gthreads - 1) / gthreads, V), dim3(gthreads), 0, st, P, W, H, vt, viewmatrix, projmatrix,
                        means3D, opacities, scales, rotations, cov3D_precomp, scale_modifier, flags, g, radii, 0,
                        small ? (uint32_t*)nullptr : b.count, small ? (uint32_t*)nullptr : b.touched, features, C,
                        small ? (uint2*)nullptr : b.fmask, small ? (uint32_t*)nullptr : b.hdr, (small && cover_per_plane(P, W, H, C)) ? 1 : 0);
     STAGE_CHECK("geometry");
+    if (tl_fused_bwd && small) {   // (sks_forward_backward: the backward behind the geometry, on its own stream)
+        FusedBackward* fb = tl_fused_bwd;
+        tl_fused_bwd = nullptr;
+        if (int rc = fb->run(fb->ctx)) return rc;
+    }
 
     FwdArgs a{ P, C, W, H, flags, g, features, out_color, out_invdepth, final_T, n_contrib, composite_slots(flags, V, P),
                ((1u << 20) + (unsigned)C) / (unsigned)(C + 1), 0, (!small || (g.cover && cover_per_plane(P, W, H, C))) ? 1 : 0,
@@ -393,6 +425,86 @@ int sks_backward(int V, int P, int C, int W, int H, const float* viewmatrix, con
             hipLaunchKernelGGL(k_mean_views, dim3((3 * P + 255) / 256), dim3(256), 0, st, V, P, dL_dmeans3D, dL_dmeans3D_mean);
     }
     STAGE_CHECK("geometry-backward");
+    return 0;
+}
+
+int sks_forward_backward(int V, int P, int C, int W, int H, const float* viewmatrix, const float* projmatrix,
+                         const float* tanfovx, const float* tanfovy, const float* means3D, const float* features,
+                         const float* opacities, const float* scales, const float* rotations, const float* cov3D_precomp,
+                         float scale_modifier, unsigned flags, float* out_color, float* out_invdepth, int* radii, void* geom,
+                         void* binning, size_t bin_capacity, int* num_rendered_dev, const float* bg,
+                         const float* dL_dout_color, const float* dL_dout_invdepth, void* accum, float* dL_dmeans3D,
+                         float* dL_dmeans2D, float* dL_dopacity, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
+                         float* dL_dfeatures, float* dL_dmeans3D_mean, void* stream, void* aux_stream, unsigned fb_flags)
+{
+    const bool small = P <= SKS_SMALL_P && !(flags & SKS_FORCE_BINNED);
+    struct Ctx {
+        int V, P, C, W, H;
+        const float *vm, *pm, *tx, *ty, *bg, *means, *feat, *opac, *scales, *rots, *cov;
+        float smod;
+        unsigned flags;
+        const int* radii;
+        const void* geom;
+        const float *dL, *dLinv;
+        void* accum;
+        float *m3, *m2, *op, *sc, *rot, *dcov, *dfeat, *mean;
+        hipStream_t s, aux;
+        bool ext, no_join;
+    } c{ V, P, C, W, H, viewmatrix, projmatrix, tanfovx, tanfovy, bg, means3D, features, opacities, scales, rotations, cov3D_precomp,
+         scale_modifier, flags, radii, geom, dL_dout_color, dL_dout_invdepth, accum, dL_dmeans3D, dL_dmeans2D, dL_dopacity,
+         dL_dscales, dL_drotations, dL_dcov3D, dL_dfeatures, dL_dmeans3D_mean, (hipStream_t)stream, (hipStream_t)aux_stream, true, (fb_flags & SKS_FB_NO_JOIN) != 0 };
+    {
+        static const bool ext_off = [] { const char* e = getenv("SKS_FB_EXT"); return e && atoi(e) == 0; }();   // tuning
+        if (ext_off) c.ext = false;
+    }
+    if (!small || !aux_stream || aux_stream == stream || P == 0 || (flags & SKS_DEBUG_SYNC)) {
+        // the binned path's backward starts from what the forward's compositor left per pixel: one after the other
+        if (int rc = sks_forward(V, P, C, W, H, viewmatrix, projmatrix, tanfovx, tanfovy, means3D, features, opacities, scales, rotations,
+                                 cov3D_precomp, scale_modifier, flags, out_color, out_invdepth, radii, geom, binning, bin_capacity,
+                                 num_rendered_dev, nullptr, nullptr, stream))
+            return rc;
+        return sks_backward(V, P, C, W, H, viewmatrix, projmatrix, tanfovx, tanfovy, bg, means3D, features, opacities, scales, rotations,
+                            cov3D_precomp, scale_modifier, flags, radii, geom, binning, bin_capacity, dL_dout_color, dL_dout_invdepth,
+                            accum, dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dscales, dL_drotations, dL_dcov3D, dL_dfeatures,
+                            dL_dmeans3D_mean, stream);
+    }
+    FbEvents& ev = tl_fb_events;
+    if (!ev.geom) {
+        // hand-over between two queues of ONE device: a device-scope release is all the waiting side needs (the default,
+        // a system-scope fence, is what a host reader of the event would want)
+        unsigned evf = hipEventDisableTiming | hipEventDisableSystemFence;
+        if (const char* e = getenv("SKS_FB_EVENT_FLAGS")) evf = (unsigned)strtoul(e, nullptr, 0);   // tuning
+        HIP_TRY(hipEventCreateWithFlags(&ev.geom, evf));
+        HIP_TRY(hipEventCreateWithFlags(&ev.done, evf));
+    }
+    struct Run {
+        static int go(void* p)
+        {
+            const Ctx& k = *(const Ctx*)p;
+            FbEvents& e = tl_fb_events;
+            // e.geom: behind k_geom_fwd, i.e. behind everything the caller enqueued
+            if (!k.ext) HIP_TRY(hipEventRecord(e.geom, k.s));   // (else it rode on k_geom_fwd's dispatch)
+            HIP_TRY(hipStreamWaitEvent(k.aux, e.geom, 0));
+            const int rc = sks_backward(k.V, k.P, k.C, k.W, k.H, k.vm, k.pm, k.tx, k.ty, k.bg, k.means, k.feat, k.opac, k.scales, k.rots,
+                                        k.cov, k.smod, k.flags, k.radii, k.geom, nullptr, 0, k.dL, k.dLinv, k.accum, k.m3, k.m2, k.op,
+                                        k.sc, k.rot, k.dcov, k.dfeat, k.mean, k.aux);
+            if (rc) return rc;
+            if (!k.no_join) HIP_TRY(hipEventRecord(e.done, k.aux));
+            return 0;
+        }
+    };
+    FusedBackward fb{ &Run::go, &c, c.ext ? ev.geom : nullptr };
+    tl_fused_bwd = &fb;
+    const int rc = sks_forward(V, P, C, W, H, viewmatrix, projmatrix, tanfovx, tanfovy, means3D, features, opacities, scales, rotations,
+                               cov3D_precomp, scale_modifier, flags, out_color, out_invdepth, radii, geom, binning, bin_capacity,
+                               num_rendered_dev, nullptr, nullptr, stream);
+    const bool ran = tl_fused_bwd == nullptr;
+    tl_fused_bwd = nullptr;
+    if (rc) return rc;
+    if (!ran) return fail(-3, "sks_forward_backward: the forward did not reach its geometry stage");
+    // the gradients are the caller's in stream order -- unless the caller has more to enqueue behind the backward on aux_stream
+    // (a view-sharded step's collective: hidden under the forward as well) and joins the two streams itself
+    if (!c.no_join) HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, ev.done, 0));
     return 0;
 }
 
@@ -528,6 +640,14 @@ int sks_loop_fused_step(int V, int P, int C, int W, int H, const float* viewmatr
                     nullptr, nullptr };
     hipLaunchKernelGGL(k_step_tail, dim3(frames), dim3(256), 0, st, ga, vt, aa, Vf, g, radii);
     STAGE_CHECK("step tail");
+    return 0;
+}
+
+int sks_prof_spin(double microseconds, void* stream)
+{
+    if (!(microseconds >= 0.0) || microseconds > 1e6) return fail(-1, "prof_spin: 0 .. 1e6 us");
+    hipLaunchKernelGGL(k_spin_us, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long)(microseconds * 100.0));
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 

@@ -68,8 +68,20 @@ class Workspace:
     def __init__(self):
         self._t = {}
         self._plans = {}     # "fwd" / "bwd" -> the last call's recorded C-ABI argument list (see _plan_key)
+        self._aux = {}
         self._bin_clean = {}   # binning buffer (data_ptr) -> the layout (V, P, C, W, H, capacity) whose last sks_forward COMPLETED
                                # on it and left its tile counters zero: only then may a replay carry SKS_BIN_CLEAN
+
+    def aux_stream(self, dev_index):
+        """The second stream forward_backward_views runs the backward on (created on first use, one per device)."""
+        st = self._aux.get(dev_index)
+        if st is None:
+            st = self._aux[dev_index] = torch.cuda.Stream(device=dev_index)
+        return st
+
+    def join(self, dev_index):
+        """The current stream waits for everything enqueued on the second stream (forward_backward_views(join=False))."""
+        torch.cuda.current_stream(dev_index).wait_stream(self.aux_stream(dev_index))
 
     def get(self, name, shape, dtype, device):
         key = (name, tuple(shape), dtype, device)
@@ -196,8 +208,8 @@ def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotati
     key = None
     if workspace is not None and not want_aux:
         # the same call as last time (same tensors, same switches)?  Then the validated argument list is replayed as is.
-        key = (id(views), _sig(means3D), _sig(features), _sig(opacities), _sig(scales), _sig(rotations), _sig(cov3D_precomp),
-               scale_modifier, antialiasing, clamp01, debug, force_binned, bin_capacity, tune_flags, check_capacity)
+        key = _fwd_key(views, means3D, features, opacities, scales, rotations, cov3D_precomp, scale_modifier, antialiasing,
+                       clamp01, debug, force_binned, bin_capacity, tune_flags, check_capacity)
         plan = workspace._plans.get("fwd")
         if plan is not None and plan[0] == key:
             _, _views, args, dev_index, result, cap_check = plan
@@ -211,6 +223,8 @@ def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotati
                     raise
                 args[23] = None if host is None else host.data_ptr()
                 result[3].num_rendered_dev = host
+            if cap_check is not None and check_capacity is True:
+                cap_check[0][1][:args[0]] = -1       # (the pinned counts of the synchronous check: "not written yet")
             if args[21] is not None:
                 # the recorded flags carry SKS_BIN_CLEAN ("the buffer is as this layout's last completed forward left it"): true
                 # only while nothing else -- another layout of the same byte size, a call that failed half-way -- has been through
@@ -228,7 +242,7 @@ def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotati
                 return result
             nr, pcap, ckey = cap_check
             if check_capacity is True:
-                if int(nr[:args[0]].max().item()) <= pcap:
+                if _wait_counts(nr, args[0], dev_index) <= pcap:
                     return result
                 del workspace._plans["fwd"]     # the binning arena overflowed: the validating path below grows it and redoes
             else:
@@ -282,6 +296,8 @@ def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotati
         # the pair counts go straight to pinned host memory (k_bin_scan stores them there: no copy launch, no event): they are
         # looked at when the NEXT call of the shape comes in -- first the previous call's, which may raise
         nrend = _lazy_probe(cap_key, cap)     # (None only inside a hipGraph capture)
+    elif binned and check_capacity is True and not torch.cuda.is_current_stream_capturing():
+        nrend = _sync_counts(cap_key)     # pinned host memory, preset to -1 (see _wait_counts)
     else:
         nrend = new("nrend", (V + 1,), torch.int32) if binned else None   # [0, V): written by k_bin_scan
     final_T = torch.empty((V, H, W), dtype=torch.float32, device=dev) if want_aux else None
@@ -290,7 +306,7 @@ def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotati
             views.tanfovy, _lib.ptr(means3D), _lib.ptr(feat2), _lib.ptr(opacities), _lib.ptr(scales),
             _lib.ptr(rotations), _lib.ptr(cov3D_precomp), float(scale_modifier), flags,
             color.data_ptr(), invdepth.data_ptr(), _lib.ptr(radii), geom.data_ptr(),
-            _lib.ptr(binning), cap, _lib.ptr(nrend), _lib.ptr(final_T), _lib.ptr(n_contrib), None]
+            _lib.ptr(binning), cap, _lib.ptr(nrend[0] if isinstance(nrend, tuple) else nrend), _lib.ptr(final_T), _lib.ptr(n_contrib), None]
     if binned and workspace is not None:
         workspace._bin_clean.pop(args[21], None)     # (this call clears the counters itself; dirty until it has completed)
     _lib.check(_replay(lib.sks_forward, args, dev.index), "sks_forward")
@@ -305,7 +321,7 @@ def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotati
         # shape comes in (_lazy_probe) -- no host synchronisation, no copy launch on the fast path; an overflow found that way
         # grows the arena for the calls to come and raises, because the image that call produced was missing entries.
         if not lazy:
-            need = int(nrend[:V].max().item())
+            need = _wait_counts(nrend, V, dev.index) if isinstance(nrend, tuple) else int(nrend[:V].max().item())
             _BIN_CAP_SEEN.add(cap_key)
             if check_capacity == "auto" and need <= cap and bin_capacity_given is None:
                 # later calls of the shape go unchecked until the call after them: leave them room to grow
@@ -317,7 +333,8 @@ def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotati
                                      check_capacity, workspace)
     st = ForwardState()
     st.views, st.P, st.C, st.flags, st.scale_modifier = views, P, C, flags, float(scale_modifier)
-    st.geom, st.binning, st.bin_capacity, st.radii, st.num_rendered_dev = geom, binning, cap, radii, nrend
+    st.geom, st.binning, st.bin_capacity, st.radii = geom, binning, cap, radii
+    st.num_rendered_dev = nrend[0] if isinstance(nrend, tuple) else nrend
     if want_aux:
         return color, invdepth, radii, st, final_T, n_contrib
     if key is not None and all(sg is not False for sg in key[1:7]) and not torch.cuda.is_current_stream_capturing():
@@ -337,6 +354,19 @@ def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotati
     return color, invdepth, radii, st
 
 
+def _fwd_key(views, means3D, features, opacities, scales, rotations, cov3D_precomp, scale_modifier, antialiasing, clamp01, debug,
+             force_binned, bin_capacity, tune_flags, check_capacity):
+    return (id(views), _sig(means3D), _sig(features), _sig(opacities), _sig(scales), _sig(rotations), _sig(cov3D_precomp),
+            scale_modifier, antialiasing, clamp01, debug, force_binned, bin_capacity, tune_flags, check_capacity)
+
+
+def _bwd_key(st, means3D, features, opacities, scales, rotations, cov3D_precomp, dL_dcolor, dL_dinvdepth, bg, want_dfeatures,
+             tune_flags, want_mean, out_means3D, stream):
+    return (id(st), _sig(means3D), _sig(features), _sig(opacities), _sig(scales), _sig(rotations), _sig(cov3D_precomp),
+            _sig(dL_dcolor), _sig(dL_dinvdepth), None if bg is None else (id(bg), bg._version), want_dfeatures, tune_flags,
+            want_mean, None if out_means3D is None else out_means3D.data_ptr(), stream)   # (the partial-sum scratch is per stream)
+
+
 _SCRATCH_BYTES = {}
 _BIN_CAP_HINT = {}     # (device, V, P, C, W, H) -> arena capacity learned from an overflow
 _BIN_CAP_SEEN = set()  # shapes whose arena a synchronous call has sized already ("auto" goes lazy after that)
@@ -348,6 +378,37 @@ class _Probes:
 
     def __init__(self):
         self.pending, self.free = [], []      # pending: [(pinned int32 tensor, its numpy view, capacity of that call)], oldest first
+
+
+_SYNC_PROBE = {}       # shape -> (pinned int32 tensor, its numpy view): the counts of the synchronous check
+
+
+def _sync_counts(cap_key):
+    hit = _SYNC_PROBE.get(cap_key)
+    if hit is None:
+        host = torch.empty((cap_key[1] + 1,), dtype=torch.int32).pin_memory()
+        hit = _SYNC_PROBE[cap_key] = (host, host.numpy())
+    hit[1][:] = -1
+    return hit
+
+
+def _wait_counts(probe, V, dev_index):
+    """check_capacity=True: the pair counts of the call just enqueued.  The reference reads them back with a blocking copy between
+    its scan and its duplication kernels (rasterizer_impl.cu:283-288).  Here k_bin_scan stores them straight into pinned host
+    memory ~30 us into the launch sequence and the host spins on THAT -- not on the stream: it has the counts long before the
+    forward's compositor is through (0.4 ms on the stress scene), returns, and the caller's next launches queue up behind the
+    running forward.  The check stays synchronous and exact (an arena that was too small is grown and the forward redone before
+    anything is returned); what it no longer costs is the idle GPU between two calls (bench.py stress: default mode vs "auto")."""
+    import time
+    view = probe[1]
+    t0 = time.perf_counter()
+    while int(view[:V].min()) < 0:
+        if time.perf_counter() - t0 > 0.2:      # (counts that never arrive: wait for the stream, look once more)
+            torch.cuda.current_stream(dev_index).synchronize()
+            if int(view[:V].min()) < 0:
+                raise RuntimeError("skelsplat_amd: the binned forward's pair counts did not reach the host")
+            break
+    return int(view[:V].max())
 
 
 _PROBES_IN_FLIGHT = 1024     # calls of one shape the host may be ahead of the GPU by (36 bytes of pinned memory each)
@@ -441,10 +502,8 @@ def backward_views(st: ForwardState, means3D, features, opacities, scales, rotat
     lib = _lib.load()
     key = None
     if workspace is not None and st.P:
-        key = (id(st), _sig(means3D), _sig(features), _sig(opacities), _sig(scales), _sig(rotations), _sig(cov3D_precomp),
-               _sig(dL_dcolor), _sig(dL_dinvdepth), None if bg is None else (id(bg), bg._version), want_dfeatures, tune_flags,
-               want_mean, None if out_means3D is None else out_means3D.data_ptr(),
-               torch._C._cuda_getCurrentRawStream(st.geom.device.index))   # (the partial-sum scratch is per stream)
+        key = _bwd_key(st, means3D, features, opacities, scales, rotations, cov3D_precomp, dL_dcolor, dL_dinvdepth, bg,
+                       want_dfeatures, tune_flags, want_mean, out_means3D, torch._C._cuda_getCurrentRawStream(st.geom.device.index))
         plan = workspace._plans.get("bwd")
         if plan is not None and plan[0] == key:
             _, _keep, args, dev_index, result = plan
@@ -507,6 +566,60 @@ def backward_views(st: ForwardState, means3D, features, opacities, scales, rotat
         keep = (st, means3D, feat2, opacities, scales, rotations, cov3D_precomp, dL_dcolor, dL_dinvdepth, bg, bgC, accum)
         workspace._plans["bwd"] = (key, keep, args, dev.index, out)
     return out
+
+
+def forward_backward_views(views: ViewBatch, means3D, features, opacities, scales, rotations, cov3D_precomp, dL_dcolor,
+                           dL_dinvdepth=None, bg=None, scale_modifier=1.0, antialiasing=False, clamp01=False, want_dfeatures=False,
+                           tune_flags=0, workspace=None, want_mean=False, out_means3D=None, overlap=True, join=True):
+    """forward_views + backward_views of the same inputs as ONE C-ABI call (sks_forward_backward), for a caller whose upstream
+    gradient `dL_dcolor` is complete when the call is made -- it does not depend on the image this call renders.  Returns
+    (color, invdepth, radii, state, grads): the same tensors, bit for bit, the two calls return.  On the small path (P <= 256) the
+    backward's launches go to the workspace's second stream, ordered behind the geometry kernel, and run BESIDE the dense
+    forward (include/skelsplat_hip.h); everything is the caller's in current-stream order when the call returns.  Needs a
+    Workspace: its first call of a shape IS the two separate calls (they validate, allocate and record their argument lists), the
+    later ones replay both records through the combined entry point.  overlap=False: the combined entry point, one stream.
+    join=False: the current stream is NOT made to wait for the backward; the caller enqueues what follows the gradients -- a
+    view-sharded step's collective -- on `workspace.aux_stream(dev)` (under the forward, too) and then calls `workspace.join(dev)`.
+    (On the paths that do not overlap -- first call, binned path, overlap=False -- the gradients are on the current stream and
+    join() is a no-op hand-over in the other direction: aux waits for the current stream first, so the same caller code is right.)"""
+    if workspace is None:
+        raise ValueError("forward_backward_views needs a Workspace (outputs, scratch and the second stream live there)")
+    lib = _lib.load()
+    fplan, bplan = workspace._plans.get("fwd"), workspace._plans.get("bwd")
+    if fplan is not None and bplan is not None and fplan[5] is None:     # (a binned forward keeps its capacity check: two calls)
+        dev_index = fplan[3]
+        fkey = _fwd_key(views, means3D, features, opacities, scales, rotations, cov3D_precomp, scale_modifier, antialiasing, clamp01,
+                        False, False, None, tune_flags, True)
+        if fplan[0] == fkey:
+            st = fplan[4][3]
+            bkey = _bwd_key(st, means3D, features, opacities, scales, rotations, cov3D_precomp, dL_dcolor, dL_dinvdepth, bg,
+                            want_dfeatures, tune_flags, want_mean, out_means3D, torch._C._cuda_getCurrentRawStream(dev_index))
+            if bplan[0] == bkey:
+                aux = workspace.aux_stream(dev_index) if (overlap or not join) else None
+                fa, ba = fplan[2], bplan[2]
+                no_join = overlap and not join
+                args = fa[:24] + [ba[9], ba[22], ba[23], ba[24]] + ba[25:33] + [None, aux.cuda_stream if overlap else None,
+                                                                             _lib.SKS_FB_NO_JOIN if no_join else 0]
+                args[-3] = torch._C._cuda_getCurrentRawStream(dev_index)
+                if torch._C._cuda_getDevice() == dev_index:
+                    rc = lib.sks_forward_backward(*args)
+                else:
+                    with torch.cuda.device(dev_index):
+                        rc = lib.sks_forward_backward(*args)
+                if rc != 0:
+                    reset_scratch()
+                    workspace._plans.pop("fwd", None), workspace._plans.pop("bwd", None)
+                _lib.check(rc, "sks_forward_backward")
+                if not join and not overlap:     # (the gradients were produced on the current stream: aux must see them)
+                    aux.wait_stream(torch.cuda.current_stream(dev_index))
+                return fplan[4] + (bplan[4],)
+    out = forward_views(views, means3D, features, opacities, scales, rotations, cov3D_precomp, scale_modifier, antialiasing, clamp01,
+                        tune_flags=tune_flags, workspace=workspace)
+    g = backward_views(out[3], means3D, features, opacities, scales, rotations, cov3D_precomp, dL_dcolor, dL_dinvdepth, bg,
+                       want_dfeatures, tune_flags, workspace, want_mean, out_means3D)
+    if not join:
+        workspace.aux_stream(means3D.device.index).wait_stream(torch.cuda.current_stream(means3D.device))
+    return out + (g,)
 
 
 def mean_views(grads, V, world=1, out=None):

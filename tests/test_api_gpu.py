@@ -7,6 +7,7 @@ GPU with the same raw inputs, and every value that crosses into the native libra
 handed to ITS native module: argument by argument (gaussian_renderer/__init__.py:28-138,
 DGR/diff_gaussian_rasterization_h36m/__init__.py:60-81, 101-139).
 """
+import math
 import os
 
 import numpy as np
@@ -259,7 +260,7 @@ def test_reference_api_fixture_is_self_consistent():
             assert np.array_equal(G[pre + "fwd_" + n], G[pre + "bwd_" + n]), n
 
 
-def _integration_md_binding(num_channels):
+def _integration_md_binding(num_channels, namespace=False):
     """The `_C` class of INTEGRATION.md section B, extracted from the document and executed as written (library path and
     NUM_CHANNELS substituted)."""
     import re
@@ -273,7 +274,7 @@ def _integration_md_binding(num_channels):
     src = re.sub(r"NUM_CHANNELS = 17\b", f"NUM_CHANNELS = {num_channels}", src, count=1)
     ns = {}
     exec(compile(src, "INTEGRATION.md#B", "exec"), ns)
-    return ns["_C"]
+    return ns if namespace else ns["_C"]
 
 
 @pytest.mark.gpu
@@ -316,3 +317,54 @@ def test_integration_md_binding_reproduces_the_reference_run(device, key):
     pts = torch.tensor(G["mark_points"], device=device)
     vm, pm = torch.tensor(G["h36m_cam_world_view_transform"], device=device), torch.tensor(G["h36m_cam_full_proj_transform"], device=device)
     assert np.array_equal(stub.mark_visible(pts, vm, pm).cpu().numpy(), G["mark_visible"])
+
+
+@pytest.mark.gpu
+def test_integration_md_binding_carries_the_stress_scene(device):
+    """P > 256 through the reference's call shape (rasterize_points.h:18-71): the INTEGRATION.md binding owns the binning arena
+    like the reference owns its binningBuffer (rasterize_points.cu:80-85), reads num_rendered back like rasterizer_impl.cu:283-288
+    and grows an arena that was too small.  One 2048 x 2048 view of BASELINE's stress scene (P = 4 352): num_rendered equals the
+    oracle's pair count, images and gradients equal the repository's own surface bit for bit -- from a first arena of 64 pairs."""
+    from skelsplat_amd.scene import stress_scene
+    from skelsplat_amd import rasterizer as R
+    from oracle import oracle as orc
+    ns = _integration_md_binding(17, namespace=True)
+    stub = ns["_C"]
+    W = H = 2048
+    sc, g = stress_scene(1, W=W, H=H)
+    cam = sc.cameras[0].to(device)
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    means, feat, opac, scales, quats = (tt(g[k]) for k in ("means", "feat", "opac", "scales", "quats"))
+    P = means.shape[0]
+    assert P == 4352
+    tfx, tfy = math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5)
+    ocam = orc.Cam(W, H, tfx, tfy, cam.world_view_transform.cpu().numpy(), cam.full_proj_transform.cpu().numpy())
+    want_R = int(orc.preprocess(g["means"], g["opac"], g["scales"], g["quats"], None, ocam)["tiles_touched"].astype(np.int64).sum())
+    ns["_ARENA"][(P, W, H)] = 64                      # far too small: the binding must grow it and render again
+    empty = torch.Tensor([])
+    bg = torch.zeros(3, device=device)
+    sh = feat.reshape(P, 1, 17)
+    fwd = (bg, means, empty, opac, scales, quats, 1.0, empty, cam.world_view_transform, cam.full_proj_transform, tfx, tfy, H, W,
+           sh, 0, cam.camera_center, False, False, False)
+    num_rendered, color, radii, geom, binning, img, invd = stub.rasterize_gaussians(*fwd)
+    assert num_rendered == want_R and ns["_ARENA"][(P, W, H)] >= want_R
+    views = R.ViewBatch.from_cameras([cam])
+    col, inv, rad, st = R.forward_views(views, means, feat, opac, scales, quats, None)
+    assert torch.equal(color, col[0]) and torch.equal(invd, inv[0]) and torch.equal(radii, rad[0])
+    gen = torch.Generator(device=device).manual_seed(3)
+    dL = torch.randn((17, H, W), device=device, generator=gen)
+    dLi = torch.randn((1, H, W), device=device, generator=gen)
+    out = stub.rasterize_gaussians_backward(bg, means, radii, empty, opac, scales, quats, 1.0, empty, cam.world_view_transform,
+                                            cam.full_proj_transform, tfx, tfy, dL, dLi, sh, 0, cam.camera_center, geom, num_rendered,
+                                            binning, img, False, False)
+    gr = R.backward_views(st, means, feat, opac, scales, quats, None, dL[None], dLi[None], want_dfeatures=True)
+    order = ("means2D", "features", "opacities", "means3D", "cov3D", None, "scales", "rotations")
+    for name, got in zip(order, out):
+        if name is not None and name != "features":
+            assert torch.equal(got, gr[name][0]), name
+    # (dL/dfeatures is accumulated with float atomics on the binned path: same sum, any order)
+    util.assert_close("dL_dcolors", out[1].cpu().numpy(), gr["features"][0].cpu().numpy(), rtol=1e-4, atol_scale=1e-5)
+    assert torch.isfinite(out[3]).all() and float(out[3].abs().max()) > 0
+    # a second call of the shape finds the grown arena: one forward, no retry
+    n2, color2, *_ = stub.rasterize_gaussians(*fwd)
+    assert n2 == want_R and torch.equal(color2, color)

@@ -1,0 +1,55 @@
+"""bench.py end to end on the GPU box (child processes): the contract line at N = 1 and the sharded step of `--gpus N` -- the path
+the driver's multi-GPU run takes -- at world 1 over RCCL and at world 2 on one device over gloo."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(cmd, env=None, timeout=900):
+    e = dict(os.environ)
+    e.update(env or {})
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines          # ONE JSON line on stdout
+    return json.loads(lines[0])
+
+
+def test_headline_line_has_the_contract_fields(device):
+    r = _run([sys.executable, "bench.py", "--steps", "12", "--warmup", "3", "--no-extras", "--no-cpu-baseline"])
+    assert r["n_gpus"] == 1 and r["steps"] == 12 and r["warmup"] == 3 and r["unit"] == "views/s" and r["dtype"] == "f32"
+    assert r["config"]["workload"] == "h36m_4view_1000x1000_P17_C17"
+    assert abs(r["value"] - 4 / r["ms_per_step"] * 1e3) < 1e-6 * r["value"]
+    roof = r["roofline"]
+    assert roof["bound"] == "hbm" and roof["launches_timed"] >= 32 and 0.3 < roof["frac"] < 1.0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    assert roof["avg_launch_us"] * 1e-3 <= r["two_call_step"]["ms_per_step"]        # the dominant kernel fits inside its step
+    assert r["ms_per_step"] <= 1.05 * r["two_call_step"]["ms_per_step"]              # one call is never the slower form
+
+
+def test_sharded_step_at_world_1_over_rccl(device):
+    """The `--gpus N` code path (views sharded, the backward and the collective on the second stream) with one rank."""
+    r = _run([sys.executable, "bench.py", "--gpus", "1", "--steps", "6", "--warmup", "2", "--no-extras", "--no-cpu-baseline"],
+             env={"SKS_BENCH_FORCE_DIST": "1", "MASTER_PORT": "29577"})
+    assert r["n_gpus"] == 1 and r["config"]["views_total"] == 31 and r["config"]["views_on_rank0"] == 31
+    assert r["config"]["exchange"] in ("all_gather", "all_reduce") and "RCCL" in r["config"]["parallelism"]
+    assert r["value"] > 0 and r["roofline"]["frac"] > 0.3
+    # at world 1 the sharded step does what the one-GPU reference does plus one collective: within a few percent of it
+    assert 0.7 < r["speedup_vs_one_gpu_same_workload"] < 1.3
+
+
+def test_sharded_step_at_world_2_on_one_device(device):
+    """Two ranks on GPU 0 over gloo (RCCL refuses two ranks on one device): the sharding logic at world > 1 -- 16 + 15 views, pad
+    rows, rank-major mean -- with the hidden exchange; timings mean nothing."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29578", "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "1", "--no-extras", "--no-cpu-baseline"]
+    r = _run(cmd, env={"SKS_BENCH_ONE_DEVICE": "1"})
+    assert r["n_gpus"] == 2 and r["config"]["views_on_rank0"] == 16 and r["strong_scaling"]["ideal_speedup"] == 31 / 16
+    assert "gloo" in r["config"]["parallelism"] and r["value"] > 0
