@@ -170,6 +170,23 @@ class ApiStep:
         color, inv, radii, st = R.forward_views(self.views, *self.params, None, workspace=self.ws)
         return R.backward_views(st, *self.params, None, self.dL, workspace=self.ws, **kw)
 
+    def autotune(self):
+        """The forward's fill-block size for THIS step on THIS box (rasterizer.autotune_fill_passes); ~120 untimed steps.  Sharded:
+        every rank issues the same number of steps whatever it tunes, so the collectives stay matched."""
+        if os.environ.get("SKS_BENCH_AUTOTUNE", "1") == "0":
+            return None
+        cands, reps, rounds = (0, 3, 4, 5), 16, 3
+        self()          # (the first call records the argument lists the tuner times)
+        self()
+        if self.views is None or self.ws._plans.get("fwd") is None:
+            for _ in range(len(cands) * rounds * (2 + reps)):
+                self()
+            return None
+        best, med = self.R.autotune_fill_passes(self.ws, self, cands, reps, rounds)
+        self.tuned = {"fill_passes_per_block": best or "default (2)", "median_us_by_candidate": {str(k): round(v, 2) for k, v in med.items()}}
+        return self.tuned
+
+    tuned = None
     wire_us = 0.0       # rank_step_8gpu only: a one-wavefront idle kernel of this length in front of the collective stands in for
                         # the xGMI hop a communicator of ONE rank does not make (sks_prof_spin)
     no_collective = False   # rank_step_8gpu only: the step without its exchange (forward + backward into the shard)
@@ -330,6 +347,7 @@ def run_single(args, torch, dev, wl):
     step = ApiStep(views, params, dL)                      # forward + backward as ONE C-ABI call (sks_forward_backward)
     step2 = ApiStep(views, params, dL, one_call=False)     # ... and as the two calls, for the roofline's kernel and for comparison
     prof = not args.no_prof
+    step.autotune(), step2.autotune()                      # (untimed: fill-block size for each form of the step on this box)
     for _ in range(args.warmup):
         step()
     for _ in range(max(3, args.warmup // 4)):
@@ -375,8 +393,9 @@ def run_single(args, torch, dev, wl):
                            "call -- the backward reads the forward's geometry records, not its image, and runs on a second stream "
                            "beside the dense forward; eager launches, outputs in a reused workspace"},
         # the same step as the two separate calls (sks_forward, then sks_backward on the same stream), K steps timed the same way
-        "two_call_step": {"ms_per_step": 1e3 * dt2 / args.steps, "views_per_s": V * args.steps / dt2},
+        "two_call_step": {"ms_per_step": 1e3 * dt2 / args.steps, "views_per_s": V * args.steps / dt2, "autotuned": step2.tuned},
     }
+    res["config"]["autotuned"] = step.tuned
     if pf and pf[1]:
         res["roofline"] = roofline_entry(4.0 * H * W * (C + 1) * V, pf, wl["name"], args.steps)
         res["roofline"]["timed_in"] = "the two-call form of the step, same run (see two_call_step)"
@@ -609,6 +628,7 @@ def extra_panoptic(args, torch, dev, sync):
     dL = torch.randn((V, C, H, W), device=dev)
     step = ApiStep(views, params, dL)                # one call (the backward beside the forward)
     step2 = ApiStep(views, params, dL, one_call=False)
+    step.autotune(), step2.autotune()
     n = max(10, args.steps // 10)
     dt, _ = timed(step, n, 3, sync)                 # the step itself: no event brackets inside the timed region
     dt2, _ = timed(step2, n, 3, sync)
@@ -618,7 +638,8 @@ def extra_panoptic(args, torch, dev, sync):
     pf, pb = _lib.prof_read_quantiles(0), _lib.prof_read_quantiles(1)
     _lib.prof_enable(False)
     out = {"workload": wl["name"], "ms_per_step": 1e3 * dt / n, "views_per_s": V * n / dt,
-           "two_call_step": {"ms_per_step": 1e3 * dt2 / n, "views_per_s": V * n / dt2}}
+           "two_call_step": {"ms_per_step": 1e3 * dt2 / n, "views_per_s": V * n / dt2, "autotuned": step2.tuned},
+           "autotuned": step.tuned}
     if pf[1]:
         alg = 4.0 * H * W * (C + 1) * V
         out["fwd_kernel_us"] = pf[0] * 1e3 / pf[1]
@@ -747,16 +768,20 @@ def extra_rank_step(args, torch, dev, sync):
         dL = torch.randn((len(local), C, H, W), device=dev)
         dL_all = torch.randn((V, C, H, W), device=dev)
         views_all = R.ViewBatch.from_cameras(scene.cameras)
-        variants = {}
+        variants, tuned = {}, {}
         for form, oc in (("two_calls", False), ("one_call", True)):
             st = ApiStep(views, params, dL, V_total=V, exchange=(world, 0, None), one_call=oc)
             st.allg_dst = st.allg[:vmax]
+            st.autotune()
+            tuned[form] = {"rank_step": st.tuned}
             for us in (None, 0, 10, 20, 30):
                 def fn(st=st, us=us):
                     st.no_collective, st.wire_us = us is None, float(us or 0)
                     return st()
                 variants[(form, "no_exchange" if us is None else f"exchange_{us}us")] = fn
             full = ApiStep(views_all, params, dL_all, one_call=oc)
+            full.autotune()
+            tuned[form]["one_gpu_31views"] = full.tuned
             variants[(form, "one_gpu_31views")] = full
         inner = {k: (4 if k[1] == "one_gpu_31views" else 16) for k in variants}
         for k, fn in variants.items():      # allocations, recorded calls, the communicator
@@ -779,9 +804,11 @@ def extra_rank_step(args, torch, dev, sync):
                "gather": "torch.distributed all_gather_into_tensor on a 1-rank RCCL communicator + sks_mean_views",
                "wire": "exchange_Nus = an idle one-wavefront kernel of N us in front of the collective (sks_prof_spin): the xGMI hop "
                        "a one-rank communicator does not make"}
+        # the speed-ups are against the FASTER of the two forms of the one-GPU step, whichever form the rank step takes
+        base = min(q(samples[(form, "one_gpu_31views")], 0.5) for form in ("two_calls", "one_call"))
+        out["one_gpu_31views_ms"] = round(base, 5)
         for form in ("two_calls", "one_call"):
-            base = q(samples[(form, "one_gpu_31views")], 0.5)
-            blk = {"one_gpu_31views_ms": round(base, 5)}
+            blk = {"one_gpu_31views_ms_this_form": round(q(samples[(form, "one_gpu_31views")], 0.5), 5)}
             for (f2, name), xs in samples.items():
                 if f2 != form or name == "one_gpu_31views":
                     continue
@@ -789,6 +816,7 @@ def extra_rank_step(args, torch, dev, sync):
                 blk[name] = {"rank_step_ms": round(med, 5), "p10_p90_ms": [round(q(xs, 0.1), 5), round(q(xs, 0.9), 5)],
                              "predicted_8gpu_speedup": round(base / med, 3)}
             # self-consistency of the table: the step without its exchange is never slower than with it (0.5 % of timer noise)
+            blk["autotuned"] = tuned[form]
             blk["consistent"] = bool(blk["no_exchange"]["rank_step_ms"] <= 1.005 * blk["exchange_0us"]["rank_step_ms"]
                                      and blk["exchange_0us"]["rank_step_ms"] <= 1.005 * blk["exchange_30us"]["rank_step_ms"])
             out[form] = blk
@@ -833,6 +861,7 @@ def run_sharded(args, torch, dist, dev, wl, world, rank):
     # (A) one GPU alone: every rank runs the whole 31-view step side by side, no communication.  Its time is the N = 1
     #     reference of this run; N x 31 views / that time is the weak-scaling aggregate.
     full = ApiStep(R.ViewBatch.from_cameras(scene.cameras), params, dL_all)
+    full.autotune()
     dt_full, _ = timed(full, n_ref, 3, sync)
     dt_full = max_over_ranks(dt_full)
     one_gpu_ms = 1e3 * dt_full / n_ref
@@ -846,6 +875,7 @@ def run_sharded(args, torch, dist, dev, wl, world, rank):
     step = ApiStep(lviews, params, dL, V_total=V, exchange=(world, rank, None))
     step()                      # (allocations, the first launches)
     exchange_mode = step.choose_mode()
+    step.autotune()             # (every rank the same number of steps: the collectives stay matched)
     for _ in range(args.warmup):
         step()
     sync()

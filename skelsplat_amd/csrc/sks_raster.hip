@@ -221,7 +221,8 @@ __global__ void k_spin_us(unsigned long long ticks)
 // sks_forward_backward: the backward's launches go to a second stream between the geometry kernel and the dense forward (see the
 // entry point).  sks_forward finds this record (per host thread) and calls it right behind k_geom_fwd.
 struct FusedBackward {
-    int (*run)(void* ctx);
+    int (*begin)(void* ctx);    // the second stream waits for the geometry kernel
+    int (*run)(void* ctx);      // the backward's launches on the second stream (+ the event the caller's stream joins on)
     void* ctx;
     hipEvent_t geom_done;   // rides on k_geom_fwd's own dispatch (hipExtLaunchKernelGGL): no marker packet in the caller's queue
 };
@@ -308,9 +309,11 @@ int sks_forward(int V, int P, int C, int W, int H, const float* viewmatrix, cons
                        small ? (uint32_t*)nullptr : b.count, small ? (uint32_t*)nullptr : b.touched, features, C,
                        small ? (uint2*)nullptr : b.fmask, small ? (uint32_t*)nullptr : b.hdr, (small && cover_per_plane(P, W, H, C)) ? 1 : 0);
     STAGE_CHECK("geometry");
+    FusedBackward* fb = nullptr;
     if (tl_fused_bwd && small) {   // (sks_forward_backward: the backward behind the geometry, on its own stream)
-        FusedBackward* fb = tl_fused_bwd;
+        fb = tl_fused_bwd;
         tl_fused_bwd = nullptr;
+        if (int rc = fb->begin(fb->ctx)) return rc;
         if (int rc = fb->run(fb->ctx)) return rc;
     }
 
@@ -478,13 +481,19 @@ int sks_forward_backward(int V, int P, int C, int W, int H, const float* viewmat
         HIP_TRY(hipEventCreateWithFlags(&ev.done, evf));
     }
     struct Run {
-        static int go(void* p)
+        static int begin(void* p)
         {
             const Ctx& k = *(const Ctx*)p;
             FbEvents& e = tl_fb_events;
             // e.geom: behind k_geom_fwd, i.e. behind everything the caller enqueued
             if (!k.ext) HIP_TRY(hipEventRecord(e.geom, k.s));   // (else it rode on k_geom_fwd's dispatch)
             HIP_TRY(hipStreamWaitEvent(k.aux, e.geom, 0));
+            return 0;
+        }
+        static int go(void* p)
+        {
+            const Ctx& k = *(const Ctx*)p;
+            FbEvents& e = tl_fb_events;
             const int rc = sks_backward(k.V, k.P, k.C, k.W, k.H, k.vm, k.pm, k.tx, k.ty, k.bg, k.means, k.feat, k.opac, k.scales, k.rots,
                                         k.cov, k.smod, k.flags, k.radii, k.geom, nullptr, 0, k.dL, k.dLinv, k.accum, k.m3, k.m2, k.op,
                                         k.sc, k.rot, k.dcov, k.dfeat, k.mean, k.aux);
@@ -493,7 +502,7 @@ int sks_forward_backward(int V, int P, int C, int W, int H, const float* viewmat
             return 0;
         }
     };
-    FusedBackward fb{ &Run::go, &c, c.ext ? ev.geom : nullptr };
+    FusedBackward fb{ &Run::begin, &Run::go, &c, c.ext ? ev.geom : nullptr };
     tl_fused_bwd = &fb;
     const int rc = sks_forward(V, P, C, W, H, viewmatrix, projmatrix, tanfovx, tanfovy, means3D, features, opacities, scales, rotations,
                                cov3D_precomp, scale_modifier, flags, out_color, out_invdepth, radii, geom, binning, bin_capacity,

@@ -622,6 +622,41 @@ def forward_backward_views(views: ViewBatch, means3D, features, opacities, scale
     return out + (g,)
 
 
+def autotune_fill_passes(workspace, step_fn, candidates=(0, 3, 4, 5), reps=8, rounds=3):
+    """Picks the forward's fill-block size (4 KB passes -- or rows, on row-aligned widths -- per fill block: bits 8..15 of the
+    flags, 0 = the library's default of two) for the step `step_fn` issues through `workspace`'s RECORDED forward, by timing it.
+    Why per step and at run time: the fill role is bound by the life time of its ~36 000 blocks, and what shares the chip with them
+    decides the best size -- two passes when the forward runs alone (sks_forward, then sks_backward), three for the H36M step
+    through sks_forward_backward (the backward's wavefronts hold slots beside it: 61.6 -> 57.8 us), four for all 31 Panoptic views,
+    five for four of them (NOTES_experiments.md, round 5); none of it moves a result bit.  `step_fn()` is called
+    len(candidates) x rounds x (2 + reps) times with device synchronisations in between (once, before a long loop); the
+    candidates are interleaved round-robin and judged by their median.  Returns (best, {candidate: median microseconds})."""
+    import time
+    plan = workspace._plans.get("fwd")
+    if plan is None or torch.cuda.is_current_stream_capturing():
+        return None, {}
+    args, dev_index = plan[2], plan[3]
+    base = args[16] & ~(0xff << 8)
+    times = {c: [] for c in candidates}
+    for _ in range(rounds):
+        for c in candidates:
+            args[16] = base | ((int(c) & 0xff) << 8)
+            for _ in range(2):
+                step_fn()
+            torch.cuda.synchronize(dev_index)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                step_fn()
+            torch.cuda.synchronize(dev_index)
+            times[c].append(1e6 * (time.perf_counter() - t0) / reps)
+    med = {c: sorted(v)[len(v) // 2] for c, v in times.items()}
+    best = min(med, key=med.get)
+    if med[best] > 0.99 * med[candidates[0]]:      # (within the noise of the first candidate: keep that one)
+        best = candidates[0]
+    args[16] = base | ((int(best) & 0xff) << 8)
+    return best, med
+
+
 def mean_views(grads, V, world=1, out=None):
     """Mean over the V views of (rows,P,3) joint gradients, summed in view order (train.py:215-217).  world > 1: `grads` is
     what all_gather_into_tensor left for a view-sharded group (world * ceil(V / world) rows, rank-major)."""
