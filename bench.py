@@ -257,6 +257,46 @@ def prof_stride(steps):
     return max(1, steps // samples)
 
 
+def measure_traffic(wl_key, kernel_prefix="k_render_fwd_sparse"):
+    """HBM bytes per launch of the forward kernel, MEASURED IN THIS RUN: two child processes under rocprofv3 (--pmc WRITE_SIZE, then
+    --pmc FETCH_SIZE: the two do not fit one pass; --kernel-trace only beside them), each running the two-call form of the step a
+    dozen times (tools/one_call_step.py).  Units and the gfx950 correction as MI355X_MICROARCH.md prescribes: both counters in KiB,
+    FETCH_SIZE doubled.  None when rocprofv3 is not on PATH or a pass fails (the caller then quotes profiles/traffic.json)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rp = shutil.which("rocprofv3")
+    if rp is None or os.environ.get("SKS_BENCH_TRAFFIC", "1") == "0":
+        return None
+    tmp = tempfile.mkdtemp(prefix="sks_traffic_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", WL=wl_key, ONE_CALL="0", STEPS="12")
+    vals = {}
+    try:
+        for counter in ("WRITE_SIZE", "FETCH_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [rp, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "p", "--",
+                   "python3", os.path.join(ROOT, "tools", "one_call_step.py")]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+            if r.returncode != 0:
+                return None
+            per = []
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row["Counter_Name"] == counter and kernel_prefix in row["Kernel_Name"]:
+                        per.append(float(row["Counter_Value"]))
+            if len(per) < 4:
+                return None
+            per = per[len(per) // 3:]          # (the first launches allocate and warm up)
+            vals[counter] = sum(per) / len(per)
+        return 1024.0 * (vals["WRITE_SIZE"] + 2.0 * vals["FETCH_SIZE"])
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def roofline_entry(alg_bytes, prof_fwd, wl_name, launches, kernel="k_render_fwd_sparse (forward fill + sparse compositor)",
                    traffic_scale=1.0):
     """`traffic_scale`: a sharded rank launches the kernel for its share of the workload's views; the PMC figure of the
@@ -399,6 +439,14 @@ def run_single(args, torch, dev, wl):
     if pf and pf[1]:
         res["roofline"] = roofline_entry(4.0 * H * W * (C + 1) * V, pf, wl["name"], args.steps)
         res["roofline"]["timed_in"] = "the two-call form of the step, same run (see two_call_step)"
+        if not args.no_extras:
+            tb = measure_traffic(wl["dataset"])
+            if tb:
+                res["roofline"]["traffic_file"] = res["roofline"]["traffic"]
+                res["roofline"]["traffic"] = tb
+                res["roofline"]["traffic_source"] = ("measured in this run: rocprofv3 --pmc WRITE_SIZE / --pmc FETCH_SIZE (separate child "
+                                                     "passes over tools/one_call_step.py, KiB units, FETCH_SIZE doubled for gfx950)")
+                res["roofline"]["traffic_over_algorithmic"] = tb / res["roofline"]["algorithmic_bytes_per_launch"]
         if zero_us:
             res["roofline"]["zero_fill_same_bytes_us"] = zero_us
             res["roofline"]["frac_of_zero_fill"] = zero_us / (1e3 * pf[2][1])     # (median launch against the median zero_())

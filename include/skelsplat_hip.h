@@ -302,6 +302,27 @@ int sks_loop_adam_step(int V, int P, const float* grads, float* slots, unsigned 
                        read in place -- the exchange step of the view-sharded loop needs no re-ordering pass */,
                        void* stream);
 
+/* sks_loop_adam_step with the reference's early-stopping criterion ON THE DEVICE (training.early_stopping = opt_early_stopping:
+ * utils/general_utils.py:467-491 fed at train.py:155, the break at train.py:182-233).  Before the step, one thread appends the
+ * losses of the group's iterations -- loss_v = S_v / max(N_v, 1) + lambda x limb loss, fp32, in iteration order -- to the history
+ * and tests the last `es_window` against the `es_window` before them (|difference| < es_tolerance, fp32).  When the criterion fires
+ * at the k-th iteration of the group, only the first k views refresh their slots, view k's scaling / rotation / opacity gradients
+ * win, the optimiser steps at once, `es_state[1]` (and *es_host_flag, pinned host memory, when given) receives that iteration --
+ * and every later launch of this entry point on the same state does nothing: a caller keeps enqueueing groups without ever
+ * reading a loss back and looks at the flag when it likes (no host synchronisation per group; the group is hipGraph-capturable).
+ * es_state: 2 + 2 * es_window ints, zero at the start of a scene ([0] losses seen, [1] stopping iteration or 0, then the ring).
+ * loss_sums: V x {S, N} doubles of the group's views (sks_masked_l2 / sks_backward_fused_loss).  shard_world = N > 1 and
+ * loss_sums == NULL: every rank's block of `grads` is sks_loop_shard_floats(V, P, N) floats -- its ceil(V / N) x P x 11 gradient
+ * rows (padded to an even count) followed by its views' {S, N} as doubles -- so gradients AND losses cross in the step's ONE
+ * all_gather and every rank takes the identical decision. */
+int sks_loop_adam_step_es(int V, int P, const float* grads, float* slots, unsigned long long group_mask, int last_view,
+                          float* xyz, float* scaling, float* rotation, float* opacity, float* exp_avg, float* exp_avg_sq,
+                          int* counters, int acc_steps, const double* lr_sched /*HOST 5*/, const double* lrs /*HOST 3*/,
+                          const double* adam /*HOST 3*/, float lambda_consistency, const int* limb /*HOST 8 or NULL*/,
+                          int shard_world, const double* loss_sums, int* es_state, int es_window, float es_tolerance,
+                          int* es_host_flag /*pinned HOST int or NULL*/, void* stream);
+size_t sks_loop_shard_floats(int V, int P, int shard_world);
+
 /* One accumulation group of the sparse loop on ONE GPU in two launches (train.py:130-222 for acc_steps views):
  * the fused-loss compositing backward (as sks_backward_fused_loss) and a single-workgroup tail that runs the geometry
  * backward of every view, the optimiser step (as sks_loop_adam_step) and the geometry forward of the UPDATED parameters.

@@ -71,6 +71,18 @@ __global__ __launch_bounds__(256) void k_loop_adam(AdamArgs a)
     __shared__ float s_hyp[6];
     __shared__ double s_d[4];
     __shared__ int s_it[2];
+    if (a.es_state) {   // device-side early stopping: the criterion decides what this step is -- or that there is none
+        __shared__ unsigned long long s_mask;
+        __shared__ int s_cut[3];
+        const int p = threadIdx.x;
+        if (p < a.P) { s_xyz[3 * p] = a.xyz[3 * p]; s_xyz[3 * p + 1] = a.xyz[3 * p + 1]; s_xyz[3 * p + 2] = a.xyz[3 * p + 2]; }
+        __syncthreads();
+        if (p == 0) sksloop::early_stop_decide(a, s_xyz, &s_mask, s_cut);
+        __syncthreads();
+        if (s_cut[2]) return;            // the scene stopped at an earlier launch: parameters, moments, counters stay
+        a.group_mask = s_mask; a.last_view = s_cut[0]; a.acc_steps = s_cut[1];
+        __syncthreads();
+    }
     sksloop::adam_block_begin(a, s_xyz, s_d, s_it);
     __syncthreads();
     sksloop::adam_block_finish(a, s_xyz, s_hyp, s_d, s_it);
@@ -111,6 +123,36 @@ int sks_loop_adam_step(int V, int P, const float* grads, float* slots, unsigned 
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail3((int)e, hipGetErrorString(e));
     return 0;
+}
+
+int sks_loop_adam_step_es(int V, int P, const float* grads, float* slots, unsigned long long group_mask, int last_view,
+                          float* xyz, float* scaling, float* rotation, float* opacity, float* exp_avg, float* exp_avg_sq,
+                          int* counters, int acc_steps, const double* lr_sched, const double* lrs, const double* adam,
+                          float lambda_consistency, const int* limb, int shard_world, const double* loss_sums, int* es_state,
+                          int es_window, float es_tolerance, int* es_host_flag, void* stream)
+{
+    if (V < 1 || V > SKS_MAX_VIEWS || P < 1 || P > SKS_SMALL_P) return fail3(-1, "loop_adam: V or P out of range");
+    if (!es_state) return fail3(-2, "loop_adam_es: es_state is required (sks_loop_adam_step is the step without a criterion)");
+    if (es_window < 1 || es_window > sksloop::ES_MAX_WINDOW) return fail3(-1, "loop_adam_es: window out of range [1, 16]");
+    if (shard_world == 1 && !loss_sums) return fail3(-2, "loop_adam_es: loss_sums is required on one rank");
+    AdamArgs a;
+    if (const char* err = sksloop::fill_adam_args(a, V, P, grads, slots, group_mask, last_view, xyz, scaling, rotation, opacity,
+                                                  exp_avg, exp_avg_sq, counters, acc_steps, lr_sched, lrs, adam,
+                                                  lambda_consistency, limb, shard_world))
+        return fail3(-2, err);
+    a.es_state = es_state; a.es_window = es_window; a.es_tol = es_tolerance; a.es_sums = loss_sums; a.es_host_flag = es_host_flag;
+    if (shard_world > 1 && !loss_sums) a.rank_stride = sksloop::es_tail_offset(a.vmax, P) + 4ll * a.vmax;
+    hipLaunchKernelGGL(k_loop_adam, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail3((int)e, hipGetErrorString(e));
+    return 0;
+}
+
+size_t sks_loop_shard_floats(int V, int P, int shard_world)
+{
+    if (V < 1 || P < 1 || shard_world < 1) return 0;
+    const int vmax = (V + shard_world - 1) / shard_world;
+    return (size_t)(sksloop::es_tail_offset(vmax, P) + 4ll * vmax);
 }
 
 }  // extern "C"

@@ -25,16 +25,85 @@ struct AdamArgs {
     int n_joints;              // joints per skeleton (limb indices address the first skeleton, like the reference)
     // layout of `grads`: world == 1: view-major (V,P,11).  world > 1: what all_gather_into_tensor leaves when view v is
     // rendered by rank v % world as that rank's local view v / world and every rank contributes vmax = ceil(V / world)
-    // rows: (world, vmax, P, 11), so the step reads the gathered buffer in place (no re-ordering pass in between)
+    // rows: (world, vmax, P, 11), so the step reads the gathered buffer in place (no re-ordering pass in between).
+    // rank_stride (floats) >= vmax * P * 11: a rank's block may carry a tail behind its rows -- the views' loss sums, so that
+    // the early-stopping criterion rides in the SAME collective as the gradients (train.py:155)
     int world, vmax;
+    long long rank_stride;
+    // device-side opt_early_stopping (utils/general_utils.py:467-491, train.py:155,182-233); es_state == nullptr: off
+    int* es_state;             // [0] losses seen so far, [1] iteration the scene stopped at (0 = running),
+                               // [2 .. 2 + 2 * es_window): the last 2 * window losses (float bits), a ring
+    int es_window;
+    float es_tol;
+    const double* es_sums;     // world == 1: (V,2) {S, N} of the views; world > 1: nullptr = the tail of each rank's block
+    int* es_host_flag;         // pinned host int or nullptr: receives the stopping iteration when the criterion fires
 };
 
-// row of view v's gradients in AdamArgs::grads
-__device__ __forceinline__ int grad_row(const AdamArgs& a, int v)
+// view v's (P,11) gradient rows in AdamArgs::grads
+__device__ __forceinline__ const float* grad_rows(const AdamArgs& a, int v)
 {
-    if (a.world == 1) return v;
+    if (a.world == 1) return a.grads + (size_t)v * a.P * 11;
     const int r = v % a.world;
-    return r * a.vmax + (v - r) / a.world;
+    return a.grads + (size_t)r * a.rank_stride + (size_t)((v - r) / a.world) * a.P * 11;
+}
+// where a rank's block keeps its views' loss sums (doubles: the rows padded to an even number of floats)
+__host__ __device__ inline long long es_tail_offset(int vmax, int P) { return ((long long)vmax * P * 11 + 1) & ~1ll; }
+__device__ __forceinline__ const double* loss_sums_of(const AdamArgs& a, int v)
+{
+    if (a.world == 1 || a.es_sums) return a.es_sums + 2 * (size_t)(a.world == 1 ? v : (v % a.world) * a.vmax + v / a.world);
+    const int r = v % a.world;
+    return reinterpret_cast<const double*>(a.grads + (size_t)r * a.rank_stride + es_tail_offset(a.vmax, a.P)) + 2 * ((v - r) / a.world);
+}
+
+// The reference's criterion, one thread, BEFORE the step: train.py:155 feeds OptEarlyStopping every iteration's loss
+// (masked L2 of that iteration's view + lambda x limb loss, an fp32 number) in order; it keeps the history and fires when the
+// last `window` losses repeat the `window` before them to within `tol` (general_utils.py:483-491, compared in fp32).  When it
+// fires at the k-th iteration of this group, only the first k views refresh their slots, view k's scaling / rotation / opacity
+// gradients win, the optimiser steps at once (train.py:182) and the scene has ended: every later launch of the step does
+// nothing.  out: cut[0] = last view, cut[1] = iterations of this step, cut[2] = 1 if the scene had stopped before.
+constexpr int ES_MAX_WINDOW = 16;
+__device__ inline void early_stop_decide(const AdamArgs& a, const float* s_xyz, unsigned long long* mask_out, int* cut)
+{
+    int* st = a.es_state;
+    cut[0] = a.last_view; cut[1] = a.acc_steps; cut[2] = 0;
+    *mask_out = a.group_mask;
+    if (st[1] != 0) { cut[2] = 1; return; }
+    float cons = 0.0f;
+    if (a.lambda_consistency != 0.0f && a.limb[0] >= 0) {
+        float len[4];
+        for (int k = 0; k < 4; k++) {
+            const int i0 = a.limb[2 * k], i1 = a.limb[2 * k + 1];
+            const float d0 = s_xyz[3 * i0] - s_xyz[3 * i1], d1 = s_xyz[3 * i0 + 1] - s_xyz[3 * i1 + 1], d2 = s_xyz[3 * i0 + 2] - s_xyz[3 * i1 + 2];
+            len[k] = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
+        }
+        cons = (fabsf(len[0] - len[1]) + fabsf(len[2] - len[3])) * a.lambda_consistency;
+    }
+    const int w = a.es_window, ring = 2 * w;
+    const int it0 = a.counters[0] + 1;
+    int n = st[0];
+    unsigned long long mask = 0ull;
+    for (int k = 0; k < a.acc_steps; k++) {
+        const int v = (it0 + k - 1) % a.V;
+        mask |= 1ull << v;
+        const double* sn = loss_sums_of(a, v);
+        const double cnt = sn[1] < 1.0 ? 1.0 : sn[1];
+        const float loss = (float)(sn[0] / cnt) + cons;
+        st[2 + n % ring] = __float_as_int(loss);
+        n++;
+        bool fire = n >= ring;
+        for (int i = 0; fire && i < w; i++) {
+            const float h1 = __int_as_float(st[2 + (n - ring + i) % ring]), h2 = __int_as_float(st[2 + (n - w + i) % ring]);
+            fire = fabsf(h1 - h2) < a.es_tol;
+        }
+        if (fire) {
+            st[1] = it0 + k;
+            if (a.es_host_flag) *a.es_host_flag = it0 + k;
+            cut[0] = v; cut[1] = k + 1;
+            *mask_out = mask;
+            break;
+        }
+    }
+    st[0] = n;
 }
 
 // torch.optim.Adam single-tensor path (python scalars are doubles, tensor math is fp32):
@@ -170,7 +239,7 @@ __device__ __forceinline__ void adam_block_finish(const AdamArgs& a, float* s_xy
             float* sl = a.slots + (size_t)i * 3;
             float val[3];
             if ((a.group_mask >> v) & 1ull) {
-                const float* gr = a.grads + ((size_t)grad_row(a, v) * P + pp) * 11;
+                const float* gr = grad_rows(a, v) + (size_t)pp * 11;
 #pragma unroll
                 for (int c = 0; c < 3; c++) { val[c] = gr[c] + s_gc[3 * pp + c]; sl[c] = val[c]; }
             } else {
@@ -191,7 +260,7 @@ __device__ __forceinline__ void adam_block_finish(const AdamArgs& a, float* s_xy
             }
             float* sl = a.slots + ((size_t)v * P + p) * 3;
             if ((a.group_mask >> v) & 1ull) {
-                const float* gr = a.grads + ((size_t)grad_row(a, v) * P + p) * 11;
+                const float* gr = grad_rows(a, v) + (size_t)p * 11;
 #pragma unroll
                 for (int c = 0; c < 3; c++) sl[c] = gr[c] + gc[c];
             }
@@ -200,7 +269,7 @@ __device__ __forceinline__ void adam_block_finish(const AdamArgs& a, float* s_xy
         }
 #pragma unroll
         for (int c = 0; c < 3; c++) g11[c] /= (float)V;
-        const float* gl = a.grads + ((size_t)grad_row(a, a.last_view) * P + p) * 11;
+        const float* gl = grad_rows(a, a.last_view) + (size_t)p * 11;
 #pragma unroll
         for (int c = 3; c < 11; c++) g11[c] = gl[c];
 #pragma unroll
@@ -247,6 +316,8 @@ inline const char* fill_adam_args(AdamArgs& a, int V, int P, const float* grads,
     if (shard_world < 1) return "loop_adam: shard_world must be >= 1";
     a.world = shard_world;
     a.vmax = (V + shard_world - 1) / shard_world;
+    a.rank_stride = (long long)a.vmax * P * 11;
+    a.es_state = nullptr; a.es_window = 0; a.es_tol = 0.0f; a.es_sums = nullptr; a.es_host_flag = nullptr;
     if (!grads || !slots || !xyz || !scaling || !rotation || !opacity || !exp_avg || !exp_avg_sq || !counters || !lr_sched || !lrs || !adam)
         return "loop_adam: missing pointer";
     if (last_view < 0 || last_view >= V) return "loop_adam: last_view out of range";

@@ -99,9 +99,12 @@ class MultiViewLoop:
     (ops.masked_l2_grad_fused); loop.masked_l2_grad_torch is the same thing in tensor ops.
     `shard_views=False`: this process runs all V views itself even when torch.distributed is initialised (frame
     sharding: every rank optimises its own frames, no communication at all -- SURVEY §8e axis 2).
-    `early_stopping`: a key of `early_stopping_strategy` (configs/*.yaml `training.early_stopping`) or a callable
-    loss -> bool; anything but "no_stopping" makes the host read the group's losses (one sync per group), so it
-    excludes use_graph."""
+    `early_stopping`: a key of `early_stopping_strategy` (configs/*.yaml `training.early_stopping`), an OptEarlyStopping
+    instance, or a callable loss -> bool.  The reference's criterion (OptEarlyStopping, window <= 16) runs ON THE DEVICE, inside
+    the optimiser kernel (sks_loop_adam_step_es): no loss is read back, the group stays a fixed launch sequence (use_graph works,
+    view-sharded ranks decide identically from the gathered sums -- they ride in the step's one all_gather), and the host learns
+    the stopping iteration from a pinned flag it polls without waiting (run() synchronises once, at its end).  Any other
+    callable is a host decision: one read-back per group, no use_graph."""
 
     def __init__(self, gaussians, cameras, heatmaps, dataset="h36m", accumulation_steps=4, lambda_consistency=1e-5,
                  bg=None, antialiasing=False, loss_grad=None, group=None, view_grad_fn=None, device_tail=None,
@@ -179,8 +182,12 @@ class MultiViewLoop:
         else:
             self.early_stopping = early_stopping_strategy[early_stopping]()
         self._stopping = not isinstance(self.early_stopping, NotStopping)
-        if self._stopping and use_graph:
-            raise ValueError("early stopping reads every iteration's loss on the host (train.py:155): use_graph must be False")
+        # the reference's criterion on the device (sks_loop_adam_step_es); anything else is a host decision per group
+        self._es_device = (self._stopping and type(self.early_stopping) is OptEarlyStopping and self.device_tail
+                           and 1 <= self.early_stopping.window_size <= 16 and not self.early_stopping.loss_history)
+        if self._stopping and not self._es_device and use_graph:
+            raise ValueError("a custom early-stopping callable reads every iteration's loss on the host (train.py:155): "
+                             "use_graph must be False")
         # hipGraph capture of a group that contains the RCCL all_gather: opt-in (graph_collectives=True or
         # SKS_GRAPH_COLLECTIVES=1); the sequence itself is fixed and allocation-free either way
         if graph_collectives is None:
@@ -222,16 +229,34 @@ class MultiViewLoop:
             # persistent buffers of the group (allocated here, never inside a graph capture): this rank's packed
             # raw-parameter gradients -- with the exchange padded to vmax rows, the pad rows stay zero for ever -- and what
             # all_gather_into_tensor leaves, which sks_loop_adam_step reads in place (rank-major layout, `shard_world`)
-            self._shard = torch.zeros((self.vmax if self.exchange else max(Vl, 1), P, 11), device=dev)
-            self._allg = torch.empty((self.world * self.vmax, P, 11), device=dev) if self.exchange else None
-            self._sums = torch.zeros((max(Vl, 1), 2), dtype=torch.float64, device=dev)
+            self._es_state = self._es_flag = None
+            if self._es_device:
+                w = self.early_stopping.window_size
+                self._es_state = torch.zeros(2 + 2 * w, dtype=torch.int32, device=dev)
+                self._es_flag = torch.zeros(1, dtype=torch.int32).pin_memory()
+                self._es_flag_np = self._es_flag.numpy()
+            if self.exchange and self._es_device:
+                # a rank's block = its vmax x P x 11 gradient rows (padded to an even float count) + its views' {S, N} doubles:
+                # gradients and losses cross in ONE all_gather, every rank runs the same criterion (sks_loop_shard_floats)
+                from . import _lib
+                nfl = int(_lib.load().sks_loop_shard_floats(self.V, P, self.world))
+                tail = nfl - 4 * self.vmax
+                self._shard_flat = torch.zeros(nfl, device=dev)
+                self._shard = self._shard_flat[:self.vmax * P * 11].view(self.vmax, P, 11)
+                self._sums = self._shard_flat[tail:].view(torch.float64).view(self.vmax, 2)
+                self._allg = torch.empty(self.world * nfl, device=dev)
+            else:
+                self._shard_flat = None
+                self._shard = torch.zeros((self.vmax if self.exchange else max(Vl, 1), P, 11), device=dev)
+                self._allg = torch.empty((self.world * self.vmax, P, 11), device=dev) if self.exchange else None
+                self._sums = torch.zeros((max(Vl, 1), 2), dtype=torch.float64, device=dev)
             self._sums_all = (torch.zeros((self.world * self.vmax, 2), dtype=torch.float64, device=dev)
-                              if self.exchange and self._stopping else None)
+                              if self.exchange and self._stopping and not self._es_device else None)
             self._direct = None
             if self.exchange:
                 # RCCL builds its communicator on the first collective: do that here, eagerly, never inside a graph
                 # capture or a timed step (the gathered rows are overwritten by every group)
-                dist.all_gather_into_tensor(self._allg, self._shard, group=self.group)
+                dist.all_gather_into_tensor(self._allg, self._shard if self._shard_flat is None else self._shard_flat, group=self.group)
                 # ... and, when asked for (SKS_RCCL_DIRECT=1), a communicator of our own, so that the group's one all_gather is
                 # enqueued on the stream its neighbours run on (torch's process group runs it on an internal stream: two event
                 # hand-overs, ~7 us of the GPU timeline per step at world 1); None by default and when the backend is not RCCL
@@ -312,7 +337,11 @@ class MultiViewLoop:
                     R.gt_tile_stats(gt, out=stats)
             if self.sparse and len(self.size_groups) > 1:
                 self._merge_totals()
-        if isinstance(self.early_stopping, (OptEarlyStopping, NotStopping)):
+        if self.device_tail and self._es_device:
+            torch.cuda.current_stream(self.device).synchronize()    # (nothing of the last scene may still write the flag)
+            self._es_state.zero_()
+            self._es_flag_np[0] = 0
+        elif isinstance(self.early_stopping, (OptEarlyStopping, NotStopping)):
             self.early_stopping = type(self.early_stopping)()
         self.stopped_at = None
         self._geom_valid = False
@@ -398,13 +427,25 @@ class MultiViewLoop:
         if self.exchange:
             # every rank needs every view's gradients (train.py:175, 215-218): ONE all_gather of the padded shards over
             # RCCL; the optimiser kernel reads the gathered buffer in place (view v = row (v % world) * vmax + v // world)
+            src = self._shard if self._shard_flat is None else self._shard_flat
             if self._direct is not None:
-                self._direct.all_gather_into_tensor(self._allg, self._shard)     # RCCL on THIS stream (rccl_direct.py)
+                self._direct.all_gather_into_tensor(self._allg, src)     # RCCL on THIS stream (rccl_direct.py)
             else:
-                dist.all_gather_into_tensor(self._allg, self._shard, group=self.group)
+                dist.all_gather_into_tensor(self._allg, src, group=self.group)
             full, world = self._allg, self.world
         else:
             full, world = self._shard, 1
+        if self._es_device:
+            es = self.early_stopping
+            _lib.check(lib.sks_loop_adam_step_es(self.V, self.P, full.data_ptr(), self.accumulated_grads.data_ptr(), group_mask,
+                                                 last_view, gm._xyz.data_ptr(), gm._scaling.data_ptr(), gm._rotation.data_ptr(),
+                                                 gm._opacity.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                                                 self.counters.data_ptr(), n_iters, self._sched, self._lrs, self._adam,
+                                                 float(self.lambda_consistency), self._limb, world,
+                                                 None if world > 1 else self._sums.data_ptr(), self._es_state.data_ptr(),
+                                                 int(es.window_size), float(es.repeat_tolerance), self._es_flag.data_ptr(), stream),
+                       "sks_loop_adam_step_es")
+            return
         _lib.check(lib.sks_loop_adam_step(self.V, self.P, full.data_ptr(), self.accumulated_grads.data_ptr(), group_mask,
                                           last_view, gm._xyz.data_ptr(), gm._scaling.data_ptr(), gm._rotation.data_ptr(),
                                           gm._opacity.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
@@ -433,9 +474,20 @@ class MultiViewLoop:
                 self._device_grads()
                 Vl = len(self.local_ids)
                 self.last_losses = (self._sums[:Vl, 0], self._sums[:Vl, 1])
-            if self._stopping:
+            if self._stopping and not self._es_device:
                 group_mask, last_view, n_iters = self._early_stop_cut(group_mask, last_view, n_iters)
             self._device_adam(group_mask, last_view, n_iters)
+
+    def _poll_stop(self, wait=False):
+        """Device-side criterion: has it fired?  The kernel stores the stopping iteration into pinned host memory; `wait`
+        first lets the stream drain (run() does, once, when it has enqueued everything it was asked for)."""
+        if wait:
+            torch.cuda.current_stream(self.device).synchronize()
+        it = int(self._es_flag_np[0])
+        if it:
+            self.stopped_at = it
+            self.iteration = it
+        return self.stopped_at
 
     def _early_stop_cut(self, group_mask, last_view, n_iters):
         """train.py:155-233 with the group's views batched: feed the criterion the losses of the group's iterations in
@@ -491,6 +543,8 @@ class MultiViewLoop:
             else:
                 self._geom_valid = False    # eager steps never assume the parameters were left untouched since the last one
                 self._device_group(*key)
+            if self._es_device:
+                self._poll_stop()           # (never waits: the groups enqueued behind a stop do nothing to the parameters)
             self.iteration = it1 if self.stopped_at is None else self.stopped_at
             return self.iteration
         if not self.local_ids:
@@ -554,12 +608,16 @@ class MultiViewLoop:
                         for _ in range(G):
                             self._device_group(*key)
                     self._multi = ((key, G), graph)
-                while remaining >= G:
+                while remaining >= G and self.stopped_at is None:
                     self._multi[1].replay()
                     self.iteration += G * self.acc_steps
                     remaining -= G
+                    if self._es_device:
+                        self._poll_stop()
         while self.iteration < iterations and self.stopped_at is None:
             self.step_group()
+        if self.device_tail and self._es_device and self.stopped_at is None:
+            self._poll_stop(wait=True)      # the ONE synchronisation of a scene with the criterion on the device
         return self.gm._xyz.detach()
 
 

@@ -789,6 +789,78 @@ def test_adam_step_reads_the_gathered_rank_major_layout(device):
         assert not torch.equal(ref[0], init[0])
 
 
+def test_adam_step_with_the_criterion_reads_the_sums_from_the_gathered_blocks(device):
+    """sks_loop_adam_step_es(shard_world = N, loss_sums = NULL): every rank's block of the gathered buffer is its gradient rows
+    (padded to an even float count) followed by its views' {S, N} doubles (sks_loop_shard_floats) -- the criterion's inputs cross in
+    the gradients' all_gather.  Against the one-rank call (view-major rows, separate sums), for uneven shards: the same stopping
+    iteration, cut inside a group, and bit for bit the same state; after the stop further launches change nothing."""
+    import ctypes
+    from skelsplat_amd import _lib
+    lib = _lib.load()
+    stream = torch.cuda.current_stream(device).cuda_stream
+    g = torch.Generator(device=device).manual_seed(5)
+    sched = (ctypes.c_double * 5)(2e-3, 2e-4, 0.0, 0.0, 4000.0)    # (small steps: the limb term of the loss barely moves)
+    lrs = (ctypes.c_double * 3)(0.005, 0.001, 0.05)
+    adam = (ctypes.c_double * 3)(0.9, 0.999, 1e-15)
+    limb = (ctypes.c_int * 8)(12, 13, 15, 16, 5, 6, 2, 3)
+    V, P, acc, w, tol = 7, 17, 5, 3, 5e-4
+    groups = 9
+    grads = torch.randn((groups, V, P, 11), device=device, generator=g) * 1e-3
+    # losses that settle: S / N converges geometrically, so the window test fires a few groups in, in the middle of a group
+    N = torch.full((groups, V), 1000.0, dtype=torch.float64, device=device)
+    it = torch.arange(groups * V, device=device, dtype=torch.float64).reshape(groups, V)
+    S = N * (0.5 + 0.3 * torch.exp(-it / 2.5))
+    init = [torch.randn(s_, device=device, generator=g) for s_ in ((P, 3), (P, 3), (P, 4), (P, 1))]
+
+    def run(world):
+        prm = [x.clone() for x in init]
+        slots = torch.zeros((V, P, 3), device=device)
+        m, vv = torch.zeros((P, 11), device=device), torch.zeros((P, 11), device=device)
+        cnt = torch.zeros(2, dtype=torch.int32, device=device)
+        es = torch.zeros(2 + 2 * w, dtype=torch.int32, device=device)
+        flag = torch.zeros(1, dtype=torch.int32).pin_memory()
+        vmax = (V + world - 1) // world
+        nfl = int(lib.sks_loop_shard_floats(V, P, world))
+        assert nfl % 2 == 0 and nfl >= vmax * P * 11 + 4 * vmax
+        snap = None
+        for k in range(groups):
+            it0 = k * acc + 1
+            views = [(it0 + j - 1) % V for j in range(acc)]
+            mask = 0
+            for v in views:
+                mask |= 1 << v
+            sums = torch.stack([S[k], N[k]], dim=1).contiguous()          # (V, 2): this group's sums, by view
+            if world == 1:
+                buf, sp = grads[k].contiguous(), sums.data_ptr()
+            else:
+                buf = torch.full((world * nfl,), float("nan"), device=device)
+                for v in range(V):
+                    r, l = v % world, v // world
+                    buf[r * nfl + l * P * 11:r * nfl + (l + 1) * P * 11] = grads[k, v].reshape(-1)
+                    buf[r * nfl + nfl - 4 * vmax:r * nfl + nfl].view(torch.float64).view(vmax, 2)[l] = sums[v]
+                sp = None
+            _lib.check(lib.sks_loop_adam_step_es(V, P, buf.data_ptr(), slots.data_ptr(), mask, views[-1], prm[0].data_ptr(),
+                                                 prm[1].data_ptr(), prm[2].data_ptr(), prm[3].data_ptr(), m.data_ptr(), vv.data_ptr(),
+                                                 cnt.data_ptr(), acc, sched, lrs, adam, 1e-3, limb, world, sp, es.data_ptr(), w, tol,
+                                                 flag.data_ptr(), stream), "sks_loop_adam_step_es")
+            torch.cuda.synchronize()
+            if int(flag[0]) and snap is None:
+                snap = [x.clone() for x in prm + [slots, m, vv, cnt]]
+        assert snap is not None, "the criterion never fired"
+        for a, b in zip(snap, prm + [slots, m, vv, cnt]):          # launches behind the stop did nothing
+            assert torch.equal(a, b)
+        assert int(es[1]) == int(flag[0]) == int(cnt[0])
+        return int(flag[0]), snap
+
+    stop1, ref = run(1)
+    assert stop1 % acc != 0 and 2 * w <= stop1 < groups * acc, stop1      # the cut falls inside a group
+    for world in (2, 3, 4, 8):
+        stop, got = run(world)
+        assert stop == stop1, (world, stop, stop1)
+        for a, b in zip(ref, got):
+            assert torch.equal(a, b), world
+
+
 def test_early_stopping_cuts_the_group_like_the_reference(device):
     """training.early_stopping = opt_early_stopping (train.py:155, 182-233): the criterion sees every iteration's loss in
     order; when it fires inside a group, only the views up to that iteration refresh their slots, that view's scaling /
@@ -805,8 +877,9 @@ def test_early_stopping_cuts_the_group_like_the_reference(device):
     tol = 8e-4        # with the reference's window of 4 (= the views) this fires at iteration 30 of this scene: mid-group
     loop = MultiViewLoop(gm, sc.cameras, hm, dataset="h36m", early_stopping=OptEarlyStopping(window_size=4, repeat_tolerance=tol))
     assert loop._stopping and not loop.fused_tail and not loop.use_graph
-    with pytest.raises(ValueError):
-        MultiViewLoop(gm, sc.cameras, hm, dataset="h36m", early_stopping="opt_early_stopping", use_graph=True)
+    assert loop._es_device                        # the reference's criterion runs inside the optimiser kernel
+    with pytest.raises(ValueError):               # ... any other callable is a host decision per group: no hipGraph
+        MultiViewLoop(gm, sc.cameras, hm, dataset="h36m", early_stopping=lambda loss: False, use_graph=True)
     loop.run(400)
     assert loop.stopped_at is not None and loop.iteration == loop.stopped_at < 400
     # literal loop
@@ -838,6 +911,47 @@ def test_early_stopping_cuts_the_group_like_the_reference(device):
     gm2 = model(device)
     MultiViewLoop(gm2, sc.cameras, hm, dataset="h36m").run(stopped + 2)
     assert (gm2._xyz.detach() - gm._xyz.detach()).norm(dim=1).max().item() > 1e-3
+
+
+@pytest.mark.parametrize("mode", ["eager", "hipgraph", "dense", "sharded-world1"])
+def test_device_side_early_stopping_decides_like_the_host_criterion(device, mode, request):
+    """sks_loop_adam_step_es against the host path (the same OptEarlyStopping class fed from a read-back of every group's sums,
+    MultiViewLoop._early_stop_cut): the same stopping iteration and bit for bit the same parameters, moments and slots -- eager,
+    inside hipGraphs (25 groups per graph: the groups replayed behind the stop must do nothing), on the dense path, and through
+    the view-sharded exchange, where the sums ride in the gradients' all_gather."""
+    from skelsplat_amd.loop import MultiViewLoop, OptEarlyStopping
+    from skelsplat_amd.heatmaps import generate_heatmaps
+    if mode == "sharded-world1":
+        request.getfixturevalue("rccl_world1")
+    sc, model = _make_loop_scene(device, seed=9)
+    tol = 8e-4
+    res = []
+    for on_device in (True, False):
+        gm = model(device)
+        hm = generate_heatmaps(gm._xyz.detach(), gm.get_scaling.detach(), gm._rotation.detach(),
+                               torch.tensor(sc.poses_2d, device=device), sc.cameras)
+        crit = OptEarlyStopping(window_size=4, repeat_tolerance=tol)
+        host_crit = OptEarlyStopping(window_size=4, repeat_tolerance=tol)
+        loop = MultiViewLoop(gm, sc.cameras, hm, dataset="h36m", sparse=mode != "dense",
+                             shard_views=mode == "sharded-world1", use_graph=on_device and mode == "hipgraph",
+                             graph_collectives=True,
+                             early_stopping=crit if on_device else (lambda loss: host_crit(loss)))
+        assert loop._es_device == on_device and loop.exchange == (mode == "sharded-world1")
+        if on_device and mode == "sharded-world1":
+            assert loop._shard_flat is not None and loop._allg.numel() == loop._shard_flat.numel()
+        loop.run(400)
+        assert loop.stopped_at is not None and loop.iteration == loop.stopped_at and loop.stopped_at % 4 != 0
+        assert int(loop.counters[0]) == loop.stopped_at          # the device's own iteration counter ended there too
+        res.append((loop.stopped_at, [x.detach().clone() for x in (gm._xyz, gm._scaling, gm._rotation, gm._opacity, loop.exp_avg,
+                                                                   loop.exp_avg_sq, loop.accumulated_grads, loop.counters)]))
+        if on_device:       # a second scene through the same loop: state, flag and counters start over
+            loop.new_scene(torch.tensor(sc.pose_3d_init, device=device, dtype=torch.float32), heatmaps=hm)
+            assert loop.stopped_at is None and int(loop._es_state.abs().sum()) == 0
+            loop.run(400)
+            assert loop.stopped_at == res[0][0]
+    assert res[0][0] == res[1][0], (res[0][0], res[1][0])
+    for k, (a, b) in enumerate(zip(res[0][1], res[1][1])):
+        assert torch.equal(a, b), k
 
 
 def test_heatmap_dropout_zeroes_the_drawn_planes(device):
