@@ -50,10 +50,10 @@ extern "C" {
                                  run inside the kernels (sks_geometry, sks_forward, sks_backward*) */
 #define SKS_RAW_GRADS    128u   /* sks_backward with SKS_RAW_PARAMS: dL_dopacity / dL_dscales / dL_drotations are the gradients of the
                                   LEAF parameters (the activation Jacobians applied here) instead of those of the activated ones */
-#define SKS_BIN_CLEAN    64u    /* sks_forward, binned path: `binning` is as the previous sks_forward with the same V, W, H left it
-                                  (completed without error, nothing else written to it since): its per-tile counters are zero
-                                  again by then and the clearing launch in front of the call is skipped.  A caller that reuses
-                                  one buffer for every step sets it from the second call on; a fresh buffer must not carry it */
+#define SKS_BIN_CLEAN    64u    /* accepted and ignored since sks_version 9: it used to promise that `binning` was as the previous
+                                  sks_forward left it (per-tile counters zero again) so that a clearing launch could be skipped.
+                                  The binned path no longer accumulates into the buffer -- every counter is written before it is
+                                  read -- so a buffer needs no clearing and may hold anything on entry */
 #define SKS_FILL_LINEAR (1u << 21)  /* tuning/tests: forward fill blocks always in linear (pass-major) mode */
 #define SKS_FILL_ROWS (1u << 22)    /* tuning/tests: row-aligned fill blocks whenever W % 4 == 0 */
 /* bits 26..29: tuning, composite blocks per (view, Gaussian) of the small-path forward (0 = default 4) */

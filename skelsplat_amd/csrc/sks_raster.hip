@@ -291,10 +291,7 @@ int sks_forward(int V, int P, int C, int W, int H, const float* viewmatrix, cons
         if (!binning) return fail(-2, "binned path needs a binning buffer");
         if (bin_capacity < 1) return fail(-1, "binned path needs bin_capacity >= 1");
         b = bin_from(binning, V, P, NT, bin_capacity);
-        // header (overflow flag, long-tile counter) + the per-tile counters k_geom_fwd adds to: one contiguous clear
-        // (a buffer the previous forward left behind has them zero already: k_bin_scatter clears the counters once they have
-        // served, k_geom_fwd the header -- SKS_BIN_CLEAN)
-        if (!(flags & SKS_BIN_CLEAN)) HIP_TRY(hipMemsetAsync(b.hdr, 0, 256 + (size_t)V * NT * 4, st));
+        // (nothing to clear: k_geom_fwd zeroes the header, k_bin_band_count writes every tile's count)
     }
     if (!small) g.cover = nullptr;   // (the binned path's cover rows are per plane: Bin::coverp, k_bin_scan + k_bin_sort_long)
     const int gthreads = small ? ((g.cover && cover_per_plane(P, W, H, C)) ? SKS_GEOM_COVER_THREADS : 256) : SKS_GEOM_BINNED_THREADS;
@@ -336,14 +333,14 @@ int sks_forward(int V, int P, int C, int W, int H, const float* viewmatrix, cons
     }
     uint32_t* cover = b.coverp;   // a row per (view, plane, band)
     const int cw = cover_cw(W);
+    hipLaunchKernelGGL(k_bin_band_count, dim3(gy, V), dim3(BAND_T), (size_t)2 * gx * 4, st, P, gx, g, b);
     {
         const int bpc = gx >= SCAN_T * 8 ? 1 : (SCAN_T * 8) / gx;   // whole tile bands per scan block (<= SCAN_T * SCAN_IPT tiles)
         const int nchunk_t = (gy + bpc - 1) / bpc, nchunk_g = (P + SCAN_G - 1) / SCAN_G;
         hipLaunchKernelGGL(k_bin_scan, dim3(nchunk_t + nchunk_g, V), dim3(SCAN_T), (size_t)bpc * cw * 4, st, P, gx, gy, cw, bpc,
                            nchunk_t, bin_capacity, b, cover, num_rendered_dev, V, C + 1);
     }
-    hipLaunchKernelGGL(k_bin_scatter, dim3((P * BIN_SUB + 255) / 256, V), dim3(256), 0, st, P, NT, gx, bin_capacity, g, b);
-    hipLaunchKernelGGL(k_bin_sort_long, dim3(SORT_LONG_BLOCKS), dim3(256), 0, st, V, P, NT, gx, bin_capacity, g, b, C, gy, cw);
+    hipLaunchKernelGGL(k_bin_band_scatter, dim3(gy, V), dim3(BAND_T), (size_t)2 * gx * 4, st, P, gx, bin_capacity, g, b, C, cw);
     STAGE_CHECK("binning");
     BinView bv = bin_view(b, NT, bin_capacity);
     {

@@ -69,8 +69,6 @@ class Workspace:
         self._t = {}
         self._plans = {}     # "fwd" / "bwd" -> the last call's recorded C-ABI argument list (see _plan_key)
         self._aux = {}
-        self._bin_clean = {}   # binning buffer (data_ptr) -> the layout (V, P, C, W, H, capacity) whose last sks_forward COMPLETED
-                               # on it and left its tile counters zero: only then may a replay carry SKS_BIN_CLEAN
 
     def aux_stream(self, dev_index):
         """The second stream forward_backward_views runs the backward on (created on first use, one per device)."""
@@ -187,11 +185,12 @@ class ForwardState:
     """What backward needs (the reference keeps geomBuffer / binningBuffer / imgBuffer + num_rendered,
     DGR/diff_gaussian_rasterization_h36m/__init__.py:87-89)."""
     __slots__ = ("views", "P", "C", "flags", "scale_modifier", "geom", "binning", "bin_capacity", "radii",
-                 "num_rendered_dev", "frames", "plan_key")
+                 "num_rendered_dev", "frames", "plan_key", "chunks")
 
     def __init__(self):
         self.frames = 1
         self.plan_key = None
+        self.chunks = None      # more than SKS_MAX_CHANNELS channels: [(view, c0, c1, feature chunk, ForwardState of that call)]
 
 
 def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotations, cov3D_precomp,
@@ -210,6 +209,10 @@ def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotati
     the caller's autograd graph), patches their pointers into a copy of the block and launches -- no re-validation."""
     lib = _lib.load()
     key = None
+    if features is not None and features.numel() and means3D is not None and means3D.dim() == 2 and means3D.shape[0] \
+            and features.numel() // means3D.shape[0] > _lib.SKS_MAX_CHANNELS:
+        return _forward_views_wide(views, means3D, features, opacities, scales, rotations, cov3D_precomp, scale_modifier, antialiasing,
+                                   clamp01, debug, force_binned, bin_capacity, want_aux, tune_flags, check_capacity)
     if plans is not None and workspace is None and not want_aux:
         pkey = _fwd_key(views, means3D, features, opacities, scales, rotations, cov3D_precomp, scale_modifier, antialiasing,
                         clamp01, debug, force_binned, bin_capacity, tune_flags, check_capacity)
@@ -247,19 +250,10 @@ def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotati
                 result[3].num_rendered_dev = host
             if cap_check is not None and check_capacity is True:
                 cap_check[0][1][:args[0]] = -1       # (the pinned counts of the synchronous check: "not written yet")
-            if args[21] is not None:
-                # the recorded flags carry SKS_BIN_CLEAN ("the buffer is as this layout's last completed forward left it"): true
-                # only while nothing else -- another layout of the same byte size, a call that failed half-way -- has been through
-                # the buffer since.  The token is taken off for the duration of the call: a failure leaves the buffer "dirty"
-                layout = (args[0], args[1], args[2], args[3], args[4], args[22])
-                clean = workspace._bin_clean.pop(args[21], None) == layout
-                args[16] = (args[16] | _lib.SKS_BIN_CLEAN) if clean else (args[16] & ~_lib.SKS_BIN_CLEAN)
             rc = _replay(lib.sks_forward, args, dev_index)
             if rc != 0:
                 del workspace._plans["fwd"]
             _lib.check(rc, "sks_forward")
-            if args[21] is not None:
-                workspace._bin_clean[args[21]] = layout
             if cap_check is None:
                 return result
             nr, pcap, ckey = cap_check
@@ -329,11 +323,7 @@ def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotati
             _lib.ptr(rotations), _lib.ptr(cov3D_precomp), float(scale_modifier), flags,
             color.data_ptr(), invdepth.data_ptr(), _lib.ptr(radii), geom.data_ptr(),
             _lib.ptr(binning), cap, _lib.ptr(nrend[0] if isinstance(nrend, tuple) else nrend), _lib.ptr(final_T), _lib.ptr(n_contrib), None]
-    if binned and workspace is not None:
-        workspace._bin_clean.pop(args[21], None)     # (this call clears the counters itself; dirty until it has completed)
     _lib.check(_replay(lib.sks_forward, args, dev.index), "sks_forward")
-    if binned and workspace is not None:
-        workspace._bin_clean[args[21]] = (V, P, C, W, H, cap)
     if binned and check_capacity:
         # The reference reads the pair count back on EVERY forward to size its buffers (rasterizer_impl.cu:283-288: a
         # blocking D2H copy between the scan and the duplication).  Here the arena is persistent and the count stays on
@@ -371,9 +361,7 @@ def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotati
         keep = (means3D, feat2, opacities, scales, rotations, cov3D_precomp)
         cap_check = None
         if binned:
-            # a replayed call that finds the binning buffer as this layout's last completed call left it -- tile counters zero
-            # again -- skips the clearing launch in front of the binning kernels (SKS_BIN_CLEAN, decided per replay from
-            # workspace._bin_clean)
+            # (the binning buffer needs no clearing between calls: every counter is written before it is read)
             args = list(args)
             if check_capacity is True:
                 cap_check = (nrend, cap, cap_key)
@@ -381,6 +369,68 @@ def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotati
                 cap_check = (None, cap, cap_key)     # replays are lazy calls: each takes a probe buffer of the shape (_lazy_probe)
         workspace._plans["fwd"] = (key, (views, keep), args, dev.index, (color, invdepth, radii, st), cap_check)
     return color, invdepth, radii, st
+
+
+def _forward_views_wide(views, means3D, features, opacities, scales, rotations, cov3D_precomp, scale_modifier, antialiasing, clamp01,
+                        debug, force_binned, bin_capacity, want_aux, tune_flags, check_capacity):
+    """Any number of channels ("any C via a generic path").  The kernels hold a pixel's channels in registers,
+    SKS_MAX_CHANNELS at most; the channels of a Gaussian splat are independent given its alpha, so a wider feature row is rendered
+    as ceil(C / 32) calls per view on 32-channel slices of the features, each writing its own planes: the same arithmetic per
+    channel as one wide call would do (the oracle, which takes any C, is the judge: bit for bit).  The backward is linear in the
+    channels (dL/dalpha is a sum over them): the slices' gradients add up.  A generic path, not a fast one: one launch sequence
+    per (view, slice), outputs copied into place."""
+    if want_aux:
+        raise RuntimeError("final_T / n_contrib are not available beyond SKS_MAX_CHANNELS channels")
+    if views.mixed:
+        raise RuntimeError("the dense forward writes one (V,C,H,W) tensor: all views of the batch must share the image size")
+    _need_gpu(means3D, "means3D")
+    P = means3D.shape[0]
+    feat2 = _f32c(features, "features").reshape(P, -1)
+    C, V, W, H, dev = feat2.shape[1], views.V, views.W, views.H, means3D.device
+    M = _lib.SKS_MAX_CHANNELS
+    color = torch.empty((V, C, H, W), dtype=torch.float32, device=dev)
+    invdepth = torch.empty((V, 1, H, W), dtype=torch.float32, device=dev)
+    radii = torch.empty((V, P), dtype=torch.int32, device=dev)
+    st = ForwardState()
+    st.views, st.P, st.C, st.scale_modifier, st.flags = views, P, C, float(scale_modifier), 0
+    st.geom = st.binning = st.num_rendered_dev = None
+    st.bin_capacity, st.radii, st.chunks = 0, radii, []
+    for v in range(V):
+        one = ViewBatch(views.viewmatrix[v:v + 1], views.projmatrix[v:v + 1], [views.tanfovx[v]], [views.tanfovy[v]], W, H)
+        for c0 in range(0, C, M):
+            c1 = min(C, c0 + M)
+            fc = feat2[:, c0:c1].contiguous()
+            col, inv, rad, sub = forward_views(one, means3D, fc, opacities, scales, rotations, cov3D_precomp, scale_modifier,
+                                               antialiasing, clamp01, debug, force_binned, bin_capacity, False, tune_flags, check_capacity)
+            color[v, c0:c1].copy_(col[0])
+            if c0 == 0:
+                invdepth[v].copy_(inv[0])
+                radii[v].copy_(rad[0])
+            st.chunks.append((v, c0, c1, fc, sub))
+    return color, invdepth, radii, st
+
+
+def _backward_views_wide(st, means3D, opacities, scales, rotations, cov3D_precomp, dL_dcolor, dL_dinvdepth, bg, want_dfeatures,
+                         tune_flags):
+    dev, V, P, C = means3D.device, st.views.V, st.P, st.C
+    dL_dcolor = _f32c(dL_dcolor, "dL_dout_color").reshape(V, C, st.views.H, st.views.W)
+    dL_dinvdepth = _f32c(dL_dinvdepth, "dL_dout_invdepth")
+    z = lambda *s_: torch.zeros(s_, dtype=torch.float32, device=dev)
+    out = dict(means3D=z(V, P, 3), means2D=z(V, P, 3), opacities=z(V, P, 1), cov3D=z(V, P, 6),
+               scales=z(V, P, 3) if scales is not None and scales.numel() else None,
+               rotations=z(V, P, 4) if rotations is not None and rotations.numel() else None,
+               features=z(V, P, C) if want_dfeatures else None)
+    bgC = _bg_channels(bg, C, dev)
+    for v, c0, c1, fc, sub in st.chunks:
+        g = backward_views(sub, means3D, fc, opacities, scales, rotations, cov3D_precomp, dL_dcolor[v:v + 1, c0:c1],
+                           None if (dL_dinvdepth is None or c0) else dL_dinvdepth.reshape(V, 1, st.views.H, st.views.W)[v:v + 1],
+                           None if bgC is None else bgC[c0:c1], want_dfeatures, tune_flags)
+        for k in ("means3D", "means2D", "opacities", "cov3D", "scales", "rotations"):
+            if out[k] is not None:
+                out[k][v] += g[k][0]
+        if want_dfeatures:
+            out["features"][v, :, c0:c1] = g["features"][0]
+    return out
 
 
 def _fwd_key(views, means3D, features, opacities, scales, rotations, cov3D_precomp, scale_modifier, antialiasing, clamp01, debug,
@@ -531,6 +581,11 @@ def backward_views(st: ForwardState, means3D, features, opacities, scales, rotat
     lib = _lib.load()
     key = None
     pkey = None
+    if st.chunks is not None:
+        if want_mean or out_means3D is not None:
+            raise RuntimeError("want_mean / out_means3D are not available beyond SKS_MAX_CHANNELS channels")
+        return _backward_views_wide(st, means3D, opacities, scales, rotations, cov3D_precomp, dL_dcolor, dL_dinvdepth, bg,
+                                    want_dfeatures, tune_flags)
     if plans is not None and workspace is None and st.plan_key is not None and out_means3D is None and not want_mean \
             and _sig(dL_dcolor) is not False and (dL_dinvdepth is None or _sig(dL_dinvdepth) is not False):
         # (the autograd path: same parameter tensors as the recorded forward, gradient tensors fresh every call)
@@ -833,7 +888,8 @@ def rasterize_views(views: ViewBatch, means3D, means2D, sh, opacities, scales=No
 
 class GaussianRasterizer(nn.Module):
     """DGR/diff_gaussian_rasterization_h36m/__init__.py:158-207.  `num_channels` pins C like the reference's
-    compile-time NUM_CHANNELS (config.h:15); None accepts any C <= 32."""
+    compile-time NUM_CHANNELS (config.h:15); None accepts any C (beyond SKS_MAX_CHANNELS = 32 through the generic path of
+    _forward_views_wide: 32-channel slices)."""
     num_channels: Optional[int] = None
 
     def __init__(self, raster_settings):

@@ -766,10 +766,11 @@ def test_gradients_of_an_overflowed_arena_are_nan_not_stale_rows(device):
         assert torch.equal(again[k], v), k
 
 
-def test_bin_clean_is_only_promised_for_the_layout_that_left_the_buffer(device):
-    """A Workspace's replayed binned forward skips the counter-clearing launch (SKS_BIN_CLEAN) -- only while the buffer is as THIS
-    layout's last completed forward left it.  Two layouts that share one byte-sized buffer, and a replay after a failed call,
-    must clear (stale counters would corrupt the tile ranges silently)."""
+def test_binning_buffer_may_hold_anything_on_entry(device):
+    """The binned path accumulates nothing into its scratch across calls -- k_bin_band_count writes every tile's count, k_geom_fwd
+    clears the header -- so a reused Workspace buffer that somebody scribbled over (another layout of the same byte size, a call
+    that failed half-way) gives the right image, lists and gradients with no clearing launch.  (Until round 5 a replay promised a
+    clean buffer with SKS_BIN_CLEAN and stale counters would have corrupted the tile ranges silently.)"""
     c = util.make_case(seed=2, W=184, H=120, scale_log=4.0, n_views=1)
     views = R.ViewBatch.from_cameras([cam.to(device) for cam in c.cams])
     args = (t(c.means, device), t(c.feat, device), t(c.opac, device), t(c.scales, device), t(c.quats, device), None)
@@ -777,22 +778,16 @@ def test_bin_clean_is_only_promised_for_the_layout_that_left_the_buffer(device):
     ws = R.Workspace()
     kw = dict(force_binned=True, bin_capacity=o["R"] + 64, check_capacity=False, workspace=ws)
     R.forward_views(views, *args, **kw)
-    col, _, _, st = R.forward_views(views, *args, **kw)            # replay, clean
-    plan = ws._plans["fwd"]
-    bptr = plan[2][21]
-    assert ws._bin_clean[bptr] == (1, c.P, c.C, c.W, c.H, o["R"] + 64)
+    col, _, _, st = R.forward_views(views, *args, **kw)            # replay
     assert np.array_equal(col[0].cpu().numpy(), o["color"])
-    # somebody else writes into the buffer (what another layout of the same byte size would do): the token is gone, the
-    # next replay must not trust the counters
-    ws._t[next(k for k in ws._t if k[0] == ("fwd", "binning"))].fill_(0x5a)
-    ws._bin_clean.pop(bptr)
-    col, _, _, st = R.forward_views(views, *args, **kw)
-    assert np.array_equal(col[0].cpu().numpy(), o["color"])
-    pl, rg, nr = R.export_lists(st)
-    assert np.array_equal(rg[0].cpu().numpy(), o["ranges"]) and np.array_equal(pl[0, :o["R"]].cpu().numpy(), o["point_list"])
-    assert ws._bin_clean[bptr] == (1, c.P, c.C, c.W, c.H, o["R"] + 64)    # promised again from here on
-    col, _, _, st = R.forward_views(views, *args, **kw)
-    assert np.array_equal(col[0].cpu().numpy(), o["color"])
+    g0 = R.backward_views(st, *args, t(c.dL_color, device), workspace=ws)["means3D"].clone()
+    for fill in (0x5a, 0xff, 0x00):
+        ws._t[next(k for k in ws._t if k[0] == ("fwd", "binning"))].fill_(fill)
+        col, _, _, st = R.forward_views(views, *args, **kw)
+        assert np.array_equal(col[0].cpu().numpy(), o["color"])
+        pl, rg, nr = R.export_lists(st)
+        assert np.array_equal(rg[0].cpu().numpy(), o["ranges"]) and np.array_equal(pl[0, :o["R"]].cpu().numpy(), o["point_list"])
+        assert torch.equal(R.backward_views(st, *args, t(c.dL_color, device), workspace=ws)["means3D"], g0)
 
 
 def test_binned_long_tile_lists(device):
@@ -865,14 +860,18 @@ def test_edge_cases(device):
     color, inv, radii, st = R.forward_views(views, e, torch.empty((0, 17), device=dev), torch.empty((0, 1), device=dev),
                                             e, torch.empty((0, 4), device=dev), None)
     assert color.shape == (2, 17, 60, 100) and not color.any() and radii.shape == (2, 0)
-    # C = 3 (RGB-like) and C = 32 (the supported maximum); C = 33 is refused with a message
-    for C in (3, 32):
+    # C = 3 (RGB-like), C = 32 (what one launch holds in registers) and C = 33 (two channel slices: the generic path)
+    for C in (3, 32, 33):
         f = torch.rand((c.P, C), device=dev)
         col, _, _, st = R.forward_views(views, args[0], f, *args[2:])
         oo = orc.forward(c.means, f.cpu().numpy(), c.opac, c.scales, c.quats, None, c.ocams[1])
         assert np.array_equal(col[1].cpu().numpy(), oo["color"])
-    with pytest.raises(RuntimeError, match="out of range"):
-        R.forward_views(views, args[0], torch.rand((c.P, 33), device=dev), *args[2:])
+    # ... the C ABI itself takes at most SKS_MAX_CHANNELS per call and says so
+    from skelsplat_amd import _lib
+    import ctypes
+    g_, b_, a_ = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
+    assert _lib.load().sks_scratch_bytes(1, 17, 33, 64, 64, 0, ctypes.byref(g_), ctypes.byref(b_), ctypes.byref(a_)) < 0
+    assert b"out of range" in _lib.load().sks_last_error()
 
 
 def orc_forward_custom(c, v, scales):
@@ -1193,3 +1192,45 @@ def test_forward_backward_as_one_call_on_the_binned_path_is_the_two_calls(device
     for _ in range(3):
         out = R.forward_backward_views(views, *args, dL, workspace=ws)
         assert torch.equal(out[0], col) and all(v is None or torch.equal(v, out[4][k]) for k, v in g.items())
+
+
+def test_any_number_of_channels_through_the_generic_path(device):
+    """"C is fixed per package (17 / 19 / 15) -- keep that, plus accept any C via a generic path".  The kernels
+    hold SKS_MAX_CHANNELS = 32 channels of a pixel in registers; a 70-channel feature row goes through as three slices per view
+    (rasterizer._forward_views_wide).  Against the oracle, which takes any C: forward bit for bit, gradients at the usual tolerance --
+    with a background, an inverse-depth gradient and the feature gradient -- and through the autograd surface."""
+    import math
+    from skelsplat_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    c = util.make_case(seed=8, W=136, H=104, scale_log=4.1, n_views=2)
+    Cw = 70
+    rng = np.random.default_rng(8)
+    feat = (rng.random((c.P, Cw)) * (rng.random((c.P, Cw)) < 0.5)).astype(np.float32)
+    dLc = rng.normal(0, 1, (2, Cw, c.H, c.W)).astype(np.float32)
+    bg = (rng.random(Cw) * 0.5).astype(np.float32)
+    views = R.ViewBatch.from_cameras([cam.to(device) for cam in c.cams])
+    args = (t(c.means, device), t(feat, device), t(c.opac, device), t(c.scales, device), t(c.quats, device), None)
+    col, inv, rad, st = R.forward_views(views, *args)
+    assert col.shape == (2, Cw, c.H, c.W) and st.chunks is not None and len(st.chunks) == 2 * 3
+    g = R.backward_views(st, *args, t(dLc, device), t(c.dL_inv, device), bg=t(bg, device), want_dfeatures=True)
+    for v in range(2):
+        o = orc.forward(c.means, feat, c.opac, c.scales, c.quats, None, c.ocams[v])
+        assert np.array_equal(col[v].cpu().numpy(), o["color"]) and np.array_equal(inv[v].cpu().numpy(), o["invdepth"])
+        assert np.array_equal(rad[v].cpu().numpy(), o["radii"])
+        b = orc.backward(o, c.means, feat, c.opac, c.scales, c.quats, None, c.ocams[v], dLc[v], c.dL_inv[v], bg=bg)
+        for ours, theirs in (("means3D", "dL_dmeans3D"), ("means2D", "dL_dmeans2D"), ("opacities", "dL_dopacity"), ("scales", "dL_dscales"),
+                             ("rotations", "dL_drotations"), ("cov3D", "dL_dcov3D"), ("features", "dL_dcolors")):
+            util.assert_close(f"{theirs} view {v}", g[ours][v].cpu().numpy(), b[theirs].reshape(g[ours][v].shape), rtol=1e-3, atol_scale=1e-5)
+    # the reference's class surface with a channel count no package is compiled for
+    cam = c.cams[0].to(device)
+    rs = GaussianRasterizationSettings(c.H, c.W, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), torch.zeros(3, device=device),
+                                       1.0, cam.world_view_transform, cam.full_proj_transform, 0, cam.camera_center, False, False, False)
+    means = args[0].clone().requires_grad_(True)
+    sh = args[1].reshape(c.P, 1, Cw).clone().requires_grad_(True)
+    img, radii, invd = GaussianRasterizer(rs)(means3D=means, means2D=torch.zeros_like(means, requires_grad=True), opacities=args[2],
+                                              shs=sh, scales=args[3], rotations=args[4])
+    assert torch.equal(img, col[0])
+    (img * t(dLc[0], device)).sum().backward()
+    o = orc.forward(c.means, feat, c.opac, c.scales, c.quats, None, c.ocams[0])
+    b = orc.backward(o, c.means, feat, c.opac, c.scales, c.quats, None, c.ocams[0], dLc[0], None)
+    util.assert_close("autograd means3D", means.grad.cpu().numpy(), b["dL_dmeans3D"], rtol=1e-3, atol_scale=1e-5)
+    util.assert_close("autograd features", sh.grad.reshape(c.P, Cw).cpu().numpy(), b["dL_dcolors"], rtol=1e-3, atol_scale=1e-5)

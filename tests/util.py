@@ -55,10 +55,10 @@ def assert_close(name, got, want, rtol=1e-3, atol_scale=1e-5):
 EPS32 = 2.0 ** -24
 # How far two fp32 evaluations of one gradient may sit apart, in units of 2**-24 x (the oracle's sum of |terms| over every pixel
 # and every path of the geometry backward, oracle.backward(bounds=True)).  Calibrated with tools/fuzz_bound_calib.py on the
-# MI355X: the largest excess seen over thousands of `extreme` cases x 7 gradients is below ONE unit (profiles/r05_fuzz_bound_calib.txt: 0.84);
-# the constant leaves a factor ~10 over it.  A dropped 16x16 tile of a 100-tile footprint moves a sum by ~1e-2 of its |terms|:
+# MI355X: the largest excess seen over 4 000 `extreme` cases x 7 gradients is 2.9 units (profiles/r05_fuzz_bound_calib.txt; below one unit for five of the seven);
+# the constant leaves a factor ~5 over it.  A dropped 16x16 tile of a 100-tile footprint moves a sum by ~1e-2 of its |terms|:
 # four orders of magnitude above this allowance.
-BOUND_KAPPA = 8.0
+BOUND_KAPPA = 16.0
 
 
 def bound_excess(got, want, bound, rtol=1e-3):
