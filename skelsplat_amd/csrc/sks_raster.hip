@@ -333,14 +333,14 @@ int sks_forward(int V, int P, int C, int W, int H, const float* viewmatrix, cons
     }
     uint32_t* cover = b.coverp;   // a row per (view, plane, band)
     const int cw = cover_cw(W);
-    hipLaunchKernelGGL(k_bin_band_count, dim3(gy, V), dim3(BAND_T), (size_t)2 * gx * 4, st, P, gx, g, b);
+    hipLaunchKernelGGL(k_bin_band_count, dim3(gy, V), dim3(BAND_TC), (size_t)2 * gx * 4, st, P, gx, g, b);
     {
         const int bpc = gx >= SCAN_T * 8 ? 1 : (SCAN_T * 8) / gx;   // whole tile bands per scan block (<= SCAN_T * SCAN_IPT tiles)
         const int nchunk_t = (gy + bpc - 1) / bpc, nchunk_g = (P + SCAN_G - 1) / SCAN_G;
         hipLaunchKernelGGL(k_bin_scan, dim3(nchunk_t + nchunk_g, V), dim3(SCAN_T), (size_t)bpc * cw * 4, st, P, gx, gy, cw, bpc,
                            nchunk_t, bin_capacity, b, cover, num_rendered_dev, V, C + 1);
     }
-    hipLaunchKernelGGL(k_bin_band_scatter, dim3(gy, V), dim3(BAND_T), (size_t)2 * gx * 4, st, P, gx, bin_capacity, g, b, C, cw);
+    hipLaunchKernelGGL(k_bin_band_scatter, dim3(gy, V), dim3(BAND_TS), (size_t)2 * gx * 4, st, P, gx, bin_capacity, g, b, C, cw);
     STAGE_CHECK("binning");
     BinView bv = bin_view(b, NT, bin_capacity);
     {
