@@ -384,42 +384,53 @@ def run_single(args, torch, dev, wl):
     W, H, P, C = scene.W, scene.H, scene.n_points, scene.n_joints
     views = R.ViewBatch.from_cameras(scene.cameras)
     dL = torch.randn((V, C, H, W), device=dev, generator=torch.Generator(device=dev).manual_seed(0))
-    step = ApiStep(views, params, dL)                      # forward + backward as ONE C-ABI call (sks_forward_backward)
-    step2 = ApiStep(views, params, dL, one_call=False)     # ... and as the two calls, for the roofline's kernel and for comparison
+    # Two forms of the same step.  "one" (the headline): sks_forward_backward -- the backward beside the forward on a second stream.
+    # "two": sks_forward, then sks_backward, one stream.  --form one / two restricts the run to one of them (a rocprofv3
+    # --kernel-trace --stats run per form gives per-kernel averages that are not a mixture); the default measures both.
+    forms = ("one", "two") if args.form == "both" else (args.form,)
     prof = not args.no_prof
-    step.autotune(), step2.autotune()                      # (untimed: fill-block size for each form of the step on this box)
-    for _ in range(args.warmup):
-        step()
-    for _ in range(max(3, args.warmup // 4)):
-        step2()
-    sync()
-    dt, out = timed(step, args.steps, 0, sync)             # THE timed region: K steps, nothing bracketed inside
-    # The dominant kernel's duration comes from the two-call form of the same step, timed right behind: in the one-call form the
-    # backward runs beside the forward on a second stream and an event pair around the forward would time the two together (its
-    # own duration there: ~51 us instead of ~46, profiles/r05_one_call_timeline.txt).  The compositor launches of every n-th step
-    # carry a hipEvent pair (hipExtLaunchKernelGGL: stamped from the kernel's own dispatch, on the launch stream); a bracketed
-    # step costs ~13 us of queue time, so the sample is 5 .. 25 launches of the K steps and the rest is made up behind them.
-    if prof:
-        _lib.prof_enable(True, every=int(os.environ.get("SKS_PROF_EVERY", "0")) or prof_stride(args.steps), kinds=(0,))
-        _lib.prof_read(0), _lib.prof_read(1)
-    dt2, out2 = timed(step2, args.steps, 0, sync)
-    assert torch.equal(out, out2)                          # (bit for bit the same gradients either way)
-    pf = pb = None
+    stride = int(os.environ.get("SKS_PROF_EVERY", "0")) or prof_stride(args.steps)
+
+    def measure(one_call):
+        """W warm-up + K timed steps of one form; the forward compositor launches of every n-th TIMED step carry a hipEvent pair
+        (hipExtLaunchKernelGGL: stamped from the kernel's own dispatch, on the launch stream -- a bracketed step costs ~13 us of
+        queue time, so the sample is 5 .. 25 of the K launches), topped up to ROOF_MIN_LAUNCHES behind the timed region by
+        untimed steps of the SAME form with every launch bracketed."""
+        st = ApiStep(views, params, dL, one_call=one_call)
+        st.autotune()                                      # (untimed: fill-block size for this form of the step on this box)
+        for _ in range(args.warmup):
+            st()
+        sync()
+        if prof:
+            _lib.prof_enable(True, every=stride, kinds=(0,))
+            _lib.prof_read(0), _lib.prof_read(1)
+        dt_, out_ = timed(st, args.steps, 0, sync)         # THE timed region: exactly K steps
+        pf_ = None
+        if prof:
+            have = _lib.prof_count(0)
+            if have < ROOF_MIN_LAUNCHES:
+                _lib.prof_enable(True, every=1, kinds=(0,))
+                for _ in range(ROOF_MIN_LAUNCHES - have):
+                    st()
+                sync()
+            pf_ = _lib.prof_read_quantiles(0)
+            _lib.prof_enable(False)
+        return st, dt_, out_, pf_
+
+    step, dt, out, pf = measure(forms[0] == "one")
+    step2 = dt2 = pf2 = None
+    if len(forms) == 2:
+        step2, dt2, out2, pf2 = measure(False)
+        assert torch.equal(out, out2)                      # (bit for bit the same gradients either way)
+    pb = None
     zero_us = None
     if prof:
-        # at least ROOF_MIN_LAUNCHES forward launches carry an event pair whatever --steps is: what the timed steps did not
-        # sample is made up by untimed steps behind them, every launch bracketed (the kernel's duration does not depend on it)
-        have = _lib.prof_count(0)
-        if have < ROOF_MIN_LAUNCHES:
-            _lib.prof_enable(True, every=1, kinds=(0,))
-            for _ in range(ROOF_MIN_LAUNCHES - have):
-                step2()
-            sync()
-        pf = _lib.prof_read_quantiles(0)
         zero_us = zero_fill_us(torch, V * (C + 1) * H * W, dev, sync)
-        _lib.prof_enable(True, every=1, kinds=(1,))     # the backward compositor: a few untimed steps behind the timed region
+        alone = step2 if step2 is not None else step
+        _lib.prof_enable(True, every=1, kinds=(1,))     # the backward compositor: a few untimed steps behind the timed regions
+        _lib.prof_read(1)
         for _ in range(10):
-            step2()
+            alone()
         sync()
         pb = _lib.prof_read_quantiles(1)
         _lib.prof_enable(False)
@@ -429,16 +440,32 @@ def run_single(args, torch, dev, wl):
         "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": wl["name"], "views_per_step": V, "P": P, "C": C, "W": W, "H": H, "parallelism": "single GPU",
-                   "path": "C ABI sks_forward_backward: forward + backward (incl. the mean over the views) of the resident dL as one "
-                           "call -- the backward reads the forward's geometry records, not its image, and runs on a second stream "
-                           "beside the dense forward; eager launches, outputs in a reused workspace"},
-        # the same step as the two separate calls (sks_forward, then sks_backward on the same stream), K steps timed the same way
-        "two_call_step": {"ms_per_step": 1e3 * dt2 / args.steps, "views_per_s": V * args.steps / dt2, "autotuned": step2.tuned},
+                   "form": forms[0],
+                   "path": ("C ABI sks_forward_backward: forward + backward (incl. the mean over the views) of the resident dL as one "
+                            "call -- the backward reads the forward's geometry records, not its image, and runs on a second stream "
+                            "beside the dense forward; eager launches, outputs in a reused workspace") if step.one_call else
+                           "C ABI sks_forward, then sks_backward (incl. the mean over the views), one stream; eager launches, outputs in "
+                           "a reused workspace"},
     }
     res["config"]["autotuned"] = step.tuned
+    alg_bytes = 4.0 * H * W * (C + 1) * V
+    if dt2 is not None:
+        # the same step as the two separate calls (sks_forward, then sks_backward on the same stream), K steps timed the same way
+        res["two_call_step"] = {"ms_per_step": 1e3 * dt2 / args.steps, "views_per_s": V * args.steps / dt2, "autotuned": step2.tuned}
     if pf and pf[1]:
-        res["roofline"] = roofline_entry(4.0 * H * W * (C + 1) * V, pf, wl["name"], args.steps)
-        res["roofline"]["timed_in"] = "the two-call form of the step, same run (see two_call_step)"
+        res["roofline"] = roofline_entry(alg_bytes, pf, wl["name"], args.steps)
+        res["roofline"]["timed_in"] = (f"the timed region of this line (the {'one' if step.one_call else 'two'}-call form)"
+                                       + (": the backward runs BESIDE the forward on a second queue there and takes wave slots from "
+                                          "its fill blocks -- the same kernel, the same bytes, alone on the chip: `kernel_alone`"
+                                          if step.one_call else ""))
+        res["roofline"]["whole_step_frac"] = alg_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS   # the step's mandatory bytes over its time
+        if pf2 and pf2[1]:
+            a_s = pf2[0] * 1e-3 / pf2[1]
+            res["roofline"]["kernel_alone"] = {
+                "what": "the same kernel in the two-call form of the step (nothing else on the chip), same run, same event pairs",
+                "avg_launch_us": a_s * 1e6, "launch_us_p10_p50_p90": [round(1e3 * x, 2) for x in pf2[2]], "launches_timed": pf2[1],
+                "achieved": alg_bytes / a_s / 1e9, "frac": alg_bytes / a_s / 1e9 / HBM_PEAK_GBS,
+                "frac_median": alg_bytes / (pf2[2][1] * 1e-3) / 1e9 / HBM_PEAK_GBS}
         if not args.no_extras:
             tb = measure_traffic(wl["dataset"])
             if tb:
@@ -450,6 +477,8 @@ def run_single(args, torch, dev, wl):
         if zero_us:
             res["roofline"]["zero_fill_same_bytes_us"] = zero_us
             res["roofline"]["frac_of_zero_fill"] = zero_us / (1e3 * pf[2][1])     # (median launch against the median zero_())
+            if pf2 and pf2[1]:
+                res["roofline"]["kernel_alone"]["frac_of_zero_fill"] = zero_us / (1e3 * pf2[2][1])
         if pb and pb[1]:
             res["bwd_kernel_avg_us"] = pb[0] * 1e3 / pb[1]
             res["bwd_kernel_us_p10_p50_p90"] = [round(1e3 * x, 2) for x in pb[2]]
@@ -690,6 +719,7 @@ def extra_panoptic(args, torch, dev, sync):
            "autotuned": step.tuned}
     if pf[1]:
         alg = 4.0 * H * W * (C + 1) * V
+        out["kernel_durations_from"] = "the two-call form of the step (the forward alone on the chip)"
         out["fwd_kernel_us"] = pf[0] * 1e3 / pf[1]
         out["fwd_kernel_us_p10_p50_p90"] = [round(1e3 * x, 1) for x in pf[2]]
         out["fwd_frac_of_hbm_peak"] = alg / (pf[0] * 1e-3 / pf[1]) / 1e9 / HBM_PEAK_GBS
@@ -931,24 +961,24 @@ def run_sharded(args, torch, dist, dev, wl, world, rank):
     for _ in range(args.warmup):
         step()
     sync()
-    prof = not args.no_prof and bool(local)
-    dt, out = timed(step, args.steps, 0, sync)      # THE timed region: K steps, nothing bracketed inside
+    prof = not args.no_prof
+    stride = prof_stride(args.steps)
+    if prof:    # the forward launches of every n-th timed step carry a hipEvent pair (run_single explains)
+        _lib.prof_enable(True, every=stride, kinds=(0,))
+        _lib.prof_read(0), _lib.prof_read(1)
+    dt, out = timed(step, args.steps, 0, sync)      # THE timed region: exactly K steps
     dt = max_over_ranks(dt)
     pf = None
     if prof:
-        # the dominant kernel's duration: from the two-call form of this rank's forward + backward, right behind the timed region
-        # (in the one-call form the backward and the collective run beside the forward: a pair around it would time all three)
-        step2 = ApiStep(lviews, params, dL, one_call=False)
-        for _ in range(3):
-            step2()
+        # topped up to ROOF_MIN_LAUNCHES by untimed steps of the same form behind the timed region -- the same number on every
+        # rank (the steps hold the collective), whatever each rank has sampled
+        extra = max(0, ROOF_MIN_LAUNCHES - (args.steps + stride - 1) // stride)
         _lib.prof_enable(True, every=1, kinds=(0,))
-        _lib.prof_read(0), _lib.prof_read(1)
-        for _ in range(ROOF_MIN_LAUNCHES):
-            step2()
+        for _ in range(extra):
+            step()
         torch.cuda.synchronize()
-        pf = _lib.prof_read_quantiles(0)
+        pf = _lib.prof_read_quantiles(0) if local else None
         _lib.prof_enable(False)
-        del step2
     assert torch.isfinite(out).all()
     # all_gather: the V rows are summed in view order on every rank -- bit for bit the one-GPU mean; all_reduce re-associates
     same = bool(torch.equal(out, ref_mean)) if exchange_mode == "all_gather" else \
@@ -989,7 +1019,8 @@ def run_sharded(args, torch, dist, dev, wl, world, rank):
         res["roofline"] = roofline_entry(4.0 * H * W * (C + 1) * len(local), pf, wl["name"], args.steps,
                                          traffic_scale=len(local) / V)
         res["roofline"]["note"] = f"rank 0's launch: its {len(local)} local views"
-        res["roofline"]["timed_in"] = "the two-call form of this rank's forward + backward, right behind the timed region"
+        res["roofline"]["timed_in"] = ("the timed region of this line" + (": the backward and the step's collective run BESIDE the forward "
+                                       "on a second queue there" if step_one_call else ""))
     if not args.no_extras:
         # (C, D) the loop's own step -- render + masked-L2 + backward + [all_gather] + Adam (train.py:130-222): dense and
         # sparse fused, each alone on one GPU (shard_views=False, all ranks side by side) and sharded over the ranks
@@ -1069,6 +1100,9 @@ def main():
     ap.add_argument("--no-dropin", action="store_true", help="skip the literal drop-in iteration extra (its single-view "
                     "launches would mix into per-kernel averages of a rocprofv3 run)")
     ap.add_argument("--no-extras", action="store_true", help="only the headline measurement")
+    ap.add_argument("--form", default="both", choices=["both", "one", "two"],
+                    help="N = 1: the step as one C-ABI call (sks_forward_backward, the headline), as two (sks_forward + sks_backward), "
+                         "or both (default: the headline is the one call, the two calls are reported beside it)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

@@ -46,6 +46,9 @@ for wl, tag in (("h36m", ""), ("panoptic", "_panoptic"), ("stress", "_stress")):
     st = glob.glob(os.path.join(SRC, f"{wl}_stats", "**", "*kernel_stats.csv"), recursive=True)
     if st:
         shutil.copy(st[0], os.path.join(DST, f"{rnd}_kernel_stats{tag}.csv"))
+    st2 = glob.glob(os.path.join(SRC, f"{wl}2_stats", "**", "*kernel_stats.csv"), recursive=True)
+    if st2:   # the two-call form of the step (bench.py --form two): the forward alone on the chip
+        shutil.copy(st2[0], os.path.join(DST, f"{rnd}_kernel_stats{tag}_two_calls.csv"))
     b = os.path.join(SRC, f"{wl}_bench.json")
     if os.path.exists(b) and os.path.getsize(b):
         shutil.copy(b, os.path.join(DST, f"{rnd}_bench{tag}.json"))

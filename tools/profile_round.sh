@@ -10,9 +10,12 @@ OUT=$ROOT/gpurun_out/prof
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for WL in h36m panoptic; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${WL}_stats" -o stats -- python3 "$ROOT/bench.py" --workload $WL --steps 50 --warmup 5 --no-cpu-baseline --no-extras > "$OUT/${WL}_bench_under_rocprof.json" 2> "$OUT/${WL}_stats.log"
-  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/${WL}_w" -o w -- python3 "$ROOT/bench.py" --workload $WL --steps 20 --warmup 3 --no-cpu-baseline --no-prof --no-extras > /dev/null 2> "$OUT/${WL}_w.log"
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/${WL}_f" -o f -- python3 "$ROOT/bench.py" --workload $WL --steps 20 --warmup 3 --no-cpu-baseline --no-prof --no-extras > /dev/null 2> "$OUT/${WL}_f.log"
+  # per-kernel averages of the HEADLINE form of the step (--form one: sks_forward_backward, the backward beside the forward) and of the
+  # two-call form (the forward alone on the chip): two runs, so that neither average is a mixture
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${WL}_stats" -o stats -- python3 "$ROOT/bench.py" --workload $WL --form one --steps 50 --warmup 5 --no-cpu-baseline --no-extras > "$OUT/${WL}_bench_under_rocprof.json" 2> "$OUT/${WL}_stats.log"
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${WL}2_stats" -o stats -- python3 "$ROOT/bench.py" --workload $WL --form two --steps 50 --warmup 5 --no-cpu-baseline --no-extras > "$OUT/${WL}_bench_two_calls_under_rocprof.json" 2> "$OUT/${WL}2_stats.log"
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/${WL}_w" -o w -- python3 "$ROOT/bench.py" --workload $WL --form two --steps 20 --warmup 3 --no-cpu-baseline --no-prof --no-extras > /dev/null 2> "$OUT/${WL}_w.log"
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/${WL}_f" -o f -- python3 "$ROOT/bench.py" --workload $WL --form two --steps 20 --warmup 3 --no-cpu-baseline --no-prof --no-extras > /dev/null 2> "$OUT/${WL}_f.log"
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stress_stats" -o stats -- python3 "$ROOT/tools/bench_stress.py" > "$OUT/stress.log" 2>&1
 # HBM traffic of the binned path's kernels (separate PMC passes, --kernel-trace only) and the timeline of one forward call
