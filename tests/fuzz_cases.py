@@ -123,6 +123,56 @@ def run_case(seed, dev, small_path_too=False, stats=None):
         raise AssertionError(f"{tag} -> {str(e)[:300]}") from None
 
 
+def run_one_call_case(seed, dev):
+    """sks_forward_backward (the backward on a second stream beside the forward, joined or not) against sks_forward + sks_backward on a
+    random small-path scene: image, inverse depth, radii and every gradient BIT FOR BIT, over several calls on one Workspace with
+    the parameters changing in place in between, any switch combination, 1-6 views, odd image sizes; every third seed with more
+    than SKS_MAX_CHANNELS channels (the generic path: two calls under the hood, same bits)."""
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev) if a is not None else None
+    rng = np.random.default_rng(seed)
+    W, H = int(rng.integers(40, 300)), int(rng.integers(40, 220))
+    if seed % 6 == 0:
+        W, H = int(rng.choice([1000, 1002, 1024, 1920])), int(rng.integers(20, 60))
+    nv = int(rng.integers(1, 7))
+    c = util.make_case(seed=seed, W=W, H=H, n_views=nv, n_skeletons=int(rng.choice([1, 1, 2, 6])), scale_log=float(rng.uniform(2.8, 4.4)),
+                       pitch=float(rng.uniform(60.0, 600.0)), onehot=bool(rng.integers(0, 2)), fxmul=float(rng.uniform(0.7, 1.5)))
+    aa, clamp = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    use_bg, use_inv, use_feat, want_mean = (bool(rng.integers(0, 2)) for _ in range(4))
+    feat = c.feat
+    if seed % 3 == 0:
+        Cw = int(rng.integers(33, 72))
+        feat = (rng.random((c.P, Cw)) * (rng.random((c.P, Cw)) < 0.4)).astype(np.float32)
+        want_mean = False
+    C = feat.shape[1]
+    tag = f"one-call seed {seed}: {W}x{H} V={nv} P={c.P} C={C} aa={aa} clamp={clamp} bg={use_bg} inv={use_inv} feat={use_feat} mean={want_mean}"
+    try:
+        views = R.ViewBatch.from_cameras([cam.to(dev) for cam in c.cams])
+        means, fe, opac, scales, quats = (t(a) for a in (c.means, feat, c.opac, c.scales, c.quats))
+        dL = torch.randn((nv, C, H, W), device=dev, generator=torch.Generator(device=dev).manual_seed(seed))
+        dLi = torch.randn((nv, 1, H, W), device=dev, generator=torch.Generator(device=dev).manual_seed(seed + 1)) if use_inv else None
+        bg = torch.rand(C, device=dev) if use_bg else None
+        kw = dict(antialiasing=aa, clamp01=clamp, bg=bg, want_dfeatures=use_feat, want_mean=want_mean)
+        ws = R.Workspace()
+        for rep in range(4):
+            if rep == 2:
+                with torch.no_grad():
+                    means.add_(float(rng.uniform(-4.0, 4.0)))
+                    scales.mul_(float(rng.uniform(0.9, 1.1)))
+                    dL.mul_(-0.5)
+            col, inv, rad, st = R.forward_views(views, means, fe, opac, scales, quats, None, antialiasing=aa, clamp01=clamp)
+            g = R.backward_views(st, means, fe, opac, scales, quats, None, dL, dLi, bg=bg, want_dfeatures=use_feat, want_mean=want_mean)
+            join = bool((seed + rep) % 2)
+            out = R.forward_backward_views(views, means, fe, opac, scales, quats, None, dL, dLi, workspace=ws, join=join, **kw)
+            if not join:
+                ws.join(dev.index)
+            assert torch.equal(col, out[0]) and torch.equal(inv, out[1]) and torch.equal(rad, out[2]), ("forward", rep)
+            for k, v in g.items():
+                assert (v is None and out[4][k] is None) or torch.equal(v, out[4][k]), (k, rep)
+        return dict(visible=float((rad > 0).sum()), grad=float(g["means3D"].abs().max()))
+    except AssertionError as e:
+        raise AssertionError(f"{tag} -> {str(e)[:300]}") from None
+
+
 def run_fused_loss_case(seed, dev):
     """The production loop's step -- sks_geometry + sks_backward_fused_loss: no image, no dense gradient, the pseudo-GT as planes
     or as separable factors -- against the dense device path sks_forward(clamp) -> sks_masked_l2 -> sks_backward on a random

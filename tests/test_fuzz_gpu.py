@@ -33,6 +33,16 @@ def test_extreme_cases_within_the_computed_rounding_allowance(device, block):
     assert stats and max(stats.values()) <= util.BOUND_KAPPA      # (what the cases needed of the allowance)
 
 
+@pytest.mark.parametrize("block", range(3))
+def test_random_one_call_steps_equal_the_two_calls_bit_for_bit(device, block):
+    from tests.fuzz_cases import run_one_call_case
+    live = 0
+    for seed in range(700 + 20 * block, 700 + 20 * (block + 1)):
+        r = run_one_call_case(seed, device)
+        live += r["visible"] > 0 and r["grad"] > 0
+    assert live >= 15
+
+
 @pytest.mark.parametrize("block", range(4))
 def test_random_fused_loss_steps_match_the_dense_path(device, block):
     from tests.fuzz_cases import run_fused_loss_case

@@ -1,5 +1,5 @@
 """Randomised parity sweep of the binned path against the CPU oracle (GPU box); the cases are tests/fuzz_cases.py's.
-    python tools/fuzz_binned.py [cases] [seed0] [raster|loss|loop|frames|dropin|ops]     (loss: the sparse fused-loss step against the dense device path; loop: the production loop against the dense loop)"""
+    python tools/fuzz_binned.py [cases] [seed0] [raster|loss|loop|frames|dropin|ops|onecall]     (loss: the sparse fused-loss step against the dense device path; loop: the production loop against the dense loop)"""
 import os
 import sys
 import time
@@ -7,14 +7,14 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
-from tests.fuzz_cases import run_case, run_fused_loss_case, run_loop_case, run_frames_case, run_dropin_case, run_ops_case
+from tests.fuzz_cases import run_case, run_fused_loss_case, run_loop_case, run_frames_case, run_dropin_case, run_ops_case, run_one_call_case
 
 dev = torch.device("cuda:0")
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 bad, t0, seen = 0, time.time(), []
 mode = sys.argv[3] if len(sys.argv) > 3 else "raster"
-which = {"raster": run_case, "loss": run_fused_loss_case, "loop": run_loop_case, "frames": run_frames_case, "dropin": run_dropin_case, "ops": run_ops_case}[mode]
+which = {"raster": run_case, "loss": run_fused_loss_case, "loop": run_loop_case, "frames": run_frames_case, "dropin": run_dropin_case, "ops": run_ops_case, "onecall": run_one_call_case}[mode]
 trace = bool(os.environ.get("FUZZ_TRACE"))   # print every seed first and synchronise after it: finds the case behind a GPU fault
 for k in range(n_cases):
     try:
