@@ -227,8 +227,9 @@ struct FusedBackward {
     hipEvent_t geom_done;   // rides on k_geom_fwd's own dispatch (hipExtLaunchKernelGGL): no marker packet in the caller's queue
 };
 thread_local FusedBackward* tl_fused_bwd = nullptr;
-struct FbEvents {   // created by a thread's first combined call, reused by every later one
+struct FbEvents {   // created by a thread's first combined call, reused by every later one on the same device
     hipEvent_t geom = nullptr, done = nullptr;
+    int dev = -1;
 };
 thread_local FbEvents tl_fb_events;
 
@@ -469,7 +470,15 @@ int sks_forward_backward(int V, int P, int C, int W, int H, const float* viewmat
                             dL_dmeans3D_mean, stream);
     }
     FbEvents& ev = tl_fb_events;
+    int cur_dev = 0;
+    HIP_TRY(hipGetDevice(&cur_dev));
+    if (ev.geom && ev.dev != cur_dev) {   // (events belong to a device: a thread that moved to another one gets new ones)
+        (void)hipEventDestroy(ev.geom);
+        (void)hipEventDestroy(ev.done);
+        ev.geom = ev.done = nullptr;
+    }
     if (!ev.geom) {
+        ev.dev = cur_dev;
         // hand-over between two queues of ONE device: a device-scope release is all the waiting side needs (the default,
         // a system-scope fence, is what a host reader of the event would want)
         unsigned evf = hipEventDisableTiming | hipEventDisableSystemFence;
