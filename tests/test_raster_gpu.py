@@ -1234,3 +1234,28 @@ def test_any_number_of_channels_through_the_generic_path(device):
     b = orc.backward(o, c.means, feat, c.opac, c.scales, c.quats, None, c.ocams[0], dLc[0], None)
     util.assert_close("autograd means3D", means.grad.cpu().numpy(), b["dL_dmeans3D"], rtol=1e-3, atol_scale=1e-5)
     util.assert_close("autograd features", sh.grad.reshape(c.P, Cw).cpu().numpy(), b["dL_dcolors"], rtol=1e-3, atol_scale=1e-5)
+
+
+def test_autotuned_fill_block_size_changes_no_bit(device):
+    """rasterizer.autotune_fill_passes times the caller's step under 2 / 3 / 4 / 5 passes per fill block and patches the recorded
+    argument block: whatever it picks, images and gradients stay bit for bit what the default gives (the knob only regroups the
+    forward's zero-fill blocks), and the choice survives the following replays."""
+    c = util.make_case(seed=12, W=1000, H=96, scale_log=4.2, n_views=2)      # (W = 1000: the linear fill mode the knob belongs to)
+    views = R.ViewBatch.from_cameras([cam.to(device) for cam in c.cams])
+    args = (t(c.means, device), t(c.feat, device), t(c.opac, device), t(c.scales, device), t(c.quats, device), None)
+    dL = t(c.dL_color, device)
+    col0, inv0, rad0, st0 = R.forward_views(views, *args)
+    g0 = R.backward_views(st0, *args, dL)
+    ws = R.Workspace()
+    step = lambda: R.forward_backward_views(views, *args, dL, workspace=ws)
+    step(), step()
+    best, med = R.autotune_fill_passes(ws, step, candidates=(0, 3, 4, 5), reps=4, rounds=2)
+    assert best in (0, 3, 4, 5) and set(med) == {0, 3, 4, 5} and all(v > 0 for v in med.values())
+    assert (ws._plans["fwd"][2][16] >> 8) & 0xff == best
+    for forced in (best, 1, 5, 7):
+        ws._plans["fwd"][2][16] = (ws._plans["fwd"][2][16] & ~(0xff << 8)) | (forced << 8)
+        col, inv, rad, st, g = step()
+        torch.cuda.synchronize()
+        assert torch.equal(col, col0) and torch.equal(inv, inv0) and torch.equal(rad, rad0), forced
+        assert all(v is None or torch.equal(v, g[k]) for k, v in g0.items()), forced
+    assert R.autotune_fill_passes(R.Workspace(), step) == (None, {})        # (nothing recorded: nothing to tune)
