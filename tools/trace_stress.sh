@@ -1,9 +1,9 @@
 #!/bin/bash
 # Timeline of one binned forward call (tools/bench_stress.py under rocprofv3 --kernel-trace): start / end of every kernel
-# relative to the call's first kernel.   bash tools/trace_stress.sh   (GPU box)
+# relative to the call's first kernel.   [TRACE_SCRIPT=bin_only.py] bash tools/trace_stress.sh   (GPU box)
 root=$(cd "$(dirname "$0")/.." && pwd)
 cd /tmp && export TMPDIR=/tmp
-rm -rf /tmp/trs && rocprofv3 --kernel-trace --output-format csv -d /tmp/trs -o t -- python3 "$root/tools/bench_stress.py" > /dev/null 2>&1
+rm -rf /tmp/trs && rocprofv3 --kernel-trace --output-format csv -d /tmp/trs -o t -- python3 "$root/tools/${TRACE_SCRIPT:-bench_stress.py}" > /dev/null 2>&1
 python3 - <<'PY'
 import csv, glob
 rows = []
