@@ -1152,12 +1152,12 @@ def main():
     wl = WORKLOADS[args.workload or ("panoptic" if use_dist else "h36m")]
     if use_dist:
         res = run_sharded(args, torch, dist, dev, wl, world, rank)
-        if rank == 0 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline:    # (the CPU sample is the N = 1 line's: no rank waits in a collective for it)
             from skelsplat_amd.scene import SyntheticScene
             sc = SyntheticScene(wl["dataset"], n_views=wl["V"], seed=0)
             _, _, prm = make_scene(torch, wl, dev)
             res["cpu_baseline"] = cpu_baseline(sc, prm, n_views=2)
-        dist.barrier()     # the other ranks wait here for rank 0's CPU sample: all ranks leave the process group together
+        dist.barrier()     # all ranks leave the process group together
     else:
         res, scene, params = run_single(args, torch, dev, wl)
         if not args.no_cpu_baseline:

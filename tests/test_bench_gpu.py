@@ -53,3 +53,16 @@ def test_sharded_step_at_world_2_on_one_device(device):
     r = _run(cmd, env={"SKS_BENCH_ONE_DEVICE": "1"})
     assert r["n_gpus"] == 2 and r["config"]["views_on_rank0"] == 16 and r["strong_scaling"]["ideal_speedup"] == 31 / 16
     assert "gloo" in r["config"]["parallelism"] and r["value"] > 0
+
+
+def test_sharded_extras_at_world_2_on_one_device(device):
+    """The same with the extras the driver's multi-GPU run carries (the loop's dense and sparse steps alone and sharded, frame
+    sharding): every rank goes through the same collectives and the line still comes out as one."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29580", "bench.py", "--gpus", "2", "--steps", "10", "--warmup", "2"]
+    r = _run(cmd, env={"SKS_BENCH_ONE_DEVICE": "1"})
+    assert "loop_error" not in r, r.get("loop_error")
+    assert "cpu_baseline" not in r            # the CPU sample belongs to the N = 1 line
+    for tag in ("api_step", "loop_dense", "loop_sparse"):
+        assert r["strong_scaling"][tag]["ms_per_step"] > 0
+    assert r["frame_sharded"]["frames_per_s_all_ranks"] > 0 and r["mean_equals_one_gpu"] == "bit for bit"
