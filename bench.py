@@ -610,6 +610,15 @@ def dropin_iteration(args, torch, dev, wl, scene):
     hm = generate_heatmaps(gm2._xyz.detach(), gm2.get_scaling.detach(), gm2._rotation.detach(),
                            torch.tensor(scene.poses_2d, device=dev), scene.cameras)
 
+    def one_launch_adam():
+        # the same groups and state under skelsplat_amd.optim.Adam (a torch.optim.Adam whose step() is one launch): the one-line
+        # change to scene/gaussian_model.py:218 that INTEGRATION.md names
+        from skelsplat_amd.optim import Adam
+        groups = [{k: g[k] for k in ("params", "lr", "name")} for g in gm2.optimizer.param_groups]
+        opt = Adam(groups, lr=0.0, eps=1e-15)
+        opt.load_state_dict(gm2.optimizer.state_dict())
+        gm2.optimizer = opt
+
     def it(i, criterion):
         pkg = render(scene.cameras[i % V], gm2, pipe, bgc)
         loss, _ = criterion(pkg["render"], hm[i % V])   # (loss, error image) like loss_utils.py:100
@@ -620,7 +629,10 @@ def dropin_iteration(args, torch, dev, wl, scene):
 
     out = {}
     # tensor-op criterion as in the reference, then the fused criterion registered in its `losses` table
-    for tag, crit in (("dropin_iteration_ms", l2_loss_gaussian), ("dropin_iteration_fused_loss_ms", l2_loss_gaussian_fused)):
+    for tag, crit in (("dropin_iteration_ms", l2_loss_gaussian), ("dropin_iteration_fused_loss_ms", l2_loss_gaussian_fused),
+                      ("dropin_iteration_fused_loss_one_launch_adam_ms", l2_loss_gaussian_fused)):
+        if "one_launch_adam" in tag:
+            one_launch_adam()
         for i in range(2 * V):
             it(i, crit)
         # host-bound (a few dozen Python-level launches per view): the median of 3 repetitions of >= 16 accumulation groups --

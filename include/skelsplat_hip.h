@@ -323,6 +323,15 @@ int sks_loop_adam_step_es(int V, int P, const float* grads, float* slots, unsign
                           int* es_host_flag /*pinned HOST int or NULL*/, void* stream);
 size_t sks_loop_shard_floats(int V, int P, int shard_world);
 
+/* torch.optim.Adam's update (no amsgrad, no weight decay; scene/gaussian_model.py:218 builds it with eps = 1e-15 over six parameter
+ * groups, train.py:219 steps it) for up to 8 fp32 tensors in ONE launch:
+ *   exp_avg.lerp_(grad, 1 - beta1); exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2);
+ *   param.addcdiv_(exp_avg, exp_avg_sq.sqrt() / sqrt(1 - beta2^step) + eps, value = -lr / (1 - beta1^step)).
+ * params / grads / exp_avg / exp_avg_sq: HOST arrays of n_tensors device pointers; numel, lr, step: HOST arrays (step = the
+ * tensor's count AFTER this step, >= 1: torch keeps one per parameter).  What skelsplat_amd.optim.Adam.step() calls. */
+int sks_adam_multi(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                   const long long* numel, const double* lr, const long long* step, double beta1, double beta2, double eps, void* stream);
+
 /* One accumulation group of the sparse loop on ONE GPU in two launches (train.py:130-222 for acc_steps views):
  * the fused-loss compositing backward (as sks_backward_fused_loss) and a single-workgroup tail that runs the geometry
  * backward of every view, the optimiser step (as sks_loop_adam_step) and the geometry forward of the UPDATED parameters.

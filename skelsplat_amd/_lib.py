@@ -63,6 +63,7 @@ SIGNATURES = {
     "sks_loop_adam_step_es": (_i, [_i, _i, _vp, _vp, C.c_ulonglong, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp,
                                    _f, _vp, _i, _vp, _vp, _i, _f, _vp, _vp]),
     "sks_loop_shard_floats": (_sz, [_i, _i, _i]),
+    "sks_adam_multi": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double, C.c_double, _vp]),
     "sks_loop_fused_step": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _u, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                  _vp, C.c_ulonglong, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp,
                                  _i, _vp, _vp]),

@@ -88,6 +88,34 @@ __global__ __launch_bounds__(256) void k_loop_adam(AdamArgs a)
     sksloop::adam_block_finish(a, s_xyz, s_hyp, s_d, s_it);
 }
 
+
+// torch.optim.Adam's step for up to ADAM_MULTI_MAX parameter tensors in ONE launch (the reference's optimiser has six parameter
+// groups, gaussian_model.py:203-218; torch's foreach path is ~10 launches per group).  Block b belongs to the tensor whose block
+// range holds it; step sizes and bias corrections come from the host in the precision torch forms them in (Python doubles).
+constexpr int ADAM_MULTI_MAX = 8;
+struct AdamMultiArgs {
+    float* p[ADAM_MULTI_MAX];
+    const float* g[ADAM_MULTI_MAX];
+    float* m[ADAM_MULTI_MAX];
+    float* v[ADAM_MULTI_MAX];
+    long long n[ADAM_MULTI_MAX];
+    unsigned blk0[ADAM_MULTI_MAX + 1];
+    float step_size[ADAM_MULTI_MAX], bc2_sqrt[ADAM_MULTI_MAX];
+    float w1, b2, w2, eps;
+    int nt;
+};
+__global__ __launch_bounds__(256) void k_adam_multi(AdamMultiArgs a)
+{
+    int t = 0;
+#pragma unroll
+    for (int k = 1; k < ADAM_MULTI_MAX; k++) t = (k < a.nt && blockIdx.x >= a.blk0[k]) ? k : t;
+    const long long i = (long long)(blockIdx.x - a.blk0[t]) * 256 + threadIdx.x;
+    if (i >= a.n[t]) return;
+    float prm = a.p[t][i], m = a.m[t][i], v = a.v[t][i];
+    sksloop::adam_update(prm, a.g[t][i], m, v, a.w1, a.b2, a.w2, a.eps, a.step_size[t], a.bc2_sqrt[t]);
+    a.p[t][i] = prm; a.m[t][i] = m; a.v[t][i] = v;
+}
+
 }  // namespace
 
 extern "C" {
@@ -143,6 +171,42 @@ int sks_loop_adam_step_es(int V, int P, const float* grads, float* slots, unsign
     a.es_state = es_state; a.es_window = es_window; a.es_tol = es_tolerance; a.es_sums = loss_sums; a.es_host_flag = es_host_flag;
     if (shard_world > 1 && !loss_sums) a.rank_stride = sksloop::es_tail_offset(a.vmax, P) + 4ll * a.vmax;
     hipLaunchKernelGGL(k_loop_adam, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail3((int)e, hipGetErrorString(e));
+    return 0;
+}
+
+int sks_adam_multi(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                   const long long* numel, const double* lr, const long long* step, double beta1, double beta2, double eps, void* stream)
+{
+    if (n_tensors < 1 || n_tensors > ADAM_MULTI_MAX) return fail3(-1, "adam_multi: 1 .. 8 tensors per call");
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !numel || !lr || !step) return fail3(-2, "adam_multi: missing pointer");
+    AdamMultiArgs a;
+    a.nt = n_tensors;
+    unsigned blocks = 0;
+    for (int t = 0; t < ADAM_MULTI_MAX; t++) {
+        const bool on = t < n_tensors;
+        if (on && (!params[t] || !grads[t] || !exp_avg[t] || !exp_avg_sq[t])) return fail3(-2, "adam_multi: missing tensor");
+        if (on && (numel[t] < 0 || step[t] < 1)) return fail3(-1, "adam_multi: numel >= 0 and step >= 1 (the count after this step)");
+        a.p[t] = on ? params[t] : nullptr; a.g[t] = on ? grads[t] : nullptr; a.m[t] = on ? exp_avg[t] : nullptr; a.v[t] = on ? exp_avg_sq[t] : nullptr;
+        a.n[t] = on ? numel[t] : 0;
+        a.blk0[t] = blocks;
+        if (on) {
+            const long long nb = (numel[t] + 255) / 256;
+            if (nb > 0x7fffffffll - (long long)blocks) return fail3(-1, "adam_multi: too many elements for one launch");
+            blocks += (unsigned)nb;
+            // torch/optim/adam.py (_single_tensor_adam, not capturable): bias corrections and the step size as Python floats
+            const double bc1 = 1.0 - pow(beta1, (double)step[t]), bc2 = 1.0 - pow(beta2, (double)step[t]);
+            a.step_size[t] = (float)(lr[t] / bc1);
+            a.bc2_sqrt[t] = (float)sqrt(bc2);
+        } else {
+            a.step_size[t] = 0.0f; a.bc2_sqrt[t] = 1.0f;
+        }
+    }
+    a.blk0[ADAM_MULTI_MAX] = blocks;
+    a.w1 = (float)(1.0 - beta1); a.b2 = (float)beta2; a.w2 = (float)(1.0 - beta2); a.eps = (float)eps;
+    if (blocks == 0) return 0;
+    hipLaunchKernelGGL(k_adam_multi, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail3((int)e, hipGetErrorString(e));
     return 0;

@@ -1,0 +1,137 @@
+"""torch.optim.Adam whose step() is ONE launch (sks_adam_multi) for all parameter groups.
+
+The reference builds `torch.optim.Adam(l, lr=0.0, eps=1e-15)` over six one-tensor parameter groups (scene/gaussian_model.py:
+203-218) and steps it once per accumulation group (train.py:219-220).  torch's foreach implementation spends ~330 us of host time
+and ~40 launches on those few hundred floats; here the same update -- same state layout (`step`, `exp_avg`, `exp_avg_sq` per
+parameter, so `state_dict()` / `load_state_dict()` / the reference's `capture()` and `restore()` keep working), same hyper-
+parameters read from `param_groups` at every step (the reference rewrites `lr` of the "xyz" group every iteration,
+gaussian_model.py:234-239) -- is one C-ABI call.  Drop-in: `self.optimizer = skelsplat_amd.optim.Adam(l, lr=0.0, eps=1e-15)`.
+
+What is not this kernel's (amsgrad, weight decay, maximize, sparse or non-fp32 gradients, CPU tensors) goes to torch's own step()
+unchanged: the class is a torch.optim.Adam in every other respect."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+_MAX = 8    # tensors per sks_adam_multi call
+
+
+class Adam(torch.optim.Adam):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, **kw):
+        kw.pop("foreach", None), kw.pop("fused", None)
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad, foreach=False, **kw)
+        self._reset_cache()
+
+    def _reset_cache(self):
+        self._steps = {}    # id(param) -> its step count as a Python int; state["step"] (a host tensor, as torch keeps it) follows lazily
+        self._plans = {}    # first index of a chunk -> (key, argument arrays)
+
+    # ---- the step counts live in Python ints between steps; everything that looks at the state sees tensors ----
+    def _flush_steps(self):
+        for group in self.param_groups:
+            for p in group["params"]:
+                k = self._steps.get(id(p))
+                if k is not None:
+                    self.state[p]["step"].fill_(float(k))
+
+    def state_dict(self, *a, **kw):
+        self._flush_steps()
+        return super().state_dict(*a, **kw)
+
+    def load_state_dict(self, *a, **kw):
+        r = super().load_state_dict(*a, **kw)
+        self._reset_cache()
+        return r
+
+    def add_param_group(self, group):
+        r = super().add_param_group(group)
+        if hasattr(self, "_plans"):
+            self._plans = {}
+        return r
+
+    @staticmethod
+    def _ours(group):
+        return not (group["amsgrad"] or group["weight_decay"] != 0 or group.get("maximize") or group.get("capturable")
+                    or group.get("differentiable") or isinstance(group["lr"], torch.Tensor))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        todo = []       # (param, grad, group)
+        dev = betas = eps = None
+        for group in self.param_groups:
+            ours = None
+            for p in group["params"]:
+                g = p.grad
+                if g is None:
+                    continue
+                if ours is None:
+                    ours = self._ours(group)
+                    if dev is None:
+                        dev, betas, eps = p.device, group["betas"], group["eps"]
+                    if not ours or group["betas"] != betas or group["eps"] != eps:
+                        return self._torch_step(loss)
+                if not (p.is_cuda and p.device == dev and g.device == dev and p.dtype == torch.float32 and g.dtype == torch.float32
+                        and g.layout == torch.strided and p.is_contiguous() and g.is_contiguous()):
+                    return self._torch_step(loss)
+                todo.append((p, g, group))
+        if not todo:
+            return loss
+        states = []
+        for p, g, group in todo:
+            st = self.state[p]
+            if len(st) == 0:    # torch/optim/adam.py _init_group: a host-side step counter, zero moments
+                st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            if id(p) not in self._steps:
+                if st["step"].is_cuda or not st["exp_avg"].is_contiguous() or not st["exp_avg_sq"].is_contiguous():
+                    return self._torch_step(loss)
+                self._steps[id(p)] = int(st["step"])
+            states.append(st)
+        if any(p.numel() == 0 for p, _, _ in todo):   # (an empty tensor keeps its state and its step count like any other; nothing to launch for it)
+            for p, _, _ in todo:
+                if p.numel() == 0:
+                    self._steps[id(p)] += 1
+            keep = [i for i, t in enumerate(todo) if t[0].numel() > 0]
+            todo, states = [todo[i] for i in keep], [states[i] for i in keep]
+        lib = _lib.load()
+        stream = torch._C._cuda_getCurrentRawStream(dev.index)
+        switch = torch.cuda.current_device() != dev.index
+        if switch:
+            prev = torch.cuda.current_device()
+            torch.cuda.set_device(dev)
+        try:
+            for c0 in range(0, len(todo), _MAX):
+                chunk, sts = todo[c0:c0 + _MAX], states[c0:c0 + _MAX]
+                n = len(chunk)
+                key = tuple((p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel())
+                            for (p, g, _), st in zip(chunk, sts))
+                plan = self._plans.get(c0)
+                if plan is None or plan[0] != key:
+                    arr = lambda vals: (C.c_void_p * n)(*vals)
+                    plan = (key, arr(k[0] for k in key), arr(k[1] for k in key), arr(k[2] for k in key), arr(k[3] for k in key),
+                            (C.c_longlong * n)(*(k[4] for k in key)), (C.c_double * n)(), (C.c_longlong * n)())
+                    self._plans[c0] = plan
+                _, ap, ag, am, av, an, alr, ast = plan
+                for i, (p, g, group) in enumerate(chunk):
+                    k = self._steps[id(p)] + 1
+                    self._steps[id(p)] = k
+                    ast[i] = k
+                    alr[i] = group["lr"]
+                _lib.check(lib.sks_adam_multi(n, ap, ag, am, av, an, alr, ast, betas[0], betas[1], eps, stream), "sks_adam_multi")
+        finally:
+            if switch:
+                torch.cuda.set_device(prev)
+        return loss
+
+    def _torch_step(self, loss):
+        self._flush_steps()
+        self._steps = {}
+        super().step()
+        return loss

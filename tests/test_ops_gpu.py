@@ -1,4 +1,5 @@
 """GPU parity of the smaller ops: fused masked-L2, fused SSIM, 3-NN mean distance, and the multi-view loop."""
+import copy
 import math
 import os
 
@@ -1233,3 +1234,77 @@ def test_two_ranks_on_one_gpu_equal_one_rank(device, mode):
     assert one_p.exitcode == 0
     for k, (a, b) in enumerate(zip(two, one)):
         assert np.array_equal(a, b), k
+
+
+def _adam_groups(dev, seed):
+    g = torch.Generator().manual_seed(seed)
+    shapes = {"xyz": (17, 3), "f_dc": (17, 1, 17), "f_rest": (17, 0, 17), "opacity": (17, 1), "scaling": (17, 3), "rotation": (17, 4),
+              "big": (1000, 33)}
+    lrs = {"xyz": 1.6e-1, "f_dc": 2.5e-3, "f_rest": 1.25e-4, "opacity": 2.5e-2, "scaling": 5e-3, "rotation": 1e-3, "big": 1e-2}
+    return [{"params": [torch.nn.Parameter((torch.randn(s, generator=g) * 3).to(dev))], "lr": lrs[n], "name": n} for n, s in shapes.items()]
+
+
+@pytest.mark.gpu
+def test_one_launch_adam_is_torch_adam(device):
+    """skelsplat_amd.optim.Adam (sks_adam_multi: every group in one launch) against torch.optim.Adam as the reference builds it
+    (gaussian_model.py:218: lr = 0, eps = 1e-15, six groups, the xyz group's lr rewritten every iteration): 60 steps, a group
+    that never gets a gradient, one that gets its first gradient late (its own step count), an empty tensor."""
+    from skelsplat_amd.optim import Adam
+    ga, gb = _adam_groups(device, 3), _adam_groups(device, 3)
+    oa, ob = torch.optim.Adam(ga, lr=0.0, eps=1e-15), Adam(gb, lr=0.0, eps=1e-15)
+    gen = torch.Generator().manual_seed(5)
+    for it in range(60):
+        for o in (oa, ob):
+            for grp in o.param_groups:
+                if grp["name"] == "xyz":
+                    grp["lr"] = 1.6e-1 * (0.99 ** it)
+        gen_state = gen.get_state()
+        for o in (oa, ob):
+            gen.set_state(gen_state)
+            for grp in o.param_groups:
+                p = grp["params"][0]
+                if grp["name"] == "f_dc" or (grp["name"] == "rotation" and it < 7):
+                    p.grad = None
+                    continue
+                scale = 1e-4 if grp["name"] == "opacity" else 10.0
+                p.grad = (torch.randn(p.shape, generator=gen) * scale).to(device)
+            o.step()
+            o.zero_grad(set_to_none=True)
+    ob.state_dict()     # (the step counts live in Python ints between steps: any look at the state through the API sees tensors)
+    for a, b in zip(oa.param_groups, ob.param_groups):
+        pa, pb = a["params"][0], b["params"][0]
+        tol = 2e-6 * float(pa.abs().max()) if pa.numel() else 0.0
+        assert torch.allclose(pa, pb, rtol=2e-5, atol=tol), a["name"]
+        if pa in oa.state:
+            assert int(oa.state[pa]["step"]) == int(ob.state[pb]["step"]) == (53 if a["name"] == "rotation" else 60)
+            assert torch.allclose(oa.state[pa]["exp_avg_sq"], ob.state[pb]["exp_avg_sq"], rtol=2e-5, atol=1e-12)
+        else:
+            assert pb not in ob.state and a["name"] == "f_dc"
+    # the state goes through state_dict() into a plain torch.optim.Adam and back: both continue alike
+    gc = _adam_groups(device, 3)
+    for src, dst in zip(gb, gc):
+        dst["params"][0].data.copy_(src["params"][0].data)
+    oc = torch.optim.Adam(gc, lr=0.0, eps=1e-15)
+    oc.load_state_dict(copy.deepcopy(ob.state_dict()))     # (load_state_dict keeps tensors that already have the right dtype and device: no aliasing)
+    for o in (ob, oc):
+        for grp in o.param_groups:
+            p = grp["params"][0]
+            p.grad = torch.full_like(p, 0.5)
+        o.step()
+    for b, c in zip(ob.param_groups, oc.param_groups):
+        pb, pc = b["params"][0], c["params"][0]
+        assert torch.allclose(pb, pc, rtol=2e-5, atol=2e-6 * float(pb.abs().max()) if pb.numel() else 0.0), b["name"]
+
+
+@pytest.mark.gpu
+def test_one_launch_adam_leaves_torch_what_is_torchs(device):
+    """Weight decay / amsgrad are not this kernel's: those steps are torch's own, bit for bit."""
+    from skelsplat_amd.optim import Adam
+    for kw in (dict(weight_decay=0.1), dict(amsgrad=True)):
+        pa = torch.nn.Parameter(torch.arange(12.0, device=device).reshape(3, 4))
+        pb = torch.nn.Parameter(pa.detach().clone())
+        oa, ob = torch.optim.Adam([pa], lr=1e-2, foreach=False, **kw), Adam([pb], lr=1e-2, **kw)
+        for _ in range(3):
+            pa.grad, pb.grad = torch.ones_like(pa), torch.ones_like(pb)
+            oa.step(), ob.step()
+        assert torch.equal(pa, pb)
