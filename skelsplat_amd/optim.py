@@ -7,8 +7,9 @@ parameter, so `state_dict()` / `load_state_dict()` / the reference's `capture()`
 parameters read from `param_groups` at every step (the reference rewrites `lr` of the "xyz" group every iteration,
 gaussian_model.py:234-239) -- is one C-ABI call.  Drop-in: `self.optimizer = skelsplat_amd.optim.Adam(l, lr=0.0, eps=1e-15)`.
 
-What is not this kernel's (amsgrad, weight decay, maximize, sparse or non-fp32 gradients, CPU tensors) goes to torch's own step()
-unchanged: the class is a torch.optim.Adam in every other respect."""
+What is not this kernel's is REFUSED, not handed to another implementation: amsgrad / weight decay / maximize / capturable /
+differentiable at construction (NotImplementedError), CPU or non-fp32 parameters, sparse or strided gradients at step()
+(RuntimeError) -- `torch.optim.Adam` is the class for those.  There is no fall-back path."""
 import ctypes as C
 
 import torch
@@ -45,16 +46,23 @@ class Adam(torch.optim.Adam):
         self._reset_cache()
         return r
 
+    @staticmethod
+    def _check_group(group):
+        bad = [k for k in ("amsgrad", "maximize", "capturable", "differentiable") if group.get(k)]
+        if group.get("weight_decay", 0) != 0:
+            bad.append("weight_decay")
+        if isinstance(group.get("lr"), torch.Tensor):
+            bad.append("a tensor lr")
+        if bad:
+            raise NotImplementedError(f"skelsplat_amd.optim.Adam: {', '.join(bad)} not supported (sks_adam_multi is the plain update "
+                                      f"of scene/gaussian_model.py:218); use torch.optim.Adam")
+
     def add_param_group(self, group):
         r = super().add_param_group(group)
+        self._check_group(self.param_groups[-1])
         if hasattr(self, "_plans"):
             self._plans = {}
         return r
-
-    @staticmethod
-    def _ours(group):
-        return not (group["amsgrad"] or group["weight_decay"] != 0 or group.get("maximize") or group.get("capturable")
-                    or group.get("differentiable") or isinstance(group["lr"], torch.Tensor))
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -65,20 +73,23 @@ class Adam(torch.optim.Adam):
         todo = []       # (param, grad, group)
         dev = betas = eps = None
         for group in self.param_groups:
-            ours = None
+            first = True
             for p in group["params"]:
                 g = p.grad
                 if g is None:
                     continue
-                if ours is None:
-                    ours = self._ours(group)
+                if first:
+                    first = False
+                    self._check_group(group)     # (param_groups is the caller's to rewrite between steps)
                     if dev is None:
                         dev, betas, eps = p.device, group["betas"], group["eps"]
-                    if not ours or group["betas"] != betas or group["eps"] != eps:
-                        return self._torch_step(loss)
+                    if group["betas"] != betas or group["eps"] != eps:
+                        raise NotImplementedError("skelsplat_amd.optim.Adam: one (betas, eps) for all parameter groups")
                 if not (p.is_cuda and p.device == dev and g.device == dev and p.dtype == torch.float32 and g.dtype == torch.float32
                         and g.layout == torch.strided and p.is_contiguous() and g.is_contiguous()):
-                    return self._torch_step(loss)
+                    raise RuntimeError("skelsplat_amd.optim.Adam: contiguous fp32 parameters and gradients on ONE ROCm device "
+                                       f"(group {group.get('name', '?')}: {p.dtype} on {p.device}, gradient {g.dtype} {g.layout}); "
+                                       "there is no CPU path -- torch.optim.Adam is the class for anything else")
                 todo.append((p, g, group))
         if not todo:
             return loss
@@ -91,7 +102,8 @@ class Adam(torch.optim.Adam):
                 st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
             if id(p) not in self._steps:
                 if st["step"].is_cuda or not st["exp_avg"].is_contiguous() or not st["exp_avg_sq"].is_contiguous():
-                    return self._torch_step(loss)
+                    raise RuntimeError("skelsplat_amd.optim.Adam: a loaded state with a device-side step counter or strided moments "
+                                       "(saved by a capturable / fused optimiser?)")
                 self._steps[id(p)] = int(st["step"])
             states.append(st)
         if any(p.numel() == 0 for p, _, _ in todo):   # (an empty tensor keeps its state and its step count like any other; nothing to launch for it)
@@ -128,10 +140,4 @@ class Adam(torch.optim.Adam):
         finally:
             if switch:
                 torch.cuda.set_device(prev)
-        return loss
-
-    def _torch_step(self, loss):
-        self._flush_steps()
-        self._steps = {}
-        super().step()
         return loss

@@ -1297,14 +1297,15 @@ def test_one_launch_adam_is_torch_adam(device):
 
 
 @pytest.mark.gpu
-def test_one_launch_adam_leaves_torch_what_is_torchs(device):
-    """Weight decay / amsgrad are not this kernel's: those steps are torch's own, bit for bit."""
+def test_one_launch_adam_refuses_what_its_kernel_does_not_do(device):
+    """No fall-back: options the kernel does not implement are refused at construction, CPU / non-fp32 tensors at step()."""
     from skelsplat_amd.optim import Adam
-    for kw in (dict(weight_decay=0.1), dict(amsgrad=True)):
-        pa = torch.nn.Parameter(torch.arange(12.0, device=device).reshape(3, 4))
-        pb = torch.nn.Parameter(pa.detach().clone())
-        oa, ob = torch.optim.Adam([pa], lr=1e-2, foreach=False, **kw), Adam([pb], lr=1e-2, **kw)
-        for _ in range(3):
-            pa.grad, pb.grad = torch.ones_like(pa), torch.ones_like(pb)
-            oa.step(), ob.step()
-        assert torch.equal(pa, pb)
+    for kw in (dict(weight_decay=0.1), dict(amsgrad=True), dict(maximize=True)):
+        with pytest.raises(NotImplementedError):
+            Adam([torch.nn.Parameter(torch.ones(3, device=device))], lr=1e-2, **kw)
+    for p in (torch.nn.Parameter(torch.ones(3)), torch.nn.Parameter(torch.ones(3, device=device, dtype=torch.float64))):
+        o = Adam([p], lr=1e-2)
+        p.grad = torch.ones_like(p)
+        with pytest.raises(RuntimeError, match="ROCm"):
+            o.step()
+        assert torch.equal(p.detach().cpu(), torch.ones(3, dtype=p.dtype)) and len(o.state[p]) == 0     # nothing was touched
