@@ -175,7 +175,7 @@ class ApiStep:
         every rank issues the same number of steps whatever it tunes, so the collectives stay matched."""
         if os.environ.get("SKS_BENCH_AUTOTUNE", "1") == "0":
             return None
-        cands, reps, rounds = (0, 3, 4, 5), 16, 3
+        cands, reps, rounds = self.R.TUNE_CANDIDATES, 16, 3
         self()          # (the first call records the argument lists the tuner times)
         self()
         if self.views is None or self.ws._plans.get("fwd") is None:
@@ -183,7 +183,9 @@ class ApiStep:
                 self()
             return None
         best, med = self.R.autotune_fill_passes(self.ws, self, cands, reps, rounds)
-        self.tuned = {"fill_passes_per_block": best or "default (2)", "median_us_by_candidate": {str(k): round(v, 2) for k, v in med.items()}}
+        self.tuned = {"fill_role": self.R.tune_name(best), "fill_passes_per_block": (best & 0xff) or "default (2)",
+                      "stores": "plain" if best & self.R.PLAIN_STORES else "non-temporal",
+                      "median_us_by_candidate": {self.R.tune_name(k): round(v, 2) for k, v in med.items()}}
         return self.tuned
 
     tuned = None

@@ -733,25 +733,45 @@ def forward_backward_views(views: ViewBatch, means3D, features, opacities, scale
     return out + (g,)
 
 
-def autotune_fill_passes(workspace, step_fn, candidates=(0, 3, 4, 5), reps=8, rounds=3):
-    """Picks the forward's fill-block size (4 KB passes -- or rows, on row-aligned widths -- per fill block: bits 8..15 of the
-    flags, 0 = the library's default of two) for the step `step_fn` issues through `workspace`'s RECORDED forward, by timing it.
+PLAIN_STORES = 0x100     # a tuner candidate's bit 8: plain stores instead of non-temporal ones (SKS_NO_NT_STORES)
+TUNE_CANDIDATES = (0, 3, 4, 5, PLAIN_STORES | 3, PLAIN_STORES | 4, PLAIN_STORES | 5)
+
+
+def _tune_flag_bits(c):
+    return ((int(c) & 0xff) << 8) | (_lib.SKS_NO_NT_STORES if int(c) & PLAIN_STORES else 0)
+
+
+def tune_name(c):
+    """A tuner candidate in words ("default (2 passes, non-temporal)", "4 passes, plain stores")."""
+    if not c:
+        return "default (2 passes, non-temporal stores)"
+    return f"{int(c) & 0xff or 2} passes, {'plain' if int(c) & PLAIN_STORES else 'non-temporal'} stores"
+
+
+def autotune_fill_passes(workspace, step_fn, candidates=TUNE_CANDIDATES, reps=8, rounds=3):
+    """Picks how the forward's fill role writes -- 4 KB passes (or rows, on row-aligned widths) per fill block (bits 0..7 of a
+    candidate -> bits 8..15 of the flags, 0 = the library's default of two) and the KIND of store (candidate bit 8, PLAIN_STORES ->
+    SKS_NO_NT_STORES) -- for the step `step_fn` issues through `workspace`'s RECORDED forward, by timing it.
     Why per step and at run time: the fill role is bound by the life time of its ~36 000 blocks, and what shares the chip with them
     decides the best size -- two passes when the forward runs alone (sks_forward, then sks_backward), three for the H36M step
-    through sks_forward_backward (the backward's wavefronts hold slots beside it: 61.6 -> 57.8 us), four for all 31 Panoptic views,
-    five for four of them (NOTES_experiments.md, round 5); none of it moves a result bit.  `step_fn()` is called
-    len(candidates) x rounds x (2 + reps) times with device synchronisations in between (once, before a long loop); the
+    through sks_forward_backward (the backward's wavefronts hold slots beside it), four for all 31 Panoptic views, five for four of
+    them.  And the store kind decides where the zeros go first: non-temporal stores stream past the 256 MB Infinity Cache
+    to HBM; plain stores may stay in it, so a call that writes the SAME output buffers step after step (a Workspace) and about
+    that many bytes hands them over at the cache's rate while the previous step's lines drain behind it -- H36M (288 MB per
+    call): forward 46.7 -> 38.0 us with plain stores and four passes; Panoptic (663 MB for four views, 5.1 GB for 31) and the
+    stress scene: 40 % SLOWER with plain stores (NOTES_experiments.md, round 5).  None of it moves a result bit.  `step_fn()` is
+    called len(candidates) x rounds x (2 + reps) times with device synchronisations in between (once, before a long loop); the
     candidates are interleaved round-robin and judged by their median.  Returns (best, {candidate: median microseconds})."""
     import time
     plan = workspace._plans.get("fwd")
     if plan is None or torch.cuda.is_current_stream_capturing():
         return None, {}
     args, dev_index = plan[2], plan[3]
-    base = args[16] & ~(0xff << 8)
+    base = args[16] & ~(0xff << 8) & ~_lib.SKS_NO_NT_STORES
     times = {c: [] for c in candidates}
     for _ in range(rounds):
         for c in candidates:
-            args[16] = base | ((int(c) & 0xff) << 8)
+            args[16] = base | _tune_flag_bits(c)
             for _ in range(2):
                 step_fn()
             torch.cuda.synchronize(dev_index)
@@ -764,7 +784,7 @@ def autotune_fill_passes(workspace, step_fn, candidates=(0, 3, 4, 5), reps=8, ro
     best = min(med, key=med.get)
     if med[best] > 0.99 * med[candidates[0]]:      # (within the noise of the first candidate: keep that one)
         best = candidates[0]
-    args[16] = base | ((int(best) & 0xff) << 8)
+    args[16] = base | _tune_flag_bits(best)
     return best, med
 
 

@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from tests import util
-from skelsplat_amd import rasterizer as R
+from skelsplat_amd import _lib, rasterizer as R
 from oracle import oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -1237,8 +1237,8 @@ def test_any_number_of_channels_through_the_generic_path(device):
 
 
 def test_autotuned_fill_block_size_changes_no_bit(device):
-    """rasterizer.autotune_fill_passes times the caller's step under 2 / 3 / 4 / 5 passes per fill block and patches the recorded
-    argument block: whatever it picks, images and gradients stay bit for bit what the default gives (the knob only regroups the
+    """rasterizer.autotune_fill_passes times the caller's step under 2 / 3 / 4 / 5 passes per fill block, with non-temporal and with
+    plain stores, and patches the recorded argument block: whatever it picks, images and gradients stay bit for bit what the default gives (the knob only regroups the
     forward's zero-fill blocks), and the choice survives the following replays."""
     c = util.make_case(seed=12, W=1000, H=96, scale_log=4.2, n_views=2)      # (W = 1000: the linear fill mode the knob belongs to)
     views = R.ViewBatch.from_cameras([cam.to(device) for cam in c.cams])
@@ -1249,11 +1249,12 @@ def test_autotuned_fill_block_size_changes_no_bit(device):
     ws = R.Workspace()
     step = lambda: R.forward_backward_views(views, *args, dL, workspace=ws)
     step(), step()
-    best, med = R.autotune_fill_passes(ws, step, candidates=(0, 3, 4, 5), reps=4, rounds=2)
-    assert best in (0, 3, 4, 5) and set(med) == {0, 3, 4, 5} and all(v > 0 for v in med.values())
-    assert (ws._plans["fwd"][2][16] >> 8) & 0xff == best
-    for forced in (best, 1, 5, 7):
-        ws._plans["fwd"][2][16] = (ws._plans["fwd"][2][16] & ~(0xff << 8)) | (forced << 8)
+    best, med = R.autotune_fill_passes(ws, step, reps=4, rounds=2)
+    assert best in R.TUNE_CANDIDATES and set(med) == set(R.TUNE_CANDIDATES) and all(v > 0 for v in med.values())
+    flags = ws._plans["fwd"][2][16]
+    assert (flags >> 8) & 0xff == best & 0xff and bool(flags & _lib.SKS_NO_NT_STORES) == bool(best & R.PLAIN_STORES)
+    for forced in (best, 1, 5, 7, R.PLAIN_STORES | 2, R.PLAIN_STORES | 4):     # (passes per block x store kind)
+        ws._plans["fwd"][2][16] = (flags & ~(0xff << 8) & ~_lib.SKS_NO_NT_STORES) | R._tune_flag_bits(forced)
         col, inv, rad, st, g = step()
         torch.cuda.synchronize()
         assert torch.equal(col, col0) and torch.equal(inv, inv0) and torch.equal(rad, rad0), forced
