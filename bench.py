@@ -323,17 +323,20 @@ def roofline_entry(alg_bytes, prof_fwd, wl_name, launches, kernel="k_render_fwd_
             "launches_timed": fwd_n, "launches": launches, "algorithmic_bytes_per_launch": alg_bytes}
 
 
-def zero_fill_us(torch, n_floats, dev, sync):
-    """The box's own ceiling for a forward's bytes, in the same run: median duration of tensor.zero_() of a buffer that size."""
+def zero_fill_us(torch, n_floats, dev, sync, rotate=1):
+    """The box's own ceiling for a forward's bytes, in the same run: median duration of tensor.zero_() of a buffer that size.
+    rotate > 1: over that many buffers in turn -- the same buffer again and again lets the 256 MB Infinity Cache hold back part of
+    the stores (288 MB: 41 us); on memory the kernel has not just written (8 buffers = 2.3 GB) the same call takes 45-46 us: the
+    rate HBM itself takes."""
     try:
-        zbuf = torch.empty(int(n_floats), device=dev)
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(12)]
-        for a_, b_ in evs:
+        zbufs = [torch.empty(int(n_floats), device=dev) for _ in range(rotate)]
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(max(12, 3 * rotate))]
+        for i, (a_, b_) in enumerate(evs):
             a_.record()
-            zbuf.zero_()
+            zbufs[i % rotate].zero_()
             b_.record()
         sync()
-        zt = sorted(a_.elapsed_time(b_) for a_, b_ in evs[2:])
+        zt = sorted(a_.elapsed_time(b_) for a_, b_ in evs[max(2, rotate):])
         return 1e3 * zt[len(zt) // 2]
     except Exception:
         return None
@@ -425,9 +428,11 @@ def run_single(args, torch, dev, wl):
         step2, dt2, out2, pf2 = measure(False)
         assert torch.equal(out, out2)                      # (bit for bit the same gradients either way)
     pb = None
-    zero_us = None
+    zero_us = zero_fresh_us = None
     if prof:
         zero_us = zero_fill_us(torch, V * (C + 1) * H * W, dev, sync)
+        nbytes_out = 4.0 * V * (C + 1) * H * W
+        zero_fresh_us = zero_fill_us(torch, V * (C + 1) * H * W, dev, sync, rotate=8) if nbytes_out < 1.2e9 else None
         alone = step2 if step2 is not None else step
         _lib.prof_enable(True, every=1, kinds=(1,))     # the backward compositor: a few untimed steps behind the timed regions
         _lib.prof_read(1)
@@ -476,6 +481,10 @@ def run_single(args, torch, dev, wl):
                 res["roofline"]["traffic_source"] = ("measured in this run: rocprofv3 --pmc WRITE_SIZE / --pmc FETCH_SIZE (separate child "
                                                      "passes over tools/one_call_step.py, KiB units, FETCH_SIZE doubled for gfx950)")
                 res["roofline"]["traffic_over_algorithmic"] = tb / res["roofline"]["algorithmic_bytes_per_launch"]
+        if zero_us and zero_fresh_us:
+            # what HBM itself takes: zero_() over 8 buffers in turn (2.3 GB), no help from the Infinity Cache
+            res["roofline"]["zero_fill_fresh_memory_us"] = zero_fresh_us
+            res["roofline"]["hbm_write_rate_by_zero_fill_GBps"] = nbytes_out / zero_fresh_us / 1e3
         if zero_us:
             res["roofline"]["zero_fill_same_bytes_us"] = zero_us
             res["roofline"]["frac_of_zero_fill"] = zero_us / (1e3 * pf[2][1])     # (median launch against the median zero_())
