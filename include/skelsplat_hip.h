@@ -41,8 +41,11 @@ extern "C" {
 #define SKS_DEBUG_SYNC   8u   /* raster_settings.debug: hipStreamSynchronize + error check after each stage
                                  (CHECK_CUDA, DGR/cuda_rasterizer/auxiliary.h:178-185) */
 
-#define SKS_NO_NT_STORES 16u  /* tuning: plain instead of non-temporal stores for the dense forward planes
-                                 (non-temporal is the default: the planes are written once and read by another kernel) */
+#define SKS_NO_NT_STORES 16u  /* tuning: plain instead of non-temporal stores for the dense forward planes.  Non-temporal (the
+                                 default) streams past the 256 MB Infinity Cache at the rate HBM takes writes; plain stores may
+                                 stay in it: faster where a call rewrites the same ~cache-sized output step after step and
+                                 nothing runs beside it (H36M: 46.5 -> 38-41 us), 40 % slower on outputs many times the cache.
+                                 No result bit depends on it (rasterizer.autotune_fill_passes times both) */
 
 /* tuning: bits 8..15 of `flags` = 4 KB passes per fill block of the fused forward (0 = automatic) */
 #define SKS_RAW_PARAMS   32u   /* opacities / scales / rotations are the LEAF parameters (_opacity logits, _scaling
