@@ -25,6 +25,8 @@ def timed(fn, n):
 
 for name, wl, ids, n in (("h36m 4 views", bench.WORKLOADS["h36m"], None, 300), ("panoptic rank 0 of 8 (4 views)", bench.WORKLOADS["panoptic"], [0, 8, 16, 24], 200),
                          ("panoptic 31 views", bench.WORKLOADS["panoptic"], None, 40)):
+    if os.environ.get("ONLY") and os.environ["ONLY"] not in name:
+        continue
     scene, gm, params = bench.make_scene(torch, wl, dev)
     cams = scene.cameras if ids is None else [scene.cameras[v] for v in ids]
     views = R.ViewBatch.from_cameras(cams)
