@@ -295,14 +295,15 @@ int sks_forward(int V, int P, int C, int W, int H, const float* viewmatrix, cons
         // (nothing to clear: k_geom_fwd zeroes the header, k_bin_band_count writes every tile's count)
     }
     if (!small) g.cover = nullptr;   // (the binned path's cover rows are per plane: Bin::coverp, k_bin_scan + k_bin_sort_long)
-    const int gthreads = small ? ((g.cover && cover_per_plane(P, W, H, C)) ? SKS_GEOM_COVER_THREADS : 256) : SKS_GEOM_BINNED_THREADS;
+    const int gthreads = small ? 256 : SKS_GEOM_BINNED_THREADS;
+    const int gplanes = (small && g.cover && cover_per_plane(P, W, H, C)) ? C + 1 : 1;     // a block per plane's cover rows
     if (tl_fused_bwd && small && tl_fused_bwd->geom_done)
-        hipExtLaunchKernelGGL(k_geom_fwd, dim3((P + gthreads - 1) / gthreads, V), dim3(gthreads), 0, st, nullptr, tl_fused_bwd->geom_done, 0,
+        hipExtLaunchKernelGGL(k_geom_fwd, dim3((P + gthreads - 1) / gthreads, V, gplanes), dim3(gthreads), 0, st, nullptr, tl_fused_bwd->geom_done, 0,
                               P, W, H, vt, viewmatrix, projmatrix, means3D, opacities, scales, rotations, cov3D_precomp, scale_modifier,
                               flags, g, radii, 0, (uint32_t*)nullptr, (uint32_t*)nullptr, features, C, (uint2*)nullptr, (uint32_t*)nullptr,
                               cover_per_plane(P, W, H, C) ? 1 : 0);
     else
-    hipLaunchKernelGGL(k_geom_fwd, dim3((P + gthreads - 1) / gthreads, V), dim3(gthreads), 0, st, P, W, H, vt, viewmatrix, projmatrix,
+    hipLaunchKernelGGL(k_geom_fwd, dim3((P + gthreads - 1) / gthreads, V, gplanes), dim3(gthreads), 0, st, P, W, H, vt, viewmatrix, projmatrix,
                        means3D, opacities, scales, rotations, cov3D_precomp, scale_modifier, flags, g, radii, 0,
                        small ? (uint32_t*)nullptr : b.count, small ? (uint32_t*)nullptr : b.touched, features, C,
                        small ? (uint2*)nullptr : b.fmask, small ? (uint32_t*)nullptr : b.hdr, (small && cover_per_plane(P, W, H, C)) ? 1 : 0);
