@@ -363,12 +363,16 @@ def fresh_model(scene, dataset, dev):
 
 
 def loop_ms(torch, loop, n, sync):
-    for _ in range(3):
-        loop.step_group()
+    """ms per accumulation group of a loop that does nothing but step: consecutive groups chained as loop.run() chains them (the
+    fused step's tail leaves the next group's geometry behind; a step_group() on its own would recompute it from the parameters)"""
+    kw = {"parameters_untouched": True} if "parameters_untouched" in loop.step_group.__code__.co_varnames else {}
+    loop.step_group()
+    for _ in range(2):
+        loop.step_group(**kw)
     sync()
     t0 = time.perf_counter()
     for _ in range(n):
-        loop.step_group()
+        loop.step_group(**kw)
     sync()
     return 1e3 * (time.perf_counter() - t0) / n
 

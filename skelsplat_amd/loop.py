@@ -516,8 +516,13 @@ class MultiViewLoop:
                 return mask, v, k + 1
         return group_mask, last_view, n_iters
 
-    def step_group(self):
-        """Runs iterations self.iteration+1 .. up to the next optimiser step (train.py:130-222)."""
+    def step_group(self, parameters_untouched=False):
+        """Runs iterations self.iteration+1 .. up to the next optimiser step (train.py:130-222).
+        parameters_untouched=True: the caller states that nothing has written the parameters since this object's previous
+        step_group() -- the fused step's tail left the geometry of the updated parameters behind, and this step then starts from
+        it instead of launching a geometry pass of its own (what run() does between its own consecutive groups, and what a
+        captured graph of several groups does inside).  There is no way to see a write through `.data` or a raw pointer from here,
+        so the default is to recompute."""
         gm = self.gm
         it0 = self.iteration + 1
         it1 = it0
@@ -541,7 +546,8 @@ class MultiViewLoop:
                     self._graph = (key, graph)      # the capture itself does not execute: replay below
                 self._graph[1].replay()
             else:
-                self._geom_valid = False    # eager steps never assume the parameters were left untouched since the last one
+                if not parameters_untouched:
+                    self._geom_valid = False    # eager steps never assume the parameters were left untouched since the last one
                 self._device_group(*key)
             if self._es_device:
                 self._poll_stop()           # (never waits: the groups enqueued behind a stop do nothing to the parameters)
@@ -614,8 +620,10 @@ class MultiViewLoop:
                     remaining -= G
                     if self._es_device:
                         self._poll_stop()
+        chained = False       # (between run()'s own consecutive groups nobody else touches the parameters)
         while self.iteration < iterations and self.stopped_at is None:
-            self.step_group()
+            self.step_group(parameters_untouched=chained)
+            chained = True
         if self.device_tail and self._es_device and self.stopped_at is None:
             self._poll_stop(wait=True)      # the ONE synchronisation of a scene with the criterion on the device
         return self.gm._xyz.detach()
@@ -779,8 +787,9 @@ class FrameBatchLoop:
         s = self._sums.view(self.F, self.V, 2)
         self.last_losses = (s[..., 0], s[..., 1])       # per (frame, view) {S, N}: loss = S / N
 
-    def step_group(self):
-        """Iterations self.iteration+1 .. the next optimiser step of EVERY frame (train.py:130-222; the frames share the
+    def step_group(self, parameters_untouched=False):
+        """(parameters_untouched: as MultiViewLoop.step_group)
+        Iterations self.iteration+1 .. the next optimiser step of EVERY frame (train.py:130-222; the frames share the
         iteration counter, the view order and therefore the group's view mask)."""
         it0 = self.iteration + 1
         it1 = it0
@@ -800,7 +809,8 @@ class FrameBatchLoop:
                 self._graph = (key, graph)
             self._graph[1].replay()
         else:
-            self._geom_valid = False
+            if not parameters_untouched:
+                self._geom_valid = False
             self._device_group(*key)
         self.iteration = it1
         return it1
@@ -828,8 +838,10 @@ class FrameBatchLoop:
                     self._multi[1].replay()
                     self.iteration += G * self.acc_steps
                     remaining -= G
+        chained = False
         while self.iteration < iterations:
-            self.step_group()
+            self.step_group(parameters_untouched=chained)
+            chained = True
         return self.xyz
 
     def optimize_sequence(self, points, poses_2d, iterations=500, groups_per_graph=25):

@@ -1309,3 +1309,46 @@ def test_one_launch_adam_refuses_what_its_kernel_does_not_do(device):
         with pytest.raises(RuntimeError, match="ROCm"):
             o.step()
         assert torch.equal(p.detach().cpu(), torch.ones(3, dtype=p.dtype)) and len(o.state[p]) == 0     # nothing was touched
+
+
+@pytest.mark.gpu
+def test_chained_eager_steps_start_from_the_tails_geometry(device, monkeypatch):
+    """The fused step's tail leaves the geometry of the UPDATED parameters behind.  run() chains its own eager groups on it (one
+    geometry launch for the whole run), step_group(parameters_untouched=True) does on the caller's word; a plain step_group()
+    recomputes it -- a write through `.data` between two steps is invisible from inside.  Bit for bit the same trajectory."""
+    from skelsplat_amd import loop as L
+    from skelsplat_amd.heatmaps import generate_heatmaps
+    sc, model = _make_loop_scene(device, seed=9)
+    calls = {"n": 0}
+    real = L.R.geometry_views
+
+    def counted(*a, **kw):
+        calls["n"] += 1
+        return real(*a, **kw)
+    monkeypatch.setattr(L.R, "geometry_views", counted)
+    loops = []
+    for _ in range(3):
+        gm = model(device)
+        hm = generate_heatmaps(gm._xyz.detach(), gm.get_scaling.detach(), gm._rotation.detach(),
+                               torch.tensor(sc.poses_2d, device=device), sc.cameras)
+        loops.append(L.MultiViewLoop(gm, sc.cameras, hm, dataset="h36m", sparse=True))
+    a, b, c = loops
+    assert a.fused_tail and not a.use_graph
+    n0 = calls["n"]
+    a.run(24)                                   # 6 groups, chained
+    assert calls["n"] - n0 == 1
+    n0 = calls["n"]
+    for _ in range(6):
+        b.step_group()                          # on its own: geometry from the parameters every time
+    assert calls["n"] - n0 == 6
+    n0 = calls["n"]
+    for k in range(6):
+        c.step_group(parameters_untouched=k > 0)
+    assert calls["n"] - n0 == 1
+    for pa, pb, pc in zip(*[(l.gm._xyz, l.gm._scaling, l.gm._rotation, l.gm._opacity) for l in loops]):
+        assert torch.equal(pa, pb) and torch.equal(pa, pc)
+    # a write between steps: the plain call sees it, because it looks at nothing but the parameters
+    with torch.no_grad():
+        a.gm._xyz.data.add_(3.0), b.gm._xyz.data.add_(3.0)
+    a.step_group(), b.step_group()
+    assert torch.equal(a.gm._xyz, b.gm._xyz)
