@@ -194,6 +194,7 @@ class MultiViewLoop:
             graph_collectives = os.environ.get("SKS_GRAPH_COLLECTIVES") == "1"
         self.use_graph = bool(use_graph) and self.device_tail and (not self.exchange or bool(graph_collectives))
         self._graph = None
+        self._graphs = {}
         # sparse fused step: render + clamp + masked-L2 + backward only on the tiles some Gaussian rect covers, using
         # per-view statistics of the constant heat-maps (sks_gt_tile_stats); no dense image / gradient is ever written
         if sparse is None:
@@ -537,14 +538,20 @@ class MultiViewLoop:
                 mask |= 1 << v
             key = (mask, view_of_iter[-1], it1 - it0 + 1)
             if self.use_graph:
-                if self._graph is None or self._graph[0] != key:
+                # (two graphs per group shape: one that first refreshes the geometry from the parameters, one -- replayed on the
+                # caller's word, parameters_untouched -- that starts from what the previous group's tail left)
+                chained = bool(parameters_untouched and self.fused_tail and self._geom_valid)
+                gkey = key + (chained,)
+                if self._graphs.get(gkey) is None:
                     # capture one group; replays advance the device counters themselves
                     graph = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(graph):
-                        self._geom_valid = False    # (see run(): a replay never assumes who ran before it)
+                        if not chained:
+                            self._geom_valid = False    # (see run(): a replay never assumes who ran before it)
                         self._device_group(*key)
-                    self._graph = (key, graph)      # the capture itself does not execute: replay below
-                self._graph[1].replay()
+                    self._graphs[gkey] = graph          # the capture itself does not execute: replay below
+                self._graphs[gkey].replay()
+                self._graph = (key, self._graphs[gkey])
             else:
                 if not parameters_untouched:
                     self._geom_valid = False    # eager steps never assume the parameters were left untouched since the last one

@@ -1327,13 +1327,16 @@ def test_chained_eager_steps_start_from_the_tails_geometry(device, monkeypatch):
         return real(*a, **kw)
     monkeypatch.setattr(L.R, "geometry_views", counted)
     loops = []
-    for _ in range(3):
+    for k in range(4):
         gm = model(device)
         hm = generate_heatmaps(gm._xyz.detach(), gm.get_scaling.detach(), gm._rotation.detach(),
                                torch.tensor(sc.poses_2d, device=device), sc.cameras)
-        loops.append(L.MultiViewLoop(gm, sc.cameras, hm, dataset="h36m", sparse=True))
-    a, b, c = loops
-    assert a.fused_tail and not a.use_graph
+        loops.append(L.MultiViewLoop(gm, sc.cameras, hm, dataset="h36m", sparse=True, use_graph=k == 3))
+    a, b, c, d = loops
+    assert a.fused_tail and not a.use_graph and d.use_graph
+    for k in range(6):                          # one captured graph per group: the chained ones are a second graph, without geometry
+        d.step_group(parameters_untouched=k > 0)
+    assert len(d._graphs) == 2
     n0 = calls["n"]
     a.run(24)                                   # 6 groups, chained
     assert calls["n"] - n0 == 1
@@ -1345,8 +1348,8 @@ def test_chained_eager_steps_start_from_the_tails_geometry(device, monkeypatch):
     for k in range(6):
         c.step_group(parameters_untouched=k > 0)
     assert calls["n"] - n0 == 1
-    for pa, pb, pc in zip(*[(l.gm._xyz, l.gm._scaling, l.gm._rotation, l.gm._opacity) for l in loops]):
-        assert torch.equal(pa, pb) and torch.equal(pa, pc)
+    for pa, pb, pc, pd in zip(*[(l.gm._xyz, l.gm._scaling, l.gm._rotation, l.gm._opacity) for l in loops]):
+        assert torch.equal(pa, pb) and torch.equal(pa, pc) and torch.equal(pa, pd)
     # a write between steps: the plain call sees it, because it looks at nothing but the parameters
     with torch.no_grad():
         a.gm._xyz.data.add_(3.0), b.gm._xyz.data.add_(3.0)
