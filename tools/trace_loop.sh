@@ -1,6 +1,6 @@
 #!/bin/bash
 # Kernel timeline of the sparse training loop's accumulation groups (MultiViewLoop.step_group, H36M 4 views) under rocprofv3
-# --kernel-trace: what one "grad step" (bench.py grad_step_ms) is made of.   bash tools/trace_loop.sh   (GPU box)
+# --kernel-trace: what one "grad step" (bench.py grad_step_ms) is made of.   [UNCHAINED=1] bash tools/trace_loop.sh   (GPU box)
 root=$(cd "$(dirname "$0")/.." && pwd)
 cd /tmp && export TMPDIR=/tmp
 cat > /tmp/trl.py <<PY
@@ -14,8 +14,11 @@ scene, gm, params = bench.make_scene(torch, wl, dev)
 gm.training_setup()
 hm = generate_heatmaps(gm._xyz.detach(), gm.get_scaling.detach(), gm._rotation.detach(), torch.tensor(scene.poses_2d, device=dev), scene.cameras)
 loop = MultiViewLoop(bench.fresh_model(scene, "h36m", dev), scene.cameras, hm, dataset="h36m", accumulation_steps=4, sparse=True)
-for _ in range(40):
-    loop.step_group()
+if "$UNCHAINED" == "1":
+    for _ in range(40):
+        loop.step_group()          # each on its own: geometry from the parameters in front of every group
+else:
+    loop.run(160)                  # 40 groups, chained on the geometry the previous group's tail left
 torch.cuda.synchronize()
 PY
 rm -rf /tmp/trl && rocprofv3 --kernel-trace --output-format csv -d /tmp/trl -o t -- python3 /tmp/trl.py > /dev/null 2>&1
