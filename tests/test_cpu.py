@@ -689,3 +689,21 @@ def test_oracle_rounding_scale_dominates_the_gradients():
         bad[worst] += 1e-2 * b["bound"][k][worst]
         with pytest.raises(AssertionError):
             util.assert_close_bound(k, bad, b[k], b["bound"][k])
+
+
+def test_one_launch_adam_has_no_cpu_path():
+    """skelsplat_amd.optim.Adam is a torch.optim.Adam whose step() is one HIP launch: what that kernel does not do is refused at
+    construction, CPU parameters at step() -- nothing is handed to another implementation (the ROCm side: tests/test_ops_gpu.py)."""
+    import torch
+    from skelsplat_amd.optim import Adam
+    for kw in (dict(weight_decay=0.1), dict(amsgrad=True), dict(maximize=True)):
+        with pytest.raises(NotImplementedError):
+            Adam([torch.nn.Parameter(torch.ones(3))], lr=1e-2, **kw)
+    p = torch.nn.Parameter(torch.ones(3))
+    o = Adam([{"params": [p], "lr": 0.1, "name": "xyz"}], lr=0.0, eps=1e-15)
+    assert isinstance(o, torch.optim.Adam) and o.param_groups[0]["name"] == "xyz"
+    o.step()                                    # no gradient anywhere: nothing to do, nothing to refuse
+    p.grad = torch.ones(3)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        o.step()
+    assert torch.equal(p.detach(), torch.ones(3)) and len(o.state[p]) == 0
