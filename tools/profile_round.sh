@@ -13,9 +13,9 @@ for WL in h36m panoptic; do
   # per-kernel averages of the HEADLINE form of the step (--form one: sks_forward_backward, the backward beside the forward) and of the
   # two-call form (the forward alone on the chip): two runs, so that neither average is a mixture
   # (no autotuning inside these runs -- its candidates' launches would be averaged in: the fill-block size the tuner picks on
-  # this pool -- three non-temporal passes for the H36M one-call step, four passes of plain stores for its two-call step, the default
-  # everywhere else -- is set by hand)
-  T1=0; T2=0; [ $WL = h36m ] && T1=0x300 && T2=0x410     # (0x410: four passes, plain stores -- SKS_NO_NT_STORES is 0x10 -- the two-call pick)
+  # this pool -- plain stores for both forms of the H36M step, five passes per block in the one-call form, three in the two-call
+  # form; the default everywhere else -- is set by hand)
+  T1=0; T2=0; [ $WL = h36m ] && T1=0x510 && T2=0x310     # (0x510: five passes, plain stores -- SKS_NO_NT_STORES is 0x10 -- the tuner's usual pick for the one-call step; 0x310 for the two-call step)
   rm -rf "$OUT/${WL}_stats" "$OUT/${WL}2_stats"
   SKS_BENCH_AUTOTUNE=0 SKS_FWD_TUNE=$T1 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${WL}_stats" -o stats -- python3 "$ROOT/bench.py" --workload $WL --form one --steps 100 --warmup 5 --no-cpu-baseline --no-extras > "$OUT/${WL}_bench_under_rocprof.json" 2> "$OUT/${WL}_stats.log"
   SKS_BENCH_AUTOTUNE=0 SKS_FWD_TUNE=$T2 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${WL}2_stats" -o stats -- python3 "$ROOT/bench.py" --workload $WL --form two --steps 100 --warmup 5 --no-cpu-baseline --no-extras > "$OUT/${WL}_bench_two_calls_under_rocprof.json" 2> "$OUT/${WL}2_stats.log"
