@@ -57,6 +57,12 @@ extern "C" {
                                   sks_forward left it (per-tile counters zero again) so that a clearing launch could be skipped.
                                   The binned path no longer accumulates into the buffer -- every counter is written before it is
                                   read -- so a buffer needs no clearing and may hold anything on entry */
+/* bits 16..18: binned path (P > SKS_SMALL_P), the views of a call are processed as (value + 1) VIEW GROUPS (at most 7, at most V):
+   the binning kernels run once for all views, the forward's fill + composite launch and the backward's tile launch once per group.
+   No result bit depends on it.  sks_forward_backward uses it to run group g's backward on the second stream while group g + 1's
+   forward streams on the first; sks_backward must be given the value its sks_forward had (like every other flag). */
+#define SKS_BIN_GROUPS_SHIFT 16
+#define SKS_BIN_GROUPS(n) ((unsigned)(((n) - 1) & 7) << SKS_BIN_GROUPS_SHIFT)
 #define SKS_FILL_LINEAR (1u << 21)  /* tuning/tests: forward fill blocks always in linear (pass-major) mode */
 #define SKS_FILL_ROWS (1u << 22)    /* tuning/tests: row-aligned fill blocks whenever W % 4 == 0 */
 /* bits 26..29: tuning, composite blocks per (view, Gaussian) of the small-path forward (0 = default 4) */

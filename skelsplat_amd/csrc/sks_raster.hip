@@ -218,17 +218,18 @@ __global__ void k_spin_us(unsigned long long ticks)
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
 }
 
-// sks_forward_backward: the backward's launches go to a second stream between the geometry kernel and the dense forward (see the
-// entry point).  sks_forward finds this record (per host thread) and calls it right behind k_geom_fwd.
-struct FusedBackward {
-    int (*begin)(void* ctx);    // the second stream waits for the geometry kernel
-    int (*run)(void* ctx);      // the backward's launches on the second stream (+ the event the caller's stream joins on)
+// What sks_forward_backward hands its forward (forward_impl; sks_forward passes none): the points of the forward's launch sequence
+// behind which the backward's launches go to the second stream.
+struct FwdHook {
+    hipEvent_t geom_done;                              // small path: rides on k_geom_fwd's own dispatch (no marker packet), or null
+    int (*after_geom)(void* ctx);                      // small path: right behind the geometry kernel
+    int (*after_group)(void* ctx, int g, int v0, int nv);   // binned path: behind the forward launch of view group g (views v0 .. v0 + nv)
     void* ctx;
-    hipEvent_t geom_done;   // rides on k_geom_fwd's own dispatch (hipExtLaunchKernelGGL): no marker packet in the caller's queue
 };
-thread_local FusedBackward* tl_fused_bwd = nullptr;
+constexpr int FB_MAX_EVENTS = BIN_MAX_GROUPS;
 struct FbEvents {   // created by a thread's first combined call, reused by every later one on the same device
     hipEvent_t geom = nullptr, done = nullptr;
+    hipEvent_t grp[FB_MAX_EVENTS] = {};
     int dev = -1;
 };
 thread_local FbEvents tl_fb_events;
@@ -258,12 +259,16 @@ int sks_scratch_bytes(int V, int P, int C, int W, int H, size_t bin_capacity, si
     return 0;
 }
 
-int sks_forward(int V, int P, int C, int W, int H, const float* viewmatrix, const float* projmatrix,
-                const float* tanfovx, const float* tanfovy, const float* means3D, const float* features,
-                const float* opacities, const float* scales, const float* rotations, const float* cov3D_precomp,
-                float scale_modifier, unsigned flags, float* out_color, float* out_invdepth, int* radii, void* geom,
-                void* binning, size_t bin_capacity, int* num_rendered_dev, float* final_T, uint32_t* n_contrib,
-                void* stream)
+}  // extern "C"
+
+namespace {
+
+int forward_impl(int V, int P, int C, int W, int H, const float* viewmatrix, const float* projmatrix,
+                 const float* tanfovx, const float* tanfovy, const float* means3D, const float* features,
+                 const float* opacities, const float* scales, const float* rotations, const float* cov3D_precomp,
+                 float scale_modifier, unsigned flags, float* out_color, float* out_invdepth, int* radii, void* geom,
+                 void* binning, size_t bin_capacity, int* num_rendered_dev, float* final_T, uint32_t* n_contrib,
+                 void* stream, const FwdHook* hook)
 {
     if (int rc = check_common(V, P, C, W, H)) return rc;
     hipStream_t st = (hipStream_t)stream;
@@ -297,8 +302,8 @@ int sks_forward(int V, int P, int C, int W, int H, const float* viewmatrix, cons
     if (!small) g.cover = nullptr;   // (the binned path's cover rows are per plane: Bin::coverp, k_bin_scan + k_bin_sort_long)
     const int gthreads = small ? 256 : SKS_GEOM_BINNED_THREADS;
     const int gplanes = (small && g.cover && cover_per_plane(P, W, H, C)) ? C + 1 : 1;     // a block per plane's cover rows
-    if (tl_fused_bwd && small && tl_fused_bwd->geom_done)
-        hipExtLaunchKernelGGL(k_geom_fwd, dim3((P + gthreads - 1) / gthreads, V, gplanes), dim3(gthreads), 0, st, nullptr, tl_fused_bwd->geom_done, 0,
+    if (hook && small && hook->geom_done)
+        hipExtLaunchKernelGGL(k_geom_fwd, dim3((P + gthreads - 1) / gthreads, V, gplanes), dim3(gthreads), 0, st, nullptr, hook->geom_done, 0,
                               P, W, H, vt, viewmatrix, projmatrix, means3D, opacities, scales, rotations, cov3D_precomp, scale_modifier,
                               flags, g, radii, 0, (uint32_t*)nullptr, (uint32_t*)nullptr, features, C, (uint2*)nullptr, (uint32_t*)nullptr,
                               cover_per_plane(P, W, H, C) ? 1 : 0);
@@ -308,12 +313,8 @@ int sks_forward(int V, int P, int C, int W, int H, const float* viewmatrix, cons
                        small ? (uint32_t*)nullptr : b.count, small ? (uint32_t*)nullptr : b.touched, features, C,
                        small ? (uint2*)nullptr : b.fmask, small ? (uint32_t*)nullptr : b.hdr, (small && cover_per_plane(P, W, H, C)) ? 1 : 0);
     STAGE_CHECK("geometry");
-    FusedBackward* fb = nullptr;
-    if (tl_fused_bwd && small) {   // (sks_forward_backward: the backward behind the geometry, on its own stream)
-        fb = tl_fused_bwd;
-        tl_fused_bwd = nullptr;
-        if (int rc = fb->begin(fb->ctx)) return rc;
-        if (int rc = fb->run(fb->ctx)) return rc;
+    if (hook && small && hook->after_geom) {   // (sks_forward_backward: the backward behind the geometry, on its own stream)
+        if (int rc = hook->after_geom(hook->ctx)) return rc;
     }
 
     FwdArgs a{ P, C, W, H, flags, g, features, out_color, out_invdepth, final_T, n_contrib, composite_slots(flags, V, P),
@@ -336,35 +337,83 @@ int sks_forward(int V, int P, int C, int W, int H, const float* viewmatrix, cons
     uint32_t* cover = b.coverp;   // a row per (view, plane, band)
     const int cw = cover_cw(W);
     hipLaunchKernelGGL(k_bin_band_count, dim3(gy, V), dim3(BAND_TC), (size_t)2 * gx * 4, st, P, gx, g, b);
+    int vg, ng;
+    bin_groups(flags, V, vg, ng);
     {
         const int bpc = gx >= SCAN_T * 8 ? 1 : (SCAN_T * 8) / gx;   // whole tile bands per scan block (<= SCAN_T * SCAN_IPT tiles)
         const int nchunk_t = (gy + bpc - 1) / bpc, nchunk_g = (P + SCAN_G - 1) / SCAN_G;
         hipLaunchKernelGGL(k_bin_scan, dim3(nchunk_t + nchunk_g, V), dim3(SCAN_T), (size_t)bpc * cw * 4, st, P, gx, gy, cw, bpc,
-                           nchunk_t, bin_capacity, b, cover, num_rendered_dev, V, C + 1);
+                           nchunk_t, bin_capacity, b, cover, num_rendered_dev, V, C + 1, vg);
     }
     hipLaunchKernelGGL(k_bin_band_scatter, dim3(gy, V), dim3(BAND_TS), (size_t)2 * gx * 4, st, P, gx, bin_capacity, g, b, C, cw);
     STAGE_CHECK("binning");
-    BinView bv = bin_view(b, NT, bin_capacity);
+    const BinView bv_all = bin_view(b, NT, bin_capacity);
     {
+        // one fill + composite launch per view group (one group = every view unless SKS_BIN_GROUPS asks for more): a group's launch
+        // sees ITS views as views 0 .. nv - 1 -- every per-view array is handed over from the group's first view on; only the tile
+        // descriptors (BinView::tlist, addressed through Bin::tidx) keep their call-wide positions
         ProfScope prof(0, st);
-        switch (cg) {
-            case 4: launch_fwd_binned<4>(a, bv, V, gx, gy, cover, st); break;
-            case 16: launch_fwd_binned<16>(a, bv, V, gx, gy, cover, st); break;
-            case 20: launch_fwd_binned<20>(a, bv, V, gx, gy, cover, st); break;
-            default: launch_fwd_binned<32>(a, bv, V, gx, gy, cover, st); break;
+        for (int gi = 0; gi < ng; gi++) {
+            const int v0 = gi * vg, nv = (V - v0 < vg) ? V - v0 : vg;
+            FwdArgs ag = a;
+            ag.out_color = a.out_color + (size_t)v0 * C * HW;
+            ag.out_invdepth = a.out_invdepth + (size_t)v0 * HW;
+            if (a.final_T) ag.final_T = a.final_T + (size_t)v0 * HW;
+            if (a.n_contrib) ag.n_contrib = a.n_contrib + (size_t)v0 * HW;
+            BinView bv = bv_all;
+            bv.ranges += (size_t)v0 * NT;
+            bv.tidx += (size_t)v0 * NT;
+            bv.aux += (size_t)v0 * NT * TILE * TILE;
+            bv.e_co += (size_t)v0 * bin_capacity;
+            bv.e_xyd += (size_t)v0 * bin_capacity;
+            bv.e_ids += (size_t)v0 * bin_capacity;
+            const uint32_t* cov_g = cover + (size_t)v0 * (C + 1) * gy * cw;
+            switch (cg) {
+                case 4: launch_fwd_binned<4>(ag, bv, nv, gx, gy, cov_g, st); break;
+                case 16: launch_fwd_binned<16>(ag, bv, nv, gx, gy, cov_g, st); break;
+                case 20: launch_fwd_binned<20>(ag, bv, nv, gx, gy, cov_g, st); break;
+                default: launch_fwd_binned<32>(ag, bv, nv, gx, gy, cov_g, st); break;
+            }
+            if (hook && hook->after_group)
+                if (int rc = hook->after_group(hook->ctx, gi, v0, nv)) return rc;
         }
     }
     STAGE_CHECK("render(binned)");
     return 0;
 }
 
-int sks_backward(int V, int P, int C, int W, int H, const float* viewmatrix, const float* projmatrix,
-                 const float* tanfovx, const float* tanfovy, const float* bg, const float* means3D,
-                 const float* features, const float* opacities, const float* scales, const float* rotations,
-                 const float* cov3D_precomp, float scale_modifier, unsigned flags, const int* radii, const void* geom,
-                 const void* binning, size_t bin_capacity, const float* dL_dout_color, const float* dL_dout_invdepth,
-                 void* accum, float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dopacity, float* dL_dscales,
-                 float* dL_drotations, float* dL_dcov3D, float* dL_dfeatures, float* dL_dmeans3D_mean, void* stream)
+}  // namespace
+
+extern "C" {
+
+int sks_forward(int V, int P, int C, int W, int H, const float* viewmatrix, const float* projmatrix,
+                const float* tanfovx, const float* tanfovy, const float* means3D, const float* features,
+                const float* opacities, const float* scales, const float* rotations, const float* cov3D_precomp,
+                float scale_modifier, unsigned flags, float* out_color, float* out_invdepth, int* radii, void* geom,
+                void* binning, size_t bin_capacity, int* num_rendered_dev, float* final_T, uint32_t* n_contrib,
+                void* stream)
+{
+    return forward_impl(V, P, C, W, H, viewmatrix, projmatrix, tanfovx, tanfovy, means3D, features, opacities, scales, rotations,
+                        cov3D_precomp, scale_modifier, flags, out_color, out_invdepth, radii, geom, binning, bin_capacity,
+                        num_rendered_dev, final_T, n_contrib, stream, nullptr);
+}
+
+}  // extern "C"
+
+namespace {
+
+// sks_backward in two phases, so that sks_forward_backward can place them: BWD_RENDER = the compositing backward (binned path:
+// of view group `group`, or of every group in turn when group < 0), BWD_GEOM = the geometry backward behind it (binned path: of
+// view group `group`'s views, or of all views when group < 0).
+constexpr unsigned BWD_RENDER = 1u, BWD_GEOM = 2u;
+int backward_impl(int V, int P, int C, int W, int H, const float* viewmatrix, const float* projmatrix,
+                  const float* tanfovx, const float* tanfovy, const float* bg, const float* means3D,
+                  const float* features, const float* opacities, const float* scales, const float* rotations,
+                  const float* cov3D_precomp, float scale_modifier, unsigned flags, const int* radii, const void* geom,
+                  const void* binning, size_t bin_capacity, const float* dL_dout_color, const float* dL_dout_invdepth,
+                  void* accum, float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dopacity, float* dL_dscales,
+                  float* dL_drotations, float* dL_dcov3D, float* dL_dfeatures, float* dL_dmeans3D_mean, void* stream,
+                  unsigned phases, int group)
 {
     if (int rc = check_common(V, P, C, W, H)) return rc;
     if (P == 0) return 0;
@@ -382,7 +431,10 @@ int sks_backward(int V, int P, int C, int W, int H, const float* viewmatrix, con
     const int cg = pick_cg(C);
     const bool dfeat = dL_dfeatures != nullptr;
     const bool small = P <= SKS_SMALL_P && !(flags & SKS_FORCE_BINNED);
-    if (small) {
+    int vg = V, ng = 1;
+    if (!small) bin_groups(flags, V, vg, ng);
+    if (group >= ng) return fail(-1, "view group %d of %d", group, ng);
+    if ((phases & BWD_RENDER) && small) {
         ProfScope prof(1, st, true);
         switch (cg) {
             case 4: launch_bwd_small<4>(a, vt, vo, V, gy, dfeat, st, prof); break;
@@ -391,22 +443,28 @@ int sks_backward(int V, int P, int C, int W, int H, const float* viewmatrix, con
             default: launch_bwd_small<32>(a, vt, vo, V, gy, dfeat, st, prof); break;
         }
         STAGE_CHECK("render-backward(small)");
-    } else {
+    } else if (phases & BWD_RENDER) {
         if (!binning) return fail(-2, "binned path needs the forward's binning buffer");
         Bin b = bin_from(const_cast<void*>(binning), V, P, NT, bin_capacity);
         BinView bv = bin_view(b, NT, bin_capacity);
         // the per-Gaussian sums go through the slot rows of the binning scratch (plain stores, every row written); only the
         // feature gradient, when wanted, is accumulated with atomics
-        if (dfeat) HIP_TRY(hipMemsetAsync(accum, 0, (size_t)V * P * (NACC + C) * sizeof(float), st));
+        if (dfeat && group <= 0) HIP_TRY(hipMemsetAsync(accum, 0, (size_t)V * P * (NACC + C) * sizeof(float), st));
         dim3 grid(bwd_tile_blocks());
         const unsigned magic_nt = (unsigned)(((1ull << 32) + (unsigned)NT - 1) / (unsigned)NT), magic_gx = (unsigned)(((1ull << 32) + (unsigned)gx - 1) / (unsigned)gx);
         const bool extra = bg != nullptr || dL_dout_invdepth != nullptr;
-        ProfScope prof(1, st);
-        if (dfeat) hipLaunchKernelGGL((k_render_bwd_tile<true, true>), grid, dim3(BWD_TILE_THREADS), 0, st, a, bv, gx, V, magic_nt, magic_gx, b.tlist, b.hdr);
-        else if (extra) hipLaunchKernelGGL((k_render_bwd_tile<false, true>), grid, dim3(BWD_TILE_THREADS), 0, st, a, bv, gx, V, magic_nt, magic_gx, b.tlist, b.hdr);
-        else hipLaunchKernelGGL((k_render_bwd_tile<false, false>), grid, dim3(BWD_TILE_THREADS), 0, st, a, bv, gx, V, magic_nt, magic_gx, b.tlist, b.hdr);
+        for (int gi = group < 0 ? 0 : group; gi < (group < 0 ? ng : group + 1); gi++) {
+            // a view group's tiles: its stretch of every class's descriptor region, its class counters (k_bin_scan)
+            const uint4* tl = b.tlist + (size_t)gi * vg * NT;
+            const uint32_t* hd = b.hdr + gi * BIN_CLASSES;
+            ProfScope prof(1, st);
+            if (dfeat) hipLaunchKernelGGL((k_render_bwd_tile<true, true>), grid, dim3(BWD_TILE_THREADS), 0, st, a, bv, gx, V, magic_nt, magic_gx, tl, hd);
+            else if (extra) hipLaunchKernelGGL((k_render_bwd_tile<false, true>), grid, dim3(BWD_TILE_THREADS), 0, st, a, bv, gx, V, magic_nt, magic_gx, tl, hd);
+            else hipLaunchKernelGGL((k_render_bwd_tile<false, false>), grid, dim3(BWD_TILE_THREADS), 0, st, a, bv, gx, V, magic_nt, magic_gx, tl, hd);
+        }
         STAGE_CHECK("render-backward(binned)");
     }
+    if (!(phases & BWD_GEOM)) return 0;
     GeomBwdArgs ga{ P, C, W, H, flags, viewmatrix, projmatrix, means3D, opacities, scales, rotations, cov3D_precomp,
                     scale_modifier, radii, (const float*)accum, small ? BWD_SPLITS : 0, nullptr, nullptr, nullptr, dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dscales,
                     dL_drotations, dL_dcov3D, dL_dfeatures };
@@ -422,12 +480,35 @@ int sks_backward(int V, int P, int C, int W, int H, const float* viewmatrix, con
         hipLaunchKernelGGL(k_geom_bwd_all, dim3(1), dim3(256), 0, st, ga, vt, V, dL_dmeans3D_mean);
     } else {
         if (small) hipLaunchKernelGGL(k_geom_bwd, dim3((P + 255) / 256, V), dim3(256), 0, st, ga, vt);
-        else hipLaunchKernelGGL(k_geom_bwd_binned, dim3((P + GEOMB_G - 1) / GEOMB_G, V), dim3(256), 0, st, ga, vt);
-        if (dL_dmeans3D_mean)
+        else {
+            const int v0 = group < 0 ? 0 : group * vg, nv = group < 0 ? V : ((V - v0 < vg) ? V - v0 : vg);
+            ga.v0 = v0;
+            hipLaunchKernelGGL(k_geom_bwd_binned, dim3((P + GEOMB_G - 1) / GEOMB_G, nv), dim3(256), 0, st, ga, vt);
+        }
+        // (the mean over the views wants every view's gradients: with view groups, behind the last group's geometry backward)
+        if (dL_dmeans3D_mean && (small || group < 0 || group == ng - 1))
             hipLaunchKernelGGL(k_mean_views, dim3((3 * P + 255) / 256), dim3(256), 0, st, V, P, dL_dmeans3D, dL_dmeans3D_mean);
     }
     STAGE_CHECK("geometry-backward");
     return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sks_backward(int V, int P, int C, int W, int H, const float* viewmatrix, const float* projmatrix,
+                 const float* tanfovx, const float* tanfovy, const float* bg, const float* means3D,
+                 const float* features, const float* opacities, const float* scales, const float* rotations,
+                 const float* cov3D_precomp, float scale_modifier, unsigned flags, const int* radii, const void* geom,
+                 const void* binning, size_t bin_capacity, const float* dL_dout_color, const float* dL_dout_invdepth,
+                 void* accum, float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dopacity, float* dL_dscales,
+                 float* dL_drotations, float* dL_dcov3D, float* dL_dfeatures, float* dL_dmeans3D_mean, void* stream)
+{
+    return backward_impl(V, P, C, W, H, viewmatrix, projmatrix, tanfovx, tanfovy, bg, means3D, features, opacities, scales, rotations,
+                         cov3D_precomp, scale_modifier, flags, radii, geom, binning, bin_capacity, dL_dout_color, dL_dout_invdepth, accum,
+                         dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dscales, dL_drotations, dL_dcov3D, dL_dfeatures, dL_dmeans3D_mean,
+                         stream, BWD_RENDER | BWD_GEOM, -1);
 }
 
 int sks_forward_backward(int V, int P, int C, int W, int H, const float* viewmatrix, const float* projmatrix,
@@ -440,35 +521,53 @@ int sks_forward_backward(int V, int P, int C, int W, int H, const float* viewmat
                          float* dL_dfeatures, float* dL_dmeans3D_mean, void* stream, void* aux_stream, unsigned fb_flags)
 {
     const bool small = P <= SKS_SMALL_P && !(flags & SKS_FORCE_BINNED);
+    if (!small && aux_stream && aux_stream != stream && !((flags >> SKS_BIN_GROUPS_SHIFT) & 7u)) {
+        // the binned path overlaps by VIEW GROUPS (the backward of a group starts from what the forward's compositor left per
+        // pixel of ITS views): unless the caller chose a count, BIN_FB_GROUPS of them
+        static const int env = [] { const char* e = getenv("SKS_BIN_GROUPS"); return e ? atoi(e) : 0; }();   // tuning sweeps
+        const int want = env > 0 ? env : BIN_FB_GROUPS;
+        flags |= SKS_BIN_GROUPS(want < 1 ? 1 : (want > BIN_MAX_GROUPS ? BIN_MAX_GROUPS : want));
+    }
+    int vg = V, ng = 1;
+    if (!small && V >= 1) bin_groups(flags, V, vg, ng);
     struct Ctx {
         int V, P, C, W, H;
         const float *vm, *pm, *tx, *ty, *bg, *means, *feat, *opac, *scales, *rots, *cov;
         float smod;
         unsigned flags;
         const int* radii;
-        const void* geom;
+        const void *geom, *binning;
+        size_t cap;
         const float *dL, *dLinv;
         void* accum;
         float *m3, *m2, *op, *sc, *rot, *dcov, *dfeat, *mean;
         hipStream_t s, aux;
-        bool ext, no_join;
+        bool ext, handed;     // handed: the second stream holds work of this call
+        int rc_aux;
+        int backward(unsigned phases, int group) const
+        {
+            return backward_impl(V, P, C, W, H, vm, pm, tx, ty, bg, means, feat, opac, scales, rots, cov, smod, flags, radii, geom, binning, cap,
+                                 dL, dLinv, accum, m3, m2, op, sc, rot, dcov, dfeat, mean, aux, phases, group);
+        }
     } c{ V, P, C, W, H, viewmatrix, projmatrix, tanfovx, tanfovy, bg, means3D, features, opacities, scales, rotations, cov3D_precomp,
-         scale_modifier, flags, radii, geom, dL_dout_color, dL_dout_invdepth, accum, dL_dmeans3D, dL_dmeans2D, dL_dopacity,
-         dL_dscales, dL_drotations, dL_dcov3D, dL_dfeatures, dL_dmeans3D_mean, (hipStream_t)stream, (hipStream_t)aux_stream, true, (fb_flags & SKS_FB_NO_JOIN) != 0 };
+         scale_modifier, flags, radii, geom, binning, bin_capacity, dL_dout_color, dL_dout_invdepth, accum, dL_dmeans3D, dL_dmeans2D,
+         dL_dopacity, dL_dscales, dL_drotations, dL_dcov3D, dL_dfeatures, dL_dmeans3D_mean, (hipStream_t)stream, (hipStream_t)aux_stream,
+         true, false, 0 };
     {
         static const bool ext_off = [] { const char* e = getenv("SKS_FB_EXT"); return e && atoi(e) == 0; }();   // tuning
         if (ext_off) c.ext = false;
     }
-    if (!small || !aux_stream || aux_stream == stream || P == 0 || (flags & SKS_DEBUG_SYNC)) {
-        // the binned path's backward starts from what the forward's compositor left per pixel: one after the other
-        if (int rc = sks_forward(V, P, C, W, H, viewmatrix, projmatrix, tanfovx, tanfovy, means3D, features, opacities, scales, rotations,
-                                 cov3D_precomp, scale_modifier, flags, out_color, out_invdepth, radii, geom, binning, bin_capacity,
-                                 num_rendered_dev, nullptr, nullptr, stream))
+    const bool no_join = (fb_flags & SKS_FB_NO_JOIN) != 0;
+    if (!aux_stream || aux_stream == stream || P == 0 || (flags & SKS_DEBUG_SYNC) || (!small && ng < 2)) {
+        // nothing to run side by side: one after the other on the caller's stream
+        if (int rc = forward_impl(V, P, C, W, H, viewmatrix, projmatrix, tanfovx, tanfovy, means3D, features, opacities, scales, rotations,
+                                  cov3D_precomp, scale_modifier, flags, out_color, out_invdepth, radii, geom, binning, bin_capacity,
+                                  num_rendered_dev, nullptr, nullptr, stream, nullptr))
             return rc;
-        return sks_backward(V, P, C, W, H, viewmatrix, projmatrix, tanfovx, tanfovy, bg, means3D, features, opacities, scales, rotations,
-                            cov3D_precomp, scale_modifier, flags, radii, geom, binning, bin_capacity, dL_dout_color, dL_dout_invdepth,
-                            accum, dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dscales, dL_drotations, dL_dcov3D, dL_dfeatures,
-                            dL_dmeans3D_mean, stream);
+        return backward_impl(V, P, C, W, H, viewmatrix, projmatrix, tanfovx, tanfovy, bg, means3D, features, opacities, scales, rotations,
+                             cov3D_precomp, scale_modifier, flags, radii, geom, binning, bin_capacity, dL_dout_color, dL_dout_invdepth,
+                             accum, dL_dmeans3D, dL_dmeans2D, dL_dopacity, dL_dscales, dL_drotations, dL_dcov3D, dL_dfeatures,
+                             dL_dmeans3D_mean, stream, BWD_RENDER | BWD_GEOM, -1);
     }
     FbEvents& ev = tl_fb_events;
     int cur_dev = 0;
@@ -476,52 +575,60 @@ int sks_forward_backward(int V, int P, int C, int W, int H, const float* viewmat
     if (ev.geom && ev.dev != cur_dev) {   // (events belong to a device: a thread that moved to another one gets new ones)
         (void)hipEventDestroy(ev.geom);
         (void)hipEventDestroy(ev.done);
+        for (hipEvent_t& e : ev.grp)
+            if (e) { (void)hipEventDestroy(e); e = nullptr; }
         ev.geom = ev.done = nullptr;
     }
+    // hand-over between two queues of ONE device: a device-scope release is all the waiting side needs (the default,
+    // a system-scope fence, is what a host reader of the event would want)
+    unsigned evf = hipEventDisableTiming | hipEventDisableSystemFence;
+    if (const char* e = getenv("SKS_FB_EVENT_FLAGS")) evf = (unsigned)strtoul(e, nullptr, 0);   // tuning
     if (!ev.geom) {
         ev.dev = cur_dev;
-        // hand-over between two queues of ONE device: a device-scope release is all the waiting side needs (the default,
-        // a system-scope fence, is what a host reader of the event would want)
-        unsigned evf = hipEventDisableTiming | hipEventDisableSystemFence;
-        if (const char* e = getenv("SKS_FB_EVENT_FLAGS")) evf = (unsigned)strtoul(e, nullptr, 0);   // tuning
         HIP_TRY(hipEventCreateWithFlags(&ev.geom, evf));
         HIP_TRY(hipEventCreateWithFlags(&ev.done, evf));
     }
+    if (!small)
+        for (int gi = 0; gi < ng; gi++)
+            if (!ev.grp[gi]) HIP_TRY(hipEventCreateWithFlags(&ev.grp[gi], evf));
     struct Run {
-        static int begin(void* p)
+        // small path: behind the geometry kernel, i.e. behind everything the caller enqueued -- the whole backward
+        static int after_geom(void* p)
         {
-            const Ctx& k = *(const Ctx*)p;
+            Ctx& k = *(Ctx*)p;
             FbEvents& e = tl_fb_events;
-            // e.geom: behind k_geom_fwd, i.e. behind everything the caller enqueued
             if (!k.ext) HIP_TRY(hipEventRecord(e.geom, k.s));   // (else it rode on k_geom_fwd's dispatch)
             HIP_TRY(hipStreamWaitEvent(k.aux, e.geom, 0));
-            return 0;
+            k.handed = true;
+            return k.rc_aux = k.backward(BWD_RENDER | BWD_GEOM, -1);
         }
-        static int go(void* p)
+        // binned path: view group g's forward is enqueued -- its compositing and geometry backward go to the second stream, where
+        // they run beside the forward of group g + 1
+        static int after_group(void* p, int g, int, int)
         {
-            const Ctx& k = *(const Ctx*)p;
+            Ctx& k = *(Ctx*)p;
             FbEvents& e = tl_fb_events;
-            const int rc = sks_backward(k.V, k.P, k.C, k.W, k.H, k.vm, k.pm, k.tx, k.ty, k.bg, k.means, k.feat, k.opac, k.scales, k.rots,
-                                        k.cov, k.smod, k.flags, k.radii, k.geom, nullptr, 0, k.dL, k.dLinv, k.accum, k.m3, k.m2, k.op,
-                                        k.sc, k.rot, k.dcov, k.dfeat, k.mean, k.aux);
-            if (rc) return rc;
-            if (!k.no_join) HIP_TRY(hipEventRecord(e.done, k.aux));
-            return 0;
+            HIP_TRY(hipEventRecord(e.grp[g], k.s));
+            HIP_TRY(hipStreamWaitEvent(k.aux, e.grp[g], 0));
+            k.handed = true;
+            return k.rc_aux = k.backward(BWD_RENDER | BWD_GEOM, g);
         }
     };
-    FusedBackward fb{ &Run::begin, &Run::go, &c, c.ext ? ev.geom : nullptr };
-    tl_fused_bwd = &fb;
-    const int rc = sks_forward(V, P, C, W, H, viewmatrix, projmatrix, tanfovx, tanfovy, means3D, features, opacities, scales, rotations,
-                               cov3D_precomp, scale_modifier, flags, out_color, out_invdepth, radii, geom, binning, bin_capacity,
-                               num_rendered_dev, nullptr, nullptr, stream);
-    const bool ran = tl_fused_bwd == nullptr;
-    tl_fused_bwd = nullptr;
-    if (rc) return rc;
-    if (!ran) return fail(-3, "sks_forward_backward: the forward did not reach its geometry stage");
-    // the gradients are the caller's in stream order -- unless the caller has more to enqueue behind the backward on aux_stream
-    // (a view-sharded step's collective: hidden under the forward as well) and joins the two streams itself
-    if (!c.no_join) HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, ev.done, 0));
-    return 0;
+    const FwdHook hook{ (small && c.ext) ? ev.geom : nullptr, small ? &Run::after_geom : nullptr, small ? nullptr : &Run::after_group, &c };
+    int rc = forward_impl(V, P, C, W, H, viewmatrix, projmatrix, tanfovx, tanfovy, means3D, features, opacities, scales, rotations,
+                          cov3D_precomp, scale_modifier, flags, out_color, out_invdepth, radii, geom, binning, bin_capacity,
+                          num_rendered_dev, nullptr, nullptr, stream, &hook);
+    if (rc == 0 && !c.handed) rc = fail(-3, "sks_forward_backward: the forward did not reach the point the backward starts from");
+    // The gradients are the caller's in stream order -- unless the caller has more to enqueue behind the backward on aux_stream
+    // (a view-sharded step's collective: hidden under the forward as well) and joins the two streams itself.  After an ERROR
+    // behind the hand-over the join is made whatever the caller asked for: what the second stream already holds reads `geom` and
+    // writes the gradient tensors, and the caller's stream must not run ahead of it.
+    if (c.handed && (!no_join || rc != 0)) {
+        const hipError_t e1 = hipEventRecord(ev.done, c.aux);
+        const hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(c.s, ev.done, 0) : e1;
+        if (rc == 0 && e2 != hipSuccess) rc = fail((int)e2, "sks_forward_backward: joining the two streams: %s", hipGetErrorString(e2));
+    }
+    return rc;
 }
 
 int sks_mean_views(int V, int P, const float* dL_dmeans3D, int shard_world, float* mean_out, void* stream)

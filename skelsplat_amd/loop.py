@@ -170,6 +170,7 @@ class MultiViewLoop:
         self.iteration = 0
         self.last_losses = None
         self.stopped_at = None       # iteration at which early stopping ended the scene (train.py:155,227-233)
+        self._es_groups = 0          # groups enqueued since the scene began (view-sharded early stopping: step_group)
         # all_gather needs equal shard sizes: pad every rank to ceil(V / world) views
         self.vmax = (self.V + self.world - 1) // self.world
         # device-side tail (sks_loop_pack_grads + sks_loop_adam_step): default whenever the HIP path is used with the
@@ -264,8 +265,8 @@ class MultiViewLoop:
                 if dev.type == "cuda":
                     from .rccl_direct import DirectGather
                     self._direct = DirectGather.create(dev, self.group)
-        elif self._stopping:
-            raise ValueError("early stopping is implemented on the device-tail path (default loss, ROCm tensors)")
+        # (without the device tail -- a custom loss_grad / view_grad_fn -- the criterion is a host decision per group: the views'
+        # losses ride in the gradients' all_gather as one more column, every rank feeds the same numbers in iteration order)
         # one GPU, sparse step: the whole group is two launches (sks_loop_fused_step); the geometry of the current
         # parameters lives in a persistent state that every step leaves up to date for the next one
         # (the single-workgroup tail walks the views four at a time: a win for a handful of views -- H36M's 4 --, a loss
@@ -345,6 +346,7 @@ class MultiViewLoop:
         elif isinstance(self.early_stopping, (OptEarlyStopping, NotStopping)):
             self.early_stopping = type(self.early_stopping)()
         self.stopped_at = None
+        self._es_groups = 0
         self._geom_valid = False
         self.iteration = 0    # (last_losses keeps pointing at the buffers the captured graphs write)
         return self
@@ -479,6 +481,8 @@ class MultiViewLoop:
                 group_mask, last_view, n_iters = self._early_stop_cut(group_mask, last_view, n_iters)
             self._device_adam(group_mask, last_view, n_iters)
 
+    ES_SYNC_GROUPS = 8      # view-sharded ranks look at the device criterion's flag every this many groups (step_group)
+
     def _poll_stop(self, wait=False):
         """Device-side criterion: has it fired?  The kernel stores the stopping iteration into pinned host memory; `wait`
         first lets the stream drain (run() does, once, when it has enqueued everything it was asked for)."""
@@ -557,7 +561,17 @@ class MultiViewLoop:
                     self._geom_valid = False    # eager steps never assume the parameters were left untouched since the last one
                 self._device_group(*key)
             if self._es_device:
-                self._poll_stop()           # (never waits: the groups enqueued behind a stop do nothing to the parameters)
+                if self.exchange and self.world > 1:
+                    # Sharded: every group holds a collective, so every rank must enqueue the SAME number of groups.  A free-running
+                    # poll would not give that -- each host runs ahead of its GPU by its own amount and would see the flag a
+                    # different number of groups late.  So the flag is only looked at behind a stream synchronisation, every
+                    # ES_SYNC_GROUPS-th group: there the state the criterion ran on (gathered sums, es_state) is the same on
+                    # every rank, and so is what each of them reads.
+                    self._es_groups += 1
+                    if self._es_groups % self.ES_SYNC_GROUPS == 0:
+                        self._poll_stop(wait=True)
+                else:
+                    self._poll_stop()       # (never waits: the groups enqueued behind a stop do nothing to the parameters)
             self.iteration = it1 if self.stopped_at is None else self.stopped_at
             return self.iteration
         if not self.local_ids:
@@ -567,20 +581,35 @@ class MultiViewLoop:
         else:
             packed, losses = self._local_view_grads()
         dev = self.device
+        n11 = self.P * 11
         if self.exchange:
-            shard = torch.zeros((self.vmax, self.P, 11), device=dev)
+            # ONE collective per group here too: a rank's block = its views' gradient rows, each followed by that view's loss
+            shard = torch.zeros((self.vmax, n11 + 1), device=dev)
             if packed is not None:
-                shard[:packed.shape[0]] = packed
-            allg = torch.empty((self.world * self.vmax, self.P, 11), device=dev)
+                shard[:packed.shape[0], :n11] = packed.reshape(packed.shape[0], n11)
+                shard[:packed.shape[0], n11] = losses.to(shard.dtype)
+            allg = torch.empty((self.world * self.vmax, n11 + 1), device=dev)
             dist.all_gather_into_tensor(allg, shard, group=self.group)
             # rank r, slot k  <->  view r + k * world: one precomputed row index, view order
             if getattr(self, "_rows", None) is None:
                 self._rows = torch.tensor([(v % self.world) * self.vmax + v // self.world for v in range(self.V)],
                                           dtype=torch.long, device=dev)
-            full = allg.index_select(0, self._rows)
+            rows = allg.index_select(0, self._rows)
+            full, losses_all = rows[:, :n11].reshape(self.V, self.P, 11), rows[:, n11]
         else:
-            full = packed
-        gcons, _ = self._consistency_grad() if self.lambda_consistency != 0.0 else (0.0, None)
+            full, losses_all = packed, losses
+        gcons, lcons = self._consistency_grad() if self.lambda_consistency != 0.0 else (0.0, None)
+        if self._stopping:
+            # train.py:155-233 with the group's views batched: the criterion sees the losses of the group's iterations in order;
+            # if it fires at the k-th, only the first k views' slots are refreshed, view k's scaling / rotation / opacity
+            # gradients win, the optimiser steps at once and the scene ends (the same numbers on every rank: the same decision)
+            l2 = losses_all.detach().to(torch.float32).cpu()
+            cons = torch.zeros((), dtype=torch.float32) if lcons is None else lcons.detach().to(torch.float32).cpu()
+            for k, v in enumerate(view_of_iter):
+                if self.early_stopping(float(l2[v] + cons)):
+                    self.stopped_at = it0 + k
+                    view_of_iter, it1 = view_of_iter[:k + 1], it0 + k
+                    break
         # every view's loss contains the consistency term, so every slot carries its gradient (train.py:150-152,175)
         for v in dict.fromkeys(view_of_iter):
             self.accumulated_grads[v] = full[v, :, 0:3] + gcons
@@ -626,7 +655,7 @@ class MultiViewLoop:
                     self.iteration += G * self.acc_steps
                     remaining -= G
                     if self._es_device:
-                        self._poll_stop()
+                        self._poll_stop(wait=self.exchange and self.world > 1)     # (sharded: see step_group)
         chained = False       # (between run()'s own consecutive groups nobody else touches the parameters)
         while self.iteration < iterations and self.stopped_at is None:
             self.step_group(parameters_untouched=chained)

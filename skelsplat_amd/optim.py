@@ -26,21 +26,12 @@ class Adam(torch.optim.Adam):
         self._reset_cache()
 
     def _reset_cache(self):
-        self._steps = {}    # id(param) -> its step count as a Python int; state["step"] (a host tensor, as torch keeps it) follows lazily
         self._plans = {}    # first index of a chunk -> (key, argument arrays)
 
-    # ---- the step counts live in Python ints between steps; everything that looks at the state sees tensors ----
-    def _flush_steps(self):
-        for group in self.param_groups:
-            for p in group["params"]:
-                k = self._steps.get(id(p))
-                if k is not None:
-                    self.state[p]["step"].fill_(float(k))
-
-    def state_dict(self, *a, **kw):
-        self._flush_steps()
-        return super().state_dict(*a, **kw)
-
+    # The step count of a parameter lives where torch keeps it: state[p]["step"], a host tensor, read and advanced at every step
+    # (~1 us per parameter).  It therefore travels with the state dict: the reference's replace_tensor_to_optimizer /
+    # _prune_optimizer / cat_tensors_to_optimizer (scene/gaussian_model.py:341-404) move a parameter's state to a NEW nn.Parameter,
+    # and code that reads optimizer.state[p]["step"] sees the current value.
     def load_state_dict(self, *a, **kw):
         r = super().load_state_dict(*a, **kw)
         self._reset_cache()
@@ -100,16 +91,14 @@ class Adam(torch.optim.Adam):
                 st["step"] = torch.tensor(0.0, dtype=torch.float32)
                 st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-            if id(p) not in self._steps:
-                if st["step"].is_cuda or not st["exp_avg"].is_contiguous() or not st["exp_avg_sq"].is_contiguous():
-                    raise RuntimeError("skelsplat_amd.optim.Adam: a loaded state with a device-side step counter or strided moments "
-                                       "(saved by a capturable / fused optimiser?)")
-                self._steps[id(p)] = int(st["step"])
+            if st["step"].is_cuda or not st["exp_avg"].is_contiguous() or not st["exp_avg_sq"].is_contiguous():
+                raise RuntimeError("skelsplat_amd.optim.Adam: a loaded state with a device-side step counter or strided moments "
+                                   "(saved by a capturable / fused optimiser?)")
             states.append(st)
         if any(p.numel() == 0 for p, _, _ in todo):   # (an empty tensor keeps its state and its step count like any other; nothing to launch for it)
-            for p, _, _ in todo:
+            for (p, _, _), st in zip(todo, states):
                 if p.numel() == 0:
-                    self._steps[id(p)] += 1
+                    st["step"] += 1
             keep = [i for i, t in enumerate(todo) if t[0].numel() > 0]
             todo, states = [todo[i] for i in keep], [states[i] for i in keep]
         lib = _lib.load()
@@ -131,9 +120,9 @@ class Adam(torch.optim.Adam):
                             (C.c_longlong * n)(*(k[4] for k in key)), (C.c_double * n)(), (C.c_longlong * n)())
                     self._plans[c0] = plan
                 _, ap, ag, am, av, an, alr, ast = plan
-                for i, (p, g, group) in enumerate(chunk):
-                    k = self._steps[id(p)] + 1
-                    self._steps[id(p)] = k
+                for i, ((p, g, group), st) in enumerate(zip(chunk, sts)):
+                    k = int(st["step"].item()) + 1
+                    st["step"].fill_(float(k))
                     ast[i] = k
                     alr[i] = group["lr"]
                 _lib.check(lib.sks_adam_multi(n, ap, ag, am, av, an, alr, ast, betas[0], betas[1], eps, stream), "sks_adam_multi")

@@ -69,6 +69,8 @@ class Workspace:
         self._t = {}
         self._plans = {}     # "fwd" / "bwd" -> the last call's recorded C-ABI argument list (see _plan_key)
         self._aux = {}
+        self._pending_join = None     # device whose second stream still holds a forward_backward_views(join=False) backward
+        self._tuned = {}     # recorded forward's key -> the tuner's pick for it (tune())
 
     def aux_stream(self, dev_index):
         """The second stream forward_backward_views runs the backward on (created on first use, one per device)."""
@@ -80,6 +82,30 @@ class Workspace:
     def join(self, dev_index):
         """The current stream waits for everything enqueued on the second stream (forward_backward_views(join=False))."""
         torch.cuda.current_stream(dev_index).wait_stream(self.aux_stream(dev_index))
+        self._pending_join = None
+
+    def tune(self, step_fn, candidates=None, reps=8, rounds=3):
+        """Picks how the forward's fill role writes for the step `step_fn` issues through THIS workspace's recorded forward, by
+        timing it: 4 KB passes (or rows, on row-aligned widths) per fill block (bits 0..7 of a candidate -> bits 8..15 of the flags,
+        0 = the library's default of two) and the KIND of store (candidate bit 8, PLAIN_STORES -> SKS_NO_NT_STORES).  Why per step
+        and at run time: the fill role is bound by the life time of its ~36 000 blocks, and what shares the chip with them decides
+        the best size -- two passes when the forward runs alone (sks_forward, then sks_backward), three for the H36M step through
+        sks_forward_backward (the backward's wavefronts hold slots beside it), four for all 31 Panoptic views, five for four of
+        them.  The store kind decides where the zeros go first: non-temporal stores stream past the 256 MB Infinity Cache to HBM;
+        plain stores may stay in it, so a call that rewrites the SAME ~cache-sized output buffers step after step (a Workspace)
+        hands them over at the cache's rate while the previous step's lines drain behind it (H36M, 288 MB per call) -- a gain of
+        the STEP only where nothing else wants that bandwidth, and 40 % slower on Panoptic and the stress scene
+        (NOTES_experiments.md).  The pick is the candidate with the lowest median step time; within 1 % of the default the default
+        stays.  None of it moves a result bit (tests/test_raster_gpu.py).  `step_fn()` is called len(candidates) x rounds x (2 + reps)
+        times with device synchronisations in between (once, before a long loop); the candidates are interleaved round-robin.
+        The pick also becomes the default of later Workspace recordings of the same shape.  Returns (best, {candidate: median us})."""
+        return _workspace_tune(self, step_fn, TUNE_CANDIDATES if candidates is None else candidates, reps, rounds)
+
+    def settle(self):
+        """A forward_backward_views(join=False) whose caller never joined: the next call through this workspace makes the join
+        itself, before its geometry kernel overwrites what the backward on the second stream may still be reading."""
+        if self._pending_join is not None:
+            self.join(self._pending_join)
 
     def get(self, name, shape, dtype, device):
         key = (name, tuple(shape), dtype, device)
@@ -231,6 +257,8 @@ def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotati
             st.geom, st.binning, st.bin_capacity, st.radii, st.num_rendered_dev = geom, None, 0, radii, None
             st.plan_key = pkey
             return color, invdepth, radii, st
+    if workspace is not None:
+        workspace.settle()
     if workspace is not None and not want_aux:
         # the same call as last time (same tensors, same switches)?  Then the validated argument list is replayed as is.
         key = _fwd_key(views, means3D, features, opacities, scales, rotations, cov3D_precomp, scale_modifier, antialiasing,
@@ -238,31 +266,14 @@ def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotati
         plan = workspace._plans.get("fwd")
         if plan is not None and plan[0] == key:
             _, _views, args, dev_index, result, cap_check = plan
-            if cap_check is not None and check_capacity is not True:
-                try:
-                    host = _lazy_probe(cap_check[2], cap_check[1])     # earlier calls' counts; a buffer for this call's (or None)
-                except RuntimeError:
-                    # the recorded call holds the overflowed arena: drop it, so that the next call takes the validating path
-                    # and allocates the grown one (`_BIN_CAP_HINT`)
-                    del workspace._plans["fwd"]
-                    raise
-                args[23] = None if host is None else host.data_ptr()
-                result[3].num_rendered_dev = host
-            if cap_check is not None and check_capacity is True:
-                cap_check[0][1][:args[0]] = -1       # (the pinned counts of the synchronous check: "not written yet")
+            _replay_cap_prepare(workspace, plan, check_capacity)
             rc = _replay(lib.sks_forward, args, dev_index)
             if rc != 0:
                 del workspace._plans["fwd"]
             _lib.check(rc, "sks_forward")
-            if cap_check is None:
+            if _replay_cap_finish(workspace, plan, check_capacity):
                 return result
-            nr, pcap, ckey = cap_check
-            if check_capacity is True:
-                if _wait_counts(nr, args[0], dev_index) <= pcap:
-                    return result
-                del workspace._plans["fwd"]     # the binning arena overflowed: the validating path below grows it and redoes
-            else:
-                return result     # (lazy: the counts of this call are looked at when the next one comes in, see above)
+            # (the binning arena overflowed: the validating path below grows it and redoes)
     if views.mixed:
         raise RuntimeError("the dense forward writes one (V,C,H,W) tensor: all views of the batch must share the image size")
     if means3D is None or means3D.dim() != 2 or means3D.shape[1] != 3:
@@ -290,6 +301,14 @@ def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotati
     V, W, H = views.V, views.W, views.H
     flags = (_lib.SKS_ANTIALIASING if antialiasing else 0) | (_lib.SKS_CLAMP01 if clamp01 else 0) | \
             (_lib.SKS_DEBUG_SYNC if debug else 0) | (_lib.SKS_FORCE_BINNED if force_binned else 0) | int(tune_flags) | _ENV_TUNE
+    if plans is not None and workspace is None and AUTOTUNE and not flags & _FILL_BITS and not _MEASURING[0] and not force_binned \
+            and (dev.index, V, P, C, W, H, "fresh") not in _FILL_TUNE:
+        # the autograd path sees a shape for the first time: its fill configuration is measured once (tune_forward), on this call's
+        # own tensors -- every later call of the shape, recorded or not, launches with the pick
+        tune_forward(views, means3D, feat2, opacities, scales, rotations, cov3D_precomp, scale_modifier, antialiasing, clamp01,
+                     tune_flags=tune_flags)
+    if not flags & _FILL_BITS and not _MEASURING[0]:      # no explicit fill configuration: what tune_forward / Workspace.tune measured for this shape, if anything
+        flags |= _FILL_TUNE.get((dev.index, V, P, C, W, H, "workspace" if workspace is not None else "fresh"), 0)
     binned = force_binned or P > _lib.SKS_SMALL_P
     bin_capacity_given = bin_capacity
     if binned and bin_capacity is None:
@@ -369,6 +388,40 @@ def forward_views(views: ViewBatch, means3D, features, opacities, scales, rotati
                 cap_check = (None, cap, cap_key)     # replays are lazy calls: each takes a probe buffer of the shape (_lazy_probe)
         workspace._plans["fwd"] = (key, (views, keep), args, dev.index, (color, invdepth, radii, st), cap_check)
     return color, invdepth, radii, st
+
+
+def _replay_cap_prepare(workspace, plan, check_capacity):
+    """In front of a REPLAYED binned forward (forward_views, forward_backward_views): where this call's pair counts go.  Lazy modes:
+    a pinned probe buffer of the shape (looking at earlier calls' counts first: raises when one of them overflowed its arena);
+    synchronous check: the shape's pinned counts preset to "not written yet"."""
+    args, result, cap_check = plan[2], plan[4], plan[5]
+    if cap_check is None:
+        return
+    if check_capacity is not True:
+        try:
+            host = _lazy_probe(cap_check[2], cap_check[1])     # earlier calls' counts; a buffer for this call's (or None)
+        except RuntimeError:
+            # the recorded call holds the overflowed arena: drop it, so that the next call takes the validating path
+            # and allocates the grown one (`_BIN_CAP_HINT`)
+            workspace._plans.pop("fwd", None)
+            raise
+        args[23] = None if host is None else host.data_ptr()
+        result[3].num_rendered_dev = host
+    else:
+        cap_check[0][1][:args[0]] = -1       # (the pinned counts of the synchronous check: "not written yet")
+
+
+def _replay_cap_finish(workspace, plan, check_capacity):
+    """Behind it: True = the call stands.  False (synchronous check only): its arena was too small -- the recorded call is dropped,
+    the caller takes the validating path, which grows the arena and redoes the forward."""
+    args, dev_index, cap_check = plan[2], plan[3], plan[5]
+    if cap_check is None or check_capacity is not True:
+        return True       # (lazy: the counts of this call are looked at when the next one comes in)
+    nr, pcap, ckey = cap_check
+    if _wait_counts(nr, args[0], dev_index) <= pcap:
+        return True
+    workspace._plans.pop("fwd", None)
+    return False
 
 
 def _forward_views_wide(views, means3D, features, opacities, scales, rotations, cov3D_precomp, scale_modifier, antialiasing, clamp01,
@@ -609,6 +662,8 @@ def backward_views(st: ForwardState, means3D, features, opacities, scales, rotat
                 plans.pop(pkey, None)
             _lib.check(rc, "sks_backward")
             return out
+    if workspace is not None:
+        workspace.settle()
     if workspace is not None and st.P:
         key = _bwd_key(st, means3D, features, opacities, scales, rotations, cov3D_precomp, dL_dcolor, dL_dinvdepth, bg,
                        want_dfeatures, tune_flags, want_mean, out_means3D, torch._C._cuda_getCurrentRawStream(st.geom.device.index))
@@ -681,7 +736,8 @@ def backward_views(st: ForwardState, means3D, features, opacities, scales, rotat
 
 def forward_backward_views(views: ViewBatch, means3D, features, opacities, scales, rotations, cov3D_precomp, dL_dcolor,
                            dL_dinvdepth=None, bg=None, scale_modifier=1.0, antialiasing=False, clamp01=False, want_dfeatures=False,
-                           tune_flags=0, workspace=None, want_mean=False, out_means3D=None, overlap=True, join=True):
+                           tune_flags=0, workspace=None, want_mean=False, out_means3D=None, overlap=True, join=True,
+                           force_binned=False, bin_capacity=None, check_capacity=True):
     """forward_views + backward_views of the same inputs as ONE C-ABI call (sks_forward_backward), for a caller whose upstream
     gradient `dL_dcolor` is complete when the call is made -- it does not depend on the image this call renders.  Returns
     (color, invdepth, radii, state, grads): the same tensors, bit for bit, the two calls return.  On the small path (P <= 256) the
@@ -696,17 +752,22 @@ def forward_backward_views(views: ViewBatch, means3D, features, opacities, scale
     if workspace is None:
         raise ValueError("forward_backward_views needs a Workspace (outputs, scratch and the second stream live there)")
     lib = _lib.load()
+    workspace.settle()
     fplan, bplan = workspace._plans.get("fwd"), workspace._plans.get("bwd")
-    if fplan is not None and bplan is not None and fplan[5] is None:     # (a binned forward keeps its capacity check: two calls)
+    if fplan is not None and bplan is not None:
         dev_index = fplan[3]
         fkey = _fwd_key(views, means3D, features, opacities, scales, rotations, cov3D_precomp, scale_modifier, antialiasing, clamp01,
-                        False, False, None, tune_flags, True)
+                        False, force_binned, bin_capacity, tune_flags, check_capacity)
         if fplan[0] == fkey:
             st = fplan[4][3]
             bkey = _bwd_key(st, means3D, features, opacities, scales, rotations, cov3D_precomp, dL_dcolor, dL_dinvdepth, bg,
                             want_dfeatures, tune_flags, want_mean, out_means3D, torch._C._cuda_getCurrentRawStream(dev_index))
             if bplan[0] == bkey:
                 aux = workspace.aux_stream(dev_index) if (overlap or not join) else None
+                # (a binned forward keeps its capacity check: the probe buffer / pinned counts go in front of the call, the
+                # synchronous check's wait behind it -- on the binned path the library runs the backward of a view group beside
+                # the forward of the next one, SKS_BIN_GROUPS)
+                _replay_cap_prepare(workspace, fplan, check_capacity)
                 fa, ba = fplan[2], bplan[2]
                 no_join = overlap and not join
                 args = fa[:24] + [ba[9], ba[22], ba[23], ba[24]] + ba[25:33] + [None, aux.cuda_stream if overlap else None,
@@ -721,10 +782,15 @@ def forward_backward_views(views: ViewBatch, means3D, features, opacities, scale
                     reset_scratch()
                     workspace._plans.pop("fwd", None), workspace._plans.pop("bwd", None)
                 _lib.check(rc, "sks_forward_backward")
+                if no_join:
+                    workspace._pending_join = dev_index     # (the caller's workspace.join(); settled by the next call otherwise)
                 if not join and not overlap:     # (the gradients were produced on the current stream: aux must see them)
                     aux.wait_stream(torch.cuda.current_stream(dev_index))
-                return fplan[4] + (bplan[4],)
+                if _replay_cap_finish(workspace, fplan, check_capacity):
+                    return fplan[4] + (bplan[4],)
+                workspace.settle()     # the arena overflowed (synchronous check): the two calls below grow it and redo the step
     out = forward_views(views, means3D, features, opacities, scales, rotations, cov3D_precomp, scale_modifier, antialiasing, clamp01,
+                        force_binned=force_binned, bin_capacity=bin_capacity, check_capacity=check_capacity,
                         tune_flags=tune_flags, workspace=workspace)
     g = backward_views(out[3], means3D, features, opacities, scales, rotations, cov3D_precomp, dL_dcolor, dL_dinvdepth, bg,
                        want_dfeatures, tune_flags, workspace, want_mean, out_means3D)
@@ -733,8 +799,23 @@ def forward_backward_views(views: ViewBatch, means3D, features, opacities, scale
     return out + (g,)
 
 
+# ------------------------------------------------------------------------------------------------------------
+# the forward's fill configuration, measured per shape and per kind of caller (no result bit depends on it)
+# ------------------------------------------------------------------------------------------------------------
 PLAIN_STORES = 0x100     # a tuner candidate's bit 8: plain stores instead of non-temporal ones (SKS_NO_NT_STORES)
-TUNE_CANDIDATES = (0, 3, 4, 5, PLAIN_STORES | 3, PLAIN_STORES | 4, PLAIN_STORES | 5)
+# What the tuners try by default: passes per fill block, non-temporal stores -- the kind that streams past the 256 MB Infinity Cache
+# at the rate HBM takes writes, whatever buffer it writes.  Plain stores (TUNE_CANDIDATES_WITH_PLAIN, on request) may sit in that
+# cache when a call rewrites the same ~cache-sized outputs step after step: the kernel then retires before its bytes are in HBM
+# (H36M forward 46 -> 38-41 us) and they drain under whatever runs next -- a cache-assisted figure, not an HBM rate, and 40 %
+# slower on outputs beyond the cache's size; round 5 took such candidates at equal step time, which moved the reported kernel
+# fraction by 0.15 without moving the step.
+TUNE_CANDIDATES = (0, 3, 4, 5)
+TUNE_CANDIDATES_WITH_PLAIN = TUNE_CANDIDATES + (PLAIN_STORES | 3, PLAIN_STORES | 4, PLAIN_STORES | 5)
+TUNE_CANDIDATES_FRESH = TUNE_CANDIDATES  # outputs in fresh memory every call (the autograd path)
+_FILL_BITS = (0xff << 8) | 16            # flag bits a candidate occupies: passes per fill block, SKS_NO_NT_STORES
+_FILL_TUNE = {}          # (device, V, P, C, W, H, "workspace" | "fresh") -> flag bits: what forward_views ORs in when the caller sets none
+_MEASURING = [False]     # tune_forward is timing candidates: forward_views leaves the flags as given
+_FILL_TUNE_LOG = {}      # same key -> {candidate name: median microseconds} of the measurement behind the pick
 
 
 def _tune_flag_bits(c):
@@ -748,30 +829,13 @@ def tune_name(c):
     return f"{int(c) & 0xff or 2} passes, {'plain' if int(c) & PLAIN_STORES else 'non-temporal'} stores"
 
 
-def autotune_fill_passes(workspace, step_fn, candidates=TUNE_CANDIDATES, reps=8, rounds=3):
-    """Picks how the forward's fill role writes -- 4 KB passes (or rows, on row-aligned widths) per fill block (bits 0..7 of a
-    candidate -> bits 8..15 of the flags, 0 = the library's default of two) and the KIND of store (candidate bit 8, PLAIN_STORES ->
-    SKS_NO_NT_STORES) -- for the step `step_fn` issues through `workspace`'s RECORDED forward, by timing it.
-    Why per step and at run time: the fill role is bound by the life time of its ~36 000 blocks, and what shares the chip with them
-    decides the best size -- two passes when the forward runs alone (sks_forward, then sks_backward), three for the H36M step
-    through sks_forward_backward (the backward's wavefronts hold slots beside it), four for all 31 Panoptic views, five for four of
-    them.  And the store kind decides where the zeros go first: non-temporal stores stream past the 256 MB Infinity Cache
-    to HBM; plain stores may stay in it, so a call that writes the SAME output buffers step after step (a Workspace) and about
-    that many bytes hands them over at the cache's rate while the previous step's lines drain behind it -- H36M (288 MB per
-    call): forward 46.7 -> 38.0 us with plain stores and four passes; Panoptic (663 MB for four views, 5.1 GB for 31) and the
-    stress scene: 40 % SLOWER with plain stores (NOTES_experiments.md, round 5).  None of it moves a result bit.  `step_fn()` is
-    called len(candidates) x rounds x (2 + reps) times with device synchronisations in between (once, before a long loop); the
-    candidates are interleaved round-robin and judged by their median.  Returns (best, {candidate: median microseconds})."""
+def _time_candidates(set_bits, step_fn, candidates, reps, rounds, dev_index):
+    """Interleaved round-robin timing of `step_fn` under every candidate; {candidate: median microseconds per call}."""
     import time
-    plan = workspace._plans.get("fwd")
-    if plan is None or torch.cuda.is_current_stream_capturing():
-        return None, {}
-    args, dev_index = plan[2], plan[3]
-    base = args[16] & ~(0xff << 8) & ~_lib.SKS_NO_NT_STORES
     times = {c: [] for c in candidates}
     for _ in range(rounds):
         for c in candidates:
-            args[16] = base | _tune_flag_bits(c)
+            set_bits(_tune_flag_bits(c))
             for _ in range(2):
                 step_fn()
             torch.cuda.synchronize(dev_index)
@@ -780,18 +844,90 @@ def autotune_fill_passes(workspace, step_fn, candidates=TUNE_CANDIDATES, reps=8,
                 step_fn()
             torch.cuda.synchronize(dev_index)
             times[c].append(1e6 * (time.perf_counter() - t0) / reps)
-    med = {c: sorted(v)[len(v) // 2] for c, v in times.items()}
+    return {c: sorted(v)[len(v) // 2] for c, v in times.items()}
+
+
+def _pick(med, candidates):
+    """The fastest candidate -- unless it is within 1 % of the first (the library's default): then that one stays."""
     best = min(med, key=med.get)
-    if med[best] > 0.99 * med[candidates[0]]:      # (within the noise of the first candidate: keep that one)
+    if med[best] > 0.99 * med[candidates[0]]:
         best = candidates[0]
-    elif not int(best) & PLAIN_STORES:
-        # a plain-store candidate within 1 % of the best step: take it -- at equal step time its forward is through earlier (the
-        # cache takes the stores at its own rate), which is what anything the caller queues behind the images wants
-        near = [c for c in candidates if int(c) & PLAIN_STORES and med[c] <= 1.01 * med[best]]
-        if near:
-            best = min(near, key=med.get)
-    args[16] = base | _tune_flag_bits(best)
+    return best
+
+
+def _workspace_tune(workspace, step_fn, candidates=TUNE_CANDIDATES, reps=8, rounds=3):
+    """Workspace.tune (see there)."""
+    plan = workspace._plans.get("fwd")
+    if plan is None or torch.cuda.is_current_stream_capturing():
+        return None, {}
+    args, dev_index = plan[2], plan[3]
+    base = args[16] & ~_FILL_BITS
+
+    def set_bits(bits):
+        args[16] = base | bits
+    med = _time_candidates(set_bits, step_fn, candidates, reps, rounds, dev_index)
+    best = _pick(med, candidates)
+    set_bits(_tune_flag_bits(best))
+    V, P, C, W, H = args[0], args[1], args[2], args[3], args[4]
+    key = (dev_index, V, P, C, W, H, "workspace")
+    _FILL_TUNE[key] = _tune_flag_bits(best)
+    _FILL_TUNE_LOG[key] = {tune_name(c): round(v, 2) for c, v in med.items()}
+    workspace._tuned[plan[0]] = best
     return best, med
+
+
+def autotune_fill_passes(workspace, step_fn, candidates=TUNE_CANDIDATES, reps=8, rounds=3):
+    """Former name of Workspace.tune (kept for callers of the round-5 API)."""
+    return _workspace_tune(workspace, step_fn, candidates, reps, rounds)
+
+
+def tune_forward(views, means3D, features, opacities, scales, rotations, cov3D_precomp, scale_modifier=1.0, antialiasing=False,
+                 clamp01=False, tune_flags=0, reps=6, rounds=3, rotate=4):
+    """The fill configuration for callers whose outputs are FRESH tensors every call (the autograd path: GaussianRasterizer,
+    render_*; MultiViewLoop's dense step): times sks_forward of this very call over `rotate` output sets in turn (memory the
+    kernel has not just written), non-temporal candidates only, and keeps the pick for the shape -- forward_views then uses it
+    whenever a caller of that shape passes no fill bits of its own.  Small path only (the binned path's fill geometry has its own
+    measured default).  ~100 forwards and a few device synchronisations, once per shape.  Returns the flag bits."""
+    P = means3D.shape[0]
+    dev = means3D.device
+    feat2 = features.reshape(P, -1)
+    C = feat2.shape[1]
+    key = (dev.index, views.V, P, C, views.W, views.H, "fresh")
+    if key in _FILL_TUNE:
+        return _FILL_TUNE[key]
+    if P == 0 or P > _lib.SKS_SMALL_P or C > _lib.SKS_MAX_CHANNELS or torch.cuda.is_current_stream_capturing():
+        return 0
+    _FILL_TUNE[key] = 0      # (the measuring calls below must not recurse into a measurement)
+    wss = [Workspace() for _ in range(rotate)]
+    state = {"bits": 0, "i": 0}
+
+    def step():
+        ws = wss[state["i"] % rotate]
+        state["i"] += 1
+        forward_views(views, means3D, feat2, opacities, scales, rotations, cov3D_precomp, scale_modifier, antialiasing, clamp01,
+                      tune_flags=(int(tune_flags) & ~_FILL_BITS) | state["bits"], workspace=ws)
+
+    def set_bits(bits):
+        state["bits"] = bits
+    _MEASURING[0] = True      # (candidate 0 means "no bits": the measuring calls must get exactly what they ask for)
+    try:
+        with torch.no_grad():
+            med = _time_candidates(set_bits, step, TUNE_CANDIDATES_FRESH, reps, rounds, dev.index)
+    finally:
+        _MEASURING[0] = False
+    best = _pick(med, TUNE_CANDIDATES_FRESH)
+    _FILL_TUNE[key] = _tune_flag_bits(best)
+    _FILL_TUNE_LOG[key] = {tune_name(c): round(v, 2) for c, v in med.items()}
+    return _FILL_TUNE[key]
+
+
+def fill_tuning():
+    """What has been measured so far: {(device, V, P, C, W, H, kind): (pick in words, {candidate: median us})}."""
+    names = {_tune_flag_bits(c): tune_name(c) for c in TUNE_CANDIDATES_WITH_PLAIN}
+    return {k: (names.get(v, hex(v)), _FILL_TUNE_LOG.get(k, {})) for k, v in _FILL_TUNE.items()}
+
+
+AUTOTUNE = os.environ.get("SKS_AUTOTUNE", "1") != "0"     # the autograd path and the loops measure a shape's fill configuration once
 
 
 def mean_views(grads, V, world=1, out=None):

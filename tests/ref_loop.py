@@ -29,24 +29,31 @@ def view_grads_ref(gm, cam, gt, W, H, dataset, lambda_consistency):
 
 
 def run_reference_loop(gm, cameras, heatmaps, W, H, dataset, iterations, accumulation_steps=4, lambda_consistency=1e-5,
-                       on_step=None):
-    """`on_step(gm)`: called after every optimiser step.  (This restatement is itself held to the reference's own
-    train.training(), run in the build container: tests/golden/reference_loop.npz, tests/test_loop_golden.py.)"""
+                       on_step=None, early_stopping=None):
+    """`on_step(gm)`: called after every optimiser step.  `early_stopping`: a callable loss -> bool fed `loss.item()` of every
+    iteration like train.py:155; when it fires the optimiser steps at once and the loop ends (train.py:182, 227-233) -- the
+    stopping iteration is then left in `run_reference_loop.stopped_at` (None otherwise).  (This restatement is itself held to
+    the reference's own train.training(), run in the build container: tests/golden/reference_loop.npz, tests/test_loop_golden.py.)"""
     V = len(cameras)
     accumulated = torch.zeros((V,) + tuple(gm._xyz.shape))
     cam_idx_counter = 0
+    run_reference_loop.stopped_at = None
     for iteration in range(1, iterations + 1):
         gm.update_learning_rate(iteration)
         idx = cam_idx_counter % V
         cam_idx_counter += 1
-        _, (gx, gs, gr, go) = view_grads_ref(gm, cameras[idx], heatmaps[idx], W, H, dataset, lambda_consistency)
+        loss, (gx, gs, gr, go) = view_grads_ref(gm, cameras[idx], heatmaps[idx], W, H, dataset, lambda_consistency)
+        stop = early_stopping is not None and bool(early_stopping(loss.item()))
         accumulated[idx] = gx
         gm._scaling.grad, gm._rotation.grad, gm._opacity.grad = gs, gr, go
-        if iteration % accumulation_steps == 0:
+        if iteration % accumulation_steps == 0 or stop:
             gm._xyz.grad = accumulated.mean(dim=0)
             with torch.no_grad():
                 gm.optimizer.step()
                 gm.optimizer.zero_grad(set_to_none=True)
             if on_step is not None:
                 on_step(gm)
+        if stop:
+            run_reference_loop.stopped_at = iteration
+            break
     return gm._xyz.detach().clone()

@@ -328,6 +328,96 @@ def test_view_sharded_loop_equals_single_process_and_reference():
     util.assert_close("loop vs reference", w1[1], ref.numpy(), rtol=1e-5, atol_scale=1e-6)
 
 
+class _StopAtCall:
+    """A host criterion that fires at its n-th loss (train.py:155 feeds it `loss.item()` of every iteration)."""
+
+    def __init__(self, n):
+        self.n, self.calls = n, 0
+
+    def __call__(self, loss):
+        self.calls += 1
+        return self.calls == self.n
+
+
+def _config4_cases():
+    from skelsplat_amd.loop import OptEarlyStopping
+    # (name, iterations, criterion factory): two whole groups; a stop in the middle of the SECOND group; the reference's own
+    # criterion with a tolerance that lets it fire as soon as it has its two windows (iteration 8: the middle of the first)
+    return [("no_stopping", 62, lambda: "no_stopping"), ("stop_at_40", 93, lambda: _StopAtCall(40)),
+            ("opt_early_stopping", 62, lambda: OptEarlyStopping(window_size=4, repeat_tolerance=10.0))]
+
+
+def _config4_scene():
+    from oracle.heatmaps_ref import generate_heatmaps
+    from skelsplat_amd.scene import SyntheticScene, GaussianModel
+    sc = SyntheticScene("panoptic", n_views=31, seed=5, W=64, H=40)
+    gm = GaussianModel().create_from_points(sc.pose_3d_init, sc.spatial_lr_scale, 19, scaling=4.5, scene_type="panoptic")
+    gm.training_setup()
+    hm = generate_heatmaps(gm._xyz.detach(), gm.get_scaling.detach(), gm._rotation.detach(), torch.tensor(sc.poses_2d), sc.cameras)
+    return sc, gm, hm
+
+
+def _config4_worker(rank, world, port, ret):
+    """BASELINE configs[3]'s partition on CPU: 31 Panoptic-shaped views over `world` gloo ranks (view v -> rank v % world)."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from skelsplat_amd.loop import MultiViewLoop
+    out = {}
+    for name, iters, crit in _config4_cases():
+        sc, gm, hm = _config4_scene()
+        loop = MultiViewLoop(gm, sc.cameras, hm, dataset="panoptic", accumulation_steps=31, lambda_consistency=1e-5,
+                             view_grad_fn=_oracle_view_grads, early_stopping=crit())
+        xyz = loop.run(iters)
+        out[name] = (len(loop.local_ids), xyz.numpy().copy(), gm._scaling.detach().numpy().copy(), loop.stopped_at, loop.iteration)
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, {k: (v[0], v[3], v[4], float(np.abs(v[1]).sum())) for k, v in out.items()})
+        if rank == 0:
+            ret.put((world, out, gathered))
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        ret.put((world, out, None))
+
+
+def test_config4_partition_on_eight_ranks_equals_one_rank_and_the_reference_loop():
+    """31 views over 8 processes (shards 4,4,4,4,4,4,4,3: the padded all_gather rows, the early-stopping losses in the same
+    block) == 1 process bit for bit == the literal reference loop (train.py:130-233), with and without early stopping."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_config4_worker, args=(r, 8, port, ret)) for r in range(8)]
+    for p in procs:
+        p.start()
+    w8 = ret.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    _config4_worker(0, 1, port + 1, ret)
+    w1 = ret.get(timeout=10)
+    assert sorted(g["no_stopping"][0] for g in w8[2]) == [3, 4, 4, 4, 4, 4, 4, 4]     # the partition north_star names
+    from tests.ref_loop import run_reference_loop
+    for name, iters, crit in _config4_cases():
+        n8, x8, s8, stop8, it8 = w8[1][name]
+        n1, x1, s1, stop1, it1 = w1[1][name]
+        assert n1 == 31 and np.array_equal(x8, x1) and np.array_equal(s8, s1), name     # identical summation order -> bit-identical
+        assert stop8 == stop1 and it8 == it1, name
+        for g in w8[2]:     # every rank took the same decision and holds the same parameters
+            assert g[name][1] == stop8 and g[name][2] == it8 and g[name][3] == float(np.abs(x8).sum()), name
+        sc, gm, hm = _config4_scene()
+        c = crit()
+        ref = run_reference_loop(gm, sc.cameras, hm, 64, 40, "panoptic", iters, accumulation_steps=31,
+                                 early_stopping=None if isinstance(c, str) else c)
+        assert run_reference_loop.stopped_at == stop1, name
+        util.assert_close("config-4 loop vs reference: " + name, x1, ref.numpy(), rtol=1e-5, atol_scale=1e-6)
+    assert w1[1]["stop_at_40"][3] == 40 and w1[1]["opt_early_stopping"][3] == 8
+
+
 # ------------------------------------------------------------------------------ "next" rows: triangulation, ply, MPJPE
 def test_dlt_triangulation_matches_reference_algorithm():
     """Batched SVD == the reference's per-joint loop (triangulation.py:122-138 restated inline), and recovers the GT."""

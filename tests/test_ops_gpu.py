@@ -1185,10 +1185,19 @@ def _two_rank_worker(rank, world, port, mode, ret):
         gm._opacity.fill_(2.0)
     hms = [generate_heatmaps(gm._xyz.detach(), gm.get_scaling.detach(), gm._rotation.detach(),
                              torch.tensor(sc.poses_2d[v:v + 1], device=dev), [cams[v]])[0] for v in range(5)]
-    loop = MultiViewLoop(gm, cams, hms, dataset="h36m", accumulation_steps=5, sparse=mode != "dense", fused_tail=False)
+    es = "no_stopping"
+    if mode == "early_stop":
+        from skelsplat_amd.loop import OptEarlyStopping
+        es = OptEarlyStopping(window_size=4, repeat_tolerance=8e-4)
+    loop = MultiViewLoop(gm, cams, hms, dataset="h36m", accumulation_steps=5, sparse=mode != "dense", fused_tail=False,
+                         early_stopping=es)
     assert loop.world == world and loop.exchange == (world > 1) and loop.device_tail
+    if mode == "early_stop":
+        assert loop._es_device
     if world > 1:
-        assert loop.local_ids == [v for v in range(5) if v % 2 == rank] and tuple(loop._allg.shape) == (6, 17, 11)
+        assert loop.local_ids == [v for v in range(5) if v % 2 == rank]
+        # (with the criterion on the device a rank's block also carries its views' {S, N}: a flat buffer, sks_loop_shard_floats)
+        assert tuple(loop._allg.shape) == ((6, 17, 11) if mode != "early_stop" else (2 * loop._shard_flat.numel(),))
     if mode == "dropout":
         # training.dropout (general_utils.py:267-283): ONE draw of dropped (camera, joint) planes per scene.  The ranks'
         # default generators are deliberately out of step here; rank 0's draw must be the scene's on every rank
@@ -1200,21 +1209,29 @@ def _two_rank_worker(rank, world, port, mode, ret):
         if world == 1:   # the draw did drop planes, and some of them belong to views the second rank owns at world 2
             dropped = [int((pl.reshape(pl.shape[0], -1).abs().amax(1) == 0).sum()) for pl in loop.hset.planes]
             assert sum(dropped) > 0 and dropped[1] + dropped[3] > 0, dropped
-    loop.run(30)
+    loop.run(600 if mode == "early_stop" else 30)
     torch.cuda.synchronize()
+    if mode == "early_stop":
+        # the criterion fired in the middle of the run, inside a group; every rank enqueued the same number of groups (each holds
+        # a collective: a rank that had stopped a group earlier than its peer would leave that peer hanging in its last all_gather)
+        assert loop.stopped_at is not None and 8 <= loop.stopped_at < 600 and loop.iteration == loop.stopped_at, loop.stopped_at
+        assert int(loop.counters[0]) == loop.stopped_at
     if rank == 0:
-        ret.put([x.detach().cpu().numpy() for x in (gm._xyz, gm._scaling, gm._rotation, gm._opacity, loop.accumulated_grads)])
+        ret.put([x.detach().cpu().numpy() for x in (gm._xyz, gm._scaling, gm._rotation, gm._opacity, loop.accumulated_grads)]
+                + [np.array([loop.stopped_at or 0, loop.iteration])])
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["sparse", "dense", "mixed", "dropout"])
+@pytest.mark.parametrize("mode", ["sparse", "dense", "mixed", "dropout", "early_stop"])
 def test_two_ranks_on_one_gpu_equal_one_rank(device, mode):
     """The view-sharded device path at world size 2 -- uneven shards (3 + 2 views, one zero pad row), all_gather, the
     rank-major optimiser kernel, every rank stepping identically -- as two processes sharing this GPU over gloo (RCCL
     does not allow two ranks on one device; the collective's transport is not what is under test).  Bit-identical to
-    one process."""
+    one process.  "early_stop": the reference's criterion on the device fires mid-run; the ranks look at its flag only behind a
+    stream synchronisation every ES_SYNC_GROUPS groups, so both stop after the same number of collectives (no hang) and at
+    the iteration the single process stops at."""
     import os
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
@@ -1270,7 +1287,7 @@ def test_one_launch_adam_is_torch_adam(device):
                 p.grad = (torch.randn(p.shape, generator=gen) * scale).to(device)
             o.step()
             o.zero_grad(set_to_none=True)
-    ob.state_dict()     # (the step counts live in Python ints between steps: any look at the state through the API sees tensors)
+    # (the step counts are read straight from optimizer.state, without a state_dict() in between: they live there, as torch keeps them)
     for a, b in zip(oa.param_groups, ob.param_groups):
         pa, pb = a["params"][0], b["params"][0]
         tol = 2e-6 * float(pa.abs().max()) if pa.numel() else 0.0
@@ -1294,6 +1311,40 @@ def test_one_launch_adam_is_torch_adam(device):
     for b, c in zip(ob.param_groups, oc.param_groups):
         pb, pc = b["params"][0], c["params"][0]
         assert torch.allclose(pb, pc, rtol=2e-5, atol=2e-6 * float(pb.abs().max()) if pb.numel() else 0.0), b["name"]
+
+
+@pytest.mark.gpu
+def test_one_launch_adam_state_moves_with_the_reference_parameter_surgery(device):
+    """scene/gaussian_model.py:341-404 (replace_tensor_to_optimizer, _prune_optimizer, cat_tensors_to_optimizer) move a parameter's
+    state dict to a NEW nn.Parameter: the step count (and with it the bias correction) must go along -- it lives in state["step"],
+    not in a cache keyed by the old parameter's identity."""
+    from skelsplat_amd.optim import Adam
+    pa, pb = torch.nn.Parameter(torch.ones(7, 3, device=device)), torch.nn.Parameter(torch.ones(7, 3, device=device))
+    oa = torch.optim.Adam([{"params": [pa], "lr": 1e-2, "name": "xyz"}], lr=0.0, eps=1e-15)
+    ob = Adam([{"params": [pb], "lr": 1e-2, "name": "xyz"}], lr=0.0, eps=1e-15)
+    gen = torch.Generator().manual_seed(0)
+
+    def steps(n):
+        for _ in range(n):
+            g = torch.randn(oa.param_groups[0]["params"][0].shape, generator=gen).to(device)
+            for o in (oa, ob):
+                o.param_groups[0]["params"][0].grad = g.clone()
+                o.step()
+    steps(5)
+    assert int(ob.state[pb]["step"]) == 5          # visible without a state_dict() in between
+    for o in (oa, ob):     # _prune_optimizer (gaussian_model.py:357-376): keep rows 0..4, re-seat the state under a new Parameter
+        grp = o.param_groups[0]
+        old = grp["params"][0]
+        st = o.state.get(old)
+        mask = torch.arange(7, device=device) < 5
+        st["exp_avg"], st["exp_avg_sq"] = st["exp_avg"][mask], st["exp_avg_sq"][mask]
+        del o.state[old]
+        grp["params"][0] = torch.nn.Parameter(old[mask].detach().clone().requires_grad_(True))
+        o.state[grp["params"][0]] = st
+    steps(4)
+    qa, qb = oa.param_groups[0]["params"][0], ob.param_groups[0]["params"][0]
+    assert int(oa.state[qa]["step"]) == int(ob.state[qb]["step"]) == 9
+    assert torch.allclose(qa, qb, rtol=2e-5, atol=2e-6)
 
 
 @pytest.mark.gpu

@@ -1236,27 +1236,61 @@ def test_any_number_of_channels_through_the_generic_path(device):
     util.assert_close("autograd features", sh.grad.reshape(c.P, Cw).cpu().numpy(), b["dL_dcolors"], rtol=1e-3, atol_scale=1e-5)
 
 
-def test_autotuned_fill_block_size_changes_no_bit(device):
-    """rasterizer.autotune_fill_passes times the caller's step under 2 / 3 / 4 / 5 passes per fill block, with non-temporal and with
-    plain stores, and patches the recorded argument block: whatever it picks, images and gradients stay bit for bit what the default gives (the knob only regroups the
-    forward's zero-fill blocks), and the choice survives the following replays."""
+def test_tuned_workspace_changes_no_bit_on_any_path(device):
+    """Workspace.tune times the caller's step under 2 / 3 / 4 / 5 passes per fill block, with non-temporal and with plain stores, and
+    patches the recorded argument block; tune_forward does the same for callers whose outputs are fresh tensors (the autograd path
+    runs it by itself the first time it sees a shape).  Whatever they pick -- and whatever is forced -- images and gradients stay bit
+    for bit what the untuned library gives, on every path: two calls, one call, the binned path (one call = view groups on two
+    streams), the autograd surface; and the choice survives the following replays."""
     c = util.make_case(seed=12, W=1000, H=96, scale_log=4.2, n_views=2)      # (W = 1000: the linear fill mode the knob belongs to)
     views = R.ViewBatch.from_cameras([cam.to(device) for cam in c.cams])
     args = (t(c.means, device), t(c.feat, device), t(c.opac, device), t(c.scales, device), t(c.quats, device), None)
     dL = t(c.dL_color, device)
+    R._FILL_TUNE.clear()
     col0, inv0, rad0, st0 = R.forward_views(views, *args)
     g0 = R.backward_views(st0, *args, dL)
-    ws = R.Workspace()
-    step = lambda: R.forward_backward_views(views, *args, dL, workspace=ws)
-    step(), step()
-    best, med = R.autotune_fill_passes(ws, step, reps=4, rounds=2)
-    assert best in R.TUNE_CANDIDATES and set(med) == set(R.TUNE_CANDIDATES) and all(v > 0 for v in med.values())
-    flags = ws._plans["fwd"][2][16]
-    assert (flags >> 8) & 0xff == best & 0xff and bool(flags & _lib.SKS_NO_NT_STORES) == bool(best & R.PLAIN_STORES)
-    for forced in (best, 1, 5, 7, R.PLAIN_STORES | 2, R.PLAIN_STORES | 4):     # (passes per block x store kind)
-        ws._plans["fwd"][2][16] = (flags & ~(0xff << 8) & ~_lib.SKS_NO_NT_STORES) | R._tune_flag_bits(forced)
-        col, inv, rad, st, g = step()
+
+    def same(out, g, tag):
         torch.cuda.synchronize()
-        assert torch.equal(col, col0) and torch.equal(inv, inv0) and torch.equal(rad, rad0), forced
-        assert all(v is None or torch.equal(v, g[k]) for k, v in g0.items()), forced
-    assert R.autotune_fill_passes(R.Workspace(), step) == (None, {})        # (nothing recorded: nothing to tune)
+        assert torch.equal(out[0], col0) and torch.equal(out[1], inv0) and torch.equal(out[2], rad0), tag
+        assert all(v is None or torch.equal(v, g[k]) for k, v in g0.items()), tag
+
+    for form in ("one_call", "two_calls", "binned_one_call"):
+        ws = R.Workspace()
+        kw = dict(force_binned=True, bin_capacity=4096) if form == "binned_one_call" else {}
+
+        def step():
+            if form == "two_calls":
+                o = R.forward_views(views, *args, workspace=ws)
+                return o + (R.backward_views(o[3], *args, dL, workspace=ws),)
+            return R.forward_backward_views(views, *args, dL, workspace=ws, **kw)
+        step(), step()
+        best, med = ws.tune(step, reps=4, rounds=2)
+        assert best in R.TUNE_CANDIDATES and set(med) == set(R.TUNE_CANDIDATES) and all(v > 0 for v in med.values())
+        flags = ws._plans["fwd"][2][16]
+        assert (flags >> 8) & 0xff == best & 0xff and bool(flags & _lib.SKS_NO_NT_STORES) == bool(best & R.PLAIN_STORES)
+        assert R._FILL_TUNE[(views.viewmatrix.device.index, 2, c.P, c.feat.shape[1], 1000, 96, "workspace")] == R._tune_flag_bits(best)
+        for forced in (best, 1, 5, 7, R.PLAIN_STORES | 2, R.PLAIN_STORES | 4):     # (passes per block x store kind)
+            ws._plans["fwd"][2][16] = (flags & ~R._FILL_BITS) | R._tune_flag_bits(forced)
+            out = step()
+            same(out, out[4], (form, forced))
+    # a Workspace recorded AFTER the measurement starts from the pick
+    ws2 = R.Workspace()
+    out = R.forward_backward_views(views, *args, dL, workspace=ws2)
+    assert ws2._plans["fwd"][2][16] & R._FILL_BITS == R._FILL_TUNE[(views.viewmatrix.device.index, 2, c.P, c.feat.shape[1], 1000, 96, "workspace")]
+    same(out, out[4], "recorded after tuning")
+    assert R.Workspace().tune(lambda: None) == (None, {})        # (nothing recorded: nothing to tune)
+    # fresh outputs: an explicit measurement, and the autograd path's own on first sight of a shape
+    bits = R.tune_forward(views, *args)
+    key = (views.viewmatrix.device.index, 2, c.P, c.feat.shape[1], 1000, 96, "fresh")
+    assert R._FILL_TUNE[key] == bits and bits in [R._tune_flag_bits(x) for x in R.TUNE_CANDIDATES_FRESH]
+    out = R.forward_views(views, *args)
+    same(out, R.backward_views(out[3], *args, dL), "fresh outputs, tuned")
+    R._FILL_TUNE.pop(key)
+    means = args[0].clone().requires_grad_(True)
+    img, radii, invd = R.rasterize_views(views, means, None, args[1].reshape(c.P, 1, -1), args[2], args[3], args[4])
+    assert key in R._FILL_TUNE and key in R.fill_tuning()       # (measured by the autograd path itself)
+    (img * dL).sum().backward()
+    torch.cuda.synchronize()
+    assert torch.equal(img, col0) and torch.equal(means.grad, g0["means3D"].sum(0))
+    R._FILL_TUNE.clear()
