@@ -121,19 +121,13 @@ void launch_fwd_small(const FwdArgs& a_in, int V, int gy, hipStream_t st, const 
 }
 
 template <int CG>
-void launch_fwd_binned(const FwdArgs& a, const BinView& bv, int V, int gx, int gy, const uint32_t* cover, hipStream_t st,
-                       const float* fused_dL = nullptr)
+void launch_fwd_binned(const FwdArgs& a, const BinView& bv, int V, int gx, int gy, const uint32_t* cover, hipStream_t st)
 {
     int fsplit, pb;
     fill_geometry(a, true, true, fsplit, pb);
     const int xc = ((gx + TGROUP - 1) / TGROUP + a.C) / (a.C + 1);   // composite blocks (TGROUP tile columns each) spread over the rows
     dim3 grid(fsplit + xc, gy, (a.C + 1) * V);
     const bool nt = !(a.flags & SKS_NO_NT_STORES);
-    if (fused_dL) {   // (the composite role also runs the tile backward: sks_forward_backward; W % 4 == 0 checked by the caller)
-        if (nt) hipLaunchKernelGGL((k_render_fwd_binned<CG, 4, true, false, true>), grid, dim3(256), 0, st, a, bv, gx, gy, fsplit, pb, cover, fused_dL);
-        else hipLaunchKernelGGL((k_render_fwd_binned<CG, 4, false, false, true>), grid, dim3(256), 0, st, a, bv, gx, gy, fsplit, pb, cover, fused_dL);
-        return;
-    }
     if (a.W % 4 == 0) {
         if (nt) hipLaunchKernelGGL((k_render_fwd_binned<CG, 4, true>), grid, dim3(256), 0, st, a, bv, gx, gy, fsplit, pb, cover);
         else hipLaunchKernelGGL((k_render_fwd_binned<CG, 4, false>), grid, dim3(256), 0, st, a, bv, gx, gy, fsplit, pb, cover);
@@ -224,14 +218,6 @@ __global__ void k_spin_us(unsigned long long ticks)
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
 }
 
-// may the binned forward run the tile backward inside its composite wavefronts (k_render_fwd_binned<.., BWD>)?  The plain case only:
-// no clamp, no background term, no inverse-depth or feature gradient (those take the separate kernel, k_render_bwd_tile)
-inline bool fused_bwd_ok(unsigned flags, int W, const float* bg, const float* dL_dinv, const float* dL_dfeat)
-{
-    static const bool off = [] { const char* e = getenv("SKS_FUSED_BWD"); return e && atoi(e) == 0; }();   // A/B runs
-    return !off && !(flags & (SKS_CLAMP01 | SKS_DEBUG_SYNC)) && W % 4 == 0 && !bg && !dL_dinv && !dL_dfeat;
-}
-
 // What sks_forward_backward hands its forward (forward_impl; sks_forward passes none): the points of the forward's launch sequence
 // behind which the backward's launches go to the second stream.
 struct FwdHook {
@@ -239,7 +225,6 @@ struct FwdHook {
     int (*after_geom)(void* ctx);                      // small path: right behind the geometry kernel
     int (*after_group)(void* ctx, int g, int v0, int nv);   // binned path: behind the forward launch of view group g (views v0 .. v0 + nv)
     void* ctx;
-    const float* fused_dL = nullptr;   // binned path: the composite role runs the tile backward itself on this dL/d(render) (V,C,H,W)
 };
 constexpr int FB_MAX_EVENTS = BIN_MAX_GROUPS;
 struct FbEvents {   // created by a thread's first combined call, reused by every later one on the same device
@@ -384,12 +369,11 @@ int forward_impl(int V, int P, int C, int W, int H, const float* viewmatrix, con
             bv.e_ids += (size_t)v0 * bin_capacity;
             bv.part += (size_t)v0 * bin_capacity * BIN_ROWS * NACC;
             const uint32_t* cov_g = cover + (size_t)v0 * (C + 1) * gy * cw;
-            const float* fdl = (hook && hook->fused_dL) ? hook->fused_dL + (size_t)v0 * C * HW : nullptr;
             switch (cg) {
-                case 4: launch_fwd_binned<4>(ag, bv, nv, gx, gy, cov_g, st, fdl); break;
-                case 16: launch_fwd_binned<16>(ag, bv, nv, gx, gy, cov_g, st, fdl); break;
-                case 20: launch_fwd_binned<20>(ag, bv, nv, gx, gy, cov_g, st, fdl); break;
-                default: launch_fwd_binned<32>(ag, bv, nv, gx, gy, cov_g, st, fdl); break;
+                case 4: launch_fwd_binned<4>(ag, bv, nv, gx, gy, cov_g, st); break;
+                case 16: launch_fwd_binned<16>(ag, bv, nv, gx, gy, cov_g, st); break;
+                case 20: launch_fwd_binned<20>(ag, bv, nv, gx, gy, cov_g, st); break;
+                default: launch_fwd_binned<32>(ag, bv, nv, gx, gy, cov_g, st); break;
             }
             if (hook && hook->after_group)
                 if (int rc = hook->after_group(hook->ctx, gi, v0, nv)) return rc;
@@ -575,18 +559,6 @@ int sks_forward_backward(int V, int P, int C, int W, int H, const float* viewmat
         if (ext_off) c.ext = false;
     }
     const bool no_join = (fb_flags & SKS_FB_NO_JOIN) != 0;
-    if (!small && P > 0 && ng < 2 && fused_bwd_ok(flags, W, bg, dL_dout_invdepth, dL_dfeatures)) {
-        // binned path, ONE stream: the forward's composite wavefronts run the tile backward themselves (k_render_fwd_binned<.., BWD>),
-        // then the geometry backward.  Bit for bit what the two calls produce.
-        if (!dL_dout_color || !accum || !dL_dmeans3D || !dL_dmeans2D || !dL_dopacity) return fail(-2, "missing required pointer");
-        const FwdHook fused{ nullptr, nullptr, nullptr, nullptr, dL_dout_color };
-        if (int rc = forward_impl(V, P, C, W, H, viewmatrix, projmatrix, tanfovx, tanfovy, means3D, features, opacities, scales, rotations,
-                                  cov3D_precomp, scale_modifier, flags, out_color, out_invdepth, radii, geom, binning, bin_capacity,
-                                  num_rendered_dev, nullptr, nullptr, stream, &fused))
-            return rc;
-        c.aux = c.s;
-        return c.backward(BWD_GEOM, -1);
-    }
     if (!aux_stream || aux_stream == stream || P == 0 || (flags & SKS_DEBUG_SYNC) || (!small && ng < 2)) {
         // nothing to run side by side: one after the other on the caller's stream
         if (int rc = forward_impl(V, P, C, W, H, viewmatrix, projmatrix, tanfovx, tanfovy, means3D, features, opacities, scales, rotations,
