@@ -1250,10 +1250,13 @@ def test_tuned_workspace_changes_no_bit_on_any_path(device):
     col0, inv0, rad0, st0 = R.forward_views(views, *args)
     g0 = R.backward_views(st0, *args, dL)
 
-    def same(out, g, tag):
+    stb = R.forward_views(views, *args, force_binned=True, bin_capacity=4096)[3]
+    g0b = R.backward_views(stb, *args, dL)      # (the binned walk contracts its multiply-adds: its own baseline for the gradients)
+
+    def same(out, g, tag, base=None):
         torch.cuda.synchronize()
         assert torch.equal(out[0], col0) and torch.equal(out[1], inv0) and torch.equal(out[2], rad0), tag
-        assert all(v is None or torch.equal(v, g[k]) for k, v in g0.items()), tag
+        assert all(v is None or torch.equal(v, g[k]) for k, v in (base or g0).items()), tag
 
     for form in ("one_call", "two_calls", "binned_one_call"):
         ws = R.Workspace()
@@ -1273,7 +1276,7 @@ def test_tuned_workspace_changes_no_bit_on_any_path(device):
         for forced in (best, 1, 5, 7, R.PLAIN_STORES | 2, R.PLAIN_STORES | 4):     # (passes per block x store kind)
             ws._plans["fwd"][2][16] = (flags & ~R._FILL_BITS) | R._tune_flag_bits(forced)
             out = step()
-            same(out, out[4], (form, forced))
+            same(out, out[4], (form, forced), g0b if form == "binned_one_call" else None)
     # a Workspace recorded AFTER the measurement starts from the pick
     ws2 = R.Workspace()
     out = R.forward_backward_views(views, *args, dL, workspace=ws2)
