@@ -267,6 +267,14 @@ class MultiViewLoop:
                     self._direct = DirectGather.create(dev, self.group)
         # (without the device tail -- a custom loss_grad / view_grad_fn -- the criterion is a host decision per group: the views'
         # losses ride in the gradients' all_gather as one more column, every rank feeds the same numbers in iteration order)
+        # the dense step renders into fresh tensors every group: its forward's fill configuration is measured once per image size
+        # (rasterizer.tune_forward; forward_views then launches with the pick) -- the library's own tuner, no caller-side knob
+        if view_grad_fn is None and dev.type == "cuda" and not self.sparse and R.AUTOTUNE and P <= 256:
+            with torch.no_grad():
+                feats = gaussians.get_features.reshape(P, -1)
+                for slots, vb, gt, _, idx in self.size_groups:
+                    R.tune_forward(vb, gaussians._xyz.detach(), feats, gaussians.get_opacity.detach(), gaussians.get_scaling.detach(),
+                                   gaussians.get_rotation.detach(), None, antialiasing=self.antialiasing, clamp01=True)
         # one GPU, sparse step: the whole group is two launches (sks_loop_fused_step); the geometry of the current
         # parameters lives in a persistent state that every step leaves up to date for the next one
         # (the single-workgroup tail walks the views four at a time: a win for a handful of views -- H36M's 4 --, a loss

@@ -1,6 +1,6 @@
-"""Freezes outputs of the CPU oracle (oracle/sks_oracle.c) for a few seeded cases into tests/golden/raster_oracle.npz.
+"""Freezes outputs of the CPU oracle (oracle/sks_oracle.c) for a few seeded cases into tests/golden/oracle_self_regression.npz.
 These are NOT reference-produced numbers (the reference's CUDA cannot run here); they pin the oracle against silent
-regressions and give the GPU tests committed vectors to compare with.  Run: python tests/golden/make_raster_golden.py"""
+regressions and give the GPU tests committed vectors to compare with.  Run: python tests/golden/make_oracle_self_regression.py"""
 import os
 import sys
 
@@ -24,8 +24,8 @@ def main():
             out[f"{name}_{k}"] = f[k]
         for k in ("dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dcov3D", "dL_dcolors"):
             out[f"{name}_{k}"] = b[k]
-    np.savez_compressed(os.path.join(HERE, "raster_oracle.npz"), **out)
-    print("wrote raster_oracle.npz", len(out), "arrays")
+    np.savez_compressed(os.path.join(HERE, "oracle_self_regression.npz"), **out)
+    print("wrote oracle_self_regression.npz", len(out), "arrays")
 
 
 if __name__ == "__main__":

@@ -13,11 +13,11 @@ import torch
 from oracle import oracle as orc
 from oracle import torch_ref
 from tests import util
-from tests.golden.make_raster_golden import CASES
+from tests.golden.make_oracle_self_regression import CASES
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = np.load(os.path.join(ROOT, "tests", "golden", "reference_python.npz"))
-RGOLD = np.load(os.path.join(ROOT, "tests", "golden", "raster_oracle.npz"))
+RGOLD = np.load(os.path.join(ROOT, "tests", "golden", "oracle_self_regression.npz"))
 
 
 # ------------------------------------------------------------------------------------------------ oracle pins
@@ -32,7 +32,10 @@ def test_oracle_expf_accuracy():
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
-def test_oracle_matches_frozen_vectors(name):
+def test_oracle_self_regression_guard(name):
+    """The oracle against ITS OWN frozen output (tests/golden/oracle_self_regression.npz, made by make_oracle_self_regression.py from
+    this same restatement): a guard against silent changes of the checker, NOT a reference fixture -- nothing the reference
+    produced is in that file (the reference-executed fixtures are the reference_*.npz)."""
     c = util.make_case(n_views=1, **CASES[name])
     f = util.oracle_forward(c, 0)
     b = util.oracle_backward(c, 0, f, bg=[0.1, 0.2, 0.3])
