@@ -443,8 +443,10 @@ def run_single(args, torch, dev, wl):
         times the 256 MB Infinity Cache): the two-call step through n_sets workspaces, every forward launch bracketed.  This is the
         HBM figure: nothing of a launch's output can still sit in the cache from the launch before."""
         sts = [ApiStep(views, params, dL, one_call=False) for _ in range(n_sets)]
-        for st in sts:          # (recorded with the fill configuration the headline's Workspace.tune picked for the shape)
+        cfg_flags = step.ws._plans["fwd"][2][16]
+        for st in sts:          # the headline step's own fill configuration (what its Workspace.tune picked), flag for flag
             st(), st()
+            st.ws._plans["fwd"][2][16] = cfg_flags
         sync()
         _lib.prof_enable(True, every=1, kinds=(0,))
         _lib.prof_read(0)
@@ -454,7 +456,7 @@ def run_single(args, torch, dev, wl):
         sync()
         pf_ = _lib.prof_read_quantiles(0)
         _lib.prof_enable(False)
-        cfg = sts[0].ws._plans["fwd"][2][16]
+        cfg = cfg_flags
         del sts
         torch.cuda.empty_cache()
         return pf_, cfg

@@ -135,7 +135,8 @@ int sks_backward(int V, int P, int C, int W, int H,
  * the backward -- outputs and gradients are the caller's in `stream` order, exactly as after the two separate calls, and bit for
  * bit the same numbers.  The latency-bound backward (a few thousand short workgroups) hides under the HBM-bound forward: the H36M
  * step 67 -> ~57 us.  aux_stream NULL (or == stream, or the binned path, whose backward starts from what the forward's
- * compositor left per pixel): the two calls one after the other.  Arguments as for sks_forward (without the two debug outputs)
+ * compositor left per pixel, or more than 400 (view, Gaussian) pairs without SKS_FB_NO_JOIN -- there the backward's wavefronts
+ * would cost the forward more than they hide: all 31 Panoptic views): the two calls one after the other.  Arguments as for sks_forward (without the two debug outputs)
  * followed by sks_backward's.  The library keeps two hipEvents per host thread for the hand-over (created by the first call).
  * fb_flags: SKS_FB_NO_JOIN = `stream` does NOT wait for the backward at the end: the caller has more to enqueue behind the
  * gradients on aux_stream -- a view-sharded step's collective on the joint gradients, which then also hides under the forward --

@@ -227,6 +227,7 @@ struct FwdHook {
     void* ctx;
 };
 constexpr int FB_MAX_EVENTS = BIN_MAX_GROUPS;
+constexpr int FB_OVERLAP_MAX_PAIRS = BWD_WG_PAIRS16;   // (view, Gaussian) pairs up to which sks_forward_backward runs the backward beside the forward
 struct FbEvents {   // created by a thread's first combined call, reused by every later one on the same device
     hipEvent_t geom = nullptr, done = nullptr;
     hipEvent_t grp[FB_MAX_EVENTS] = {};
@@ -559,7 +560,13 @@ int sks_forward_backward(int V, int P, int C, int W, int H, const float* viewmat
         if (ext_off) c.ext = false;
     }
     const bool no_join = (fb_flags & SKS_FB_NO_JOIN) != 0;
-    if (!aux_stream || aux_stream == stream || P == 0 || (flags & SKS_DEBUG_SYNC) || (!small && ng < 2)) {
+    // The step's form per workload: beside the forward the small path's backward pays while it is a handful of workgroups (H36M's 4
+    // views: 1 088, step 66 -> 58 us; one rank's 4 Panoptic views) and costs more than it hides once its wavefronts crowd the fill
+    // blocks out (all 31 Panoptic views, 589 (view, Gaussian) pairs: 0.908 ms beside, 0.893 behind -- the forward 817 -> 866 us, the
+    // backward 56 -> 133).  Beyond FB_OVERLAP_MAX_PAIRS the call runs its two halves one after the other -- unless the caller
+    // keeps the second stream's tail for itself (SKS_FB_NO_JOIN: a sharded step's collective wants the gradients THERE).
+    const bool crowded = small && (long long)V * P > FB_OVERLAP_MAX_PAIRS && !no_join;
+    if (!aux_stream || aux_stream == stream || P == 0 || (flags & SKS_DEBUG_SYNC) || (!small && ng < 2) || crowded) {
         // nothing to run side by side: one after the other on the caller's stream
         if (int rc = forward_impl(V, P, C, W, H, viewmatrix, projmatrix, tanfovx, tanfovy, means3D, features, opacities, scales, rotations,
                                   cov3D_precomp, scale_modifier, flags, out_color, out_invdepth, radii, geom, binning, bin_capacity,

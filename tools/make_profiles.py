@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Turn the rocprofv3 output of tools/profile_round.sh (gpurun_out/prof/) into the files kept under profiles/:
 
-  <round>_kernel_stats.csv            rocprofv3 --kernel-trace --stats summary, H36M workload (bench.py default)
+  <round>_kernel_stats.csv            rocprofv3 --kernel-trace --stats summary, H36M workload, the headline (two-call) form of the step
+  <round>_kernel_stats_one_call.csv   same, the one-call form (sks_forward_backward)
   <round>_kernel_stats_panoptic.csv   same, Panoptic 31-view workload
   <round>_kernel_stats_stress.csv     same, tools/bench_stress.py (P = 4352, 8 views, 2048^2, binned path)
   <round>_bench.json / <round>_bench_panoptic.json    the bench.py lines of the same box
@@ -19,7 +20,7 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
 DST = os.path.join(ROOT, "profiles")
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r05"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r06"
 NAMES = {"h36m": "h36m_4view_1000x1000_P17_C17", "panoptic": "panoptic_31view_1920x1080_P19_C19",
          "stress": "stress_256skeletons_8view_2048x2048_P4352_C17"}
 
@@ -46,9 +47,9 @@ for wl, tag in (("h36m", ""), ("panoptic", "_panoptic"), ("stress", "_stress")):
     st = glob.glob(os.path.join(SRC, f"{wl}_stats", "**", "*kernel_stats.csv"), recursive=True)
     if st:
         shutil.copy(st[0], os.path.join(DST, f"{rnd}_kernel_stats{tag}.csv"))
-    st2 = glob.glob(os.path.join(SRC, f"{wl}2_stats", "**", "*kernel_stats.csv"), recursive=True)
-    if st2:   # the two-call form of the step (bench.py --form two): the forward alone on the chip
-        shutil.copy(st2[0], os.path.join(DST, f"{rnd}_kernel_stats{tag}_two_calls.csv"))
+    st1 = glob.glob(os.path.join(SRC, f"{wl}1_stats", "**", "*kernel_stats.csv"), recursive=True)
+    if st1:   # the one-call form of the step (bench.py --form one): the backward beside the forward (the headline is the two calls)
+        shutil.copy(st1[0], os.path.join(DST, f"{rnd}_kernel_stats{tag}_one_call.csv"))
     b = os.path.join(SRC, f"{wl}_bench.json")
     if os.path.exists(b) and os.path.getsize(b):
         shutil.copy(b, os.path.join(DST, f"{rnd}_bench{tag}.json"))
@@ -84,7 +85,8 @@ for name in ("bench_ssim.txt", "ssim_pmc_fwd.txt", "ssim_pmc_train.txt", "sharde
              "frames.txt", "stress_traffic.txt", "stress_timeline.txt", "stress.log",
              "dropin_trace_fused.txt", "dropin_trace_tensor.txt", "one_call_timeline.txt", "one_call_timeline_rank_step.txt",
              "pmc_bwd_tile_stress.txt", "pmc_bwd_wave_h36m.txt", "pmc_bwd_wave_panoptic.txt", "pmc_ssim_fwd.txt", "pmc_ssim_train.txt",
-             "fuzz_bound_calib.txt", "fill_passes_sweep.txt"):   # fused-SSIM timings and SQ counter passes, the sharded path at world 1, sweeps
+             "fuzz_bound_calib.txt", "fill_passes_sweep.txt", "loop_timeline.txt", "probe_rotating.txt", "stress_forms.txt",
+             "dropin_host.txt"):   # fused-SSIM timings and SQ counter passes, the sharded path at world 1, sweeps
     src = os.path.join(SRC, name)
     if os.path.exists(src) and os.path.getsize(src):
         shutil.copy(src, os.path.join(DST, f"{rnd}_{name}"))

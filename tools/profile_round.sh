@@ -4,24 +4,26 @@
 # --kernel-trace).  Run on the GPU box from the repo root:  bash tools/profile_round.sh r01
 # Outputs land in gpurun_out/prof/; tools/make_profiles.py turns them into profiles/<round>_*.
 set -u
-R=${1:-r05}
+R=${1:-r06}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
+export SKS_BENCH_TRAFFIC=0     # (bench.py's own in-run PMC child passes stay out of a bench.py that is itself being profiled)
 for WL in h36m panoptic; do
-  # per-kernel averages of the HEADLINE form of the step (--form one: sks_forward_backward, the backward beside the forward) and of the
-  # two-call form (the forward alone on the chip): two runs, so that neither average is a mixture
-  # (no autotuning inside these runs -- its candidates' launches would be averaged in: the fill-block size the tuner picks on
-  # this pool -- plain stores for both forms of the H36M step, five passes per block in the one-call form, three in the two-call
-  # form; the default everywhere else -- is set by hand)
-  T1=0; T2=0; [ $WL = h36m ] && T1=0x510 && T2=0x310     # (0x510: five passes, plain stores -- SKS_NO_NT_STORES is 0x10 -- the tuner's usual pick for the one-call step; 0x310 for the two-call step)
-  rm -rf "$OUT/${WL}_stats" "$OUT/${WL}2_stats"
-  SKS_BENCH_AUTOTUNE=0 SKS_FWD_TUNE=$T1 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${WL}_stats" -o stats -- python3 "$ROOT/bench.py" --workload $WL --form one --steps 100 --warmup 5 --no-cpu-baseline --no-extras > "$OUT/${WL}_bench_under_rocprof.json" 2> "$OUT/${WL}_stats.log"
-  SKS_BENCH_AUTOTUNE=0 SKS_FWD_TUNE=$T2 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${WL}2_stats" -o stats -- python3 "$ROOT/bench.py" --workload $WL --form two --steps 100 --warmup 5 --no-cpu-baseline --no-extras > "$OUT/${WL}_bench_two_calls_under_rocprof.json" 2> "$OUT/${WL}2_stats.log"
+  # per-kernel averages of the HEADLINE form of the step (--form two: sks_forward, then sks_backward: the forward alone on the chip)
+  # and of the one-call form (sks_forward_backward, the backward beside the forward): two runs, so that neither average is a mixture
+  # (no tuning inside these runs -- its candidates' launches would be averaged in: the fill configuration Workspace.tune picks on
+  # this pool -- the library's default for the two-call step, three non-temporal passes per fill block for the H36M one-call step --
+  # is set by hand)
+  T1=0; [ $WL = h36m ] && T1=0x300
+  rm -rf "$OUT/${WL}_stats" "$OUT/${WL}1_stats"
+  SKS_BENCH_AUTOTUNE=0 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${WL}_stats" -o stats -- python3 "$ROOT/bench.py" --workload $WL --form two --steps 100 --warmup 5 --no-cpu-baseline --no-extras > "$OUT/${WL}_bench_under_rocprof.json" 2> "$OUT/${WL}_stats.log"
+  SKS_BENCH_AUTOTUNE=0 SKS_FWD_TUNE=$T1 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${WL}1_stats" -o stats -- python3 "$ROOT/bench.py" --workload $WL --form one --steps 100 --warmup 5 --no-cpu-baseline --no-extras > "$OUT/${WL}_bench_one_call_under_rocprof.json" 2> "$OUT/${WL}1_stats.log"
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/${WL}_w" -o w -- python3 "$ROOT/bench.py" --workload $WL --form two --steps 20 --warmup 3 --no-cpu-baseline --no-prof --no-extras > /dev/null 2> "$OUT/${WL}_w.log"
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/${WL}_f" -o f -- python3 "$ROOT/bench.py" --workload $WL --form two --steps 20 --warmup 3 --no-cpu-baseline --no-prof --no-extras > /dev/null 2> "$OUT/${WL}_f.log"
 done
+unset SKS_BENCH_TRAFFIC
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stress_stats" -o stats -- python3 "$ROOT/tools/bench_stress.py" > "$OUT/stress.log" 2>&1
 # HBM traffic of the binned path's kernels (separate PMC passes, --kernel-trace only) and the timeline of one forward call
 bash "$ROOT/tools/pmc_traffic_stress.sh" "$OUT" > "$OUT/stress_traffic.txt" 2>&1
@@ -45,12 +47,18 @@ FACTORED=0 ONLY_BATCH=1 python3 tools/bench_frames.py 16 2>/dev/null | grep "fra
 # with the fused criterion and with the reference's tensor-op criterion (whose own ops are ~560 us of GPU time per iteration)
 bash tools/dropin_trace.sh "$OUT/dropin_trace_fused.txt" > /dev/null 2>&1
 bash tools/dropin_trace.sh --tensor "$OUT/dropin_trace_tensor.txt" > /dev/null 2>&1
-# round 5: the one-call step's kernel timeline (two queues), SQ counter tables of the backward kernels and of fused SSIM, the
-# calibration of the fuzz sweep's rounding allowance, the knobs of sks_forward_backward
+# the one-call step's kernel timeline (two queues), SQ counter tables of the backward kernels and of fused SSIM, the
+# calibration of the fuzz sweep's rounding allowance, passes per fill block in both forms
 bash tools/trace_one_call.sh h36m > "$OUT/one_call_timeline.txt" 2>&1
 bash tools/trace_one_call.sh panoptic4 > "$OUT/one_call_timeline_rank_step.txt" 2>&1
-bash tools/r05_counters.sh > /dev/null 2>&1
-for f in bwd_tile_stress bwd_wave_h36m bwd_wave_panoptic ssim_fwd ssim_train; do cp "$ROOT/gpurun_out/r05_pmc_$f.txt" "$OUT/pmc_$f.txt"; done
+bash tools/trace_loop.sh > "$OUT/loop_timeline.txt" 2>&1
+bash tools/counters.sh $R > /dev/null 2>&1
+for f in bwd_tile_stress bwd_wave_h36m bwd_wave_panoptic ssim_fwd ssim_train; do cp "$ROOT/gpurun_out/${R}_pmc_$f.txt" "$OUT/pmc_$f.txt"; done
 python3 tools/fuzz_bound_calib.py 4000 10000 > "$OUT/fuzz_bound_calib.txt" 2>&1
 bash tools/ab_split.sh 2>&1 | grep -v amdgpu.ids > "$OUT/fill_passes_sweep.txt"
+# round 6: the forward over one output set vs eight in turn (what roofline.frac / frac_same_buffer are made of); the stress step as
+# two calls vs one call with view groups on two streams (the A/B that closes the binned overlap); the drop-in iteration's host side
+python3 tools/probe_rotating.py 2>&1 | grep -v amdgpu.ids > "$OUT/probe_rotating.txt"
+for G in 1 2 4; do SKS_BIN_GROUPS=$G python3 tools/bench_stress_forms.py 5 2>&1 | grep -v amdgpu.ids | tail -2; done > "$OUT/stress_forms.txt"
+python3 tools/profile_dropin_host.py 2>&1 | grep -v amdgpu.ids | head -60 > "$OUT/dropin_host.txt"
 find "$OUT" -name "*.csv" | head -40
