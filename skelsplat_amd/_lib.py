@@ -22,7 +22,14 @@ SKS_RAW_PARAMS = 32
 SKS_BIN_CLEAN = 64
 SKS_RAW_GRADS = 128
 SKS_FB_NO_JOIN = 1
+SKS_BIN_GROUPS_SHIFT = 16
 SKS_SSIM_SCRATCH_BYTES = 64 * 8
+
+
+def SKS_BIN_GROUPS(n):
+    """Flag bits for `n` view groups on the binned path (include/skelsplat_hip.h)."""
+    return ((int(n) - 1) & 7) << SKS_BIN_GROUPS_SHIFT
+
 
 _vp, _i, _u, _f, _sz = C.c_void_p, C.c_int, C.c_uint, C.c_float, C.c_size_t
 

@@ -1194,6 +1194,48 @@ def test_forward_backward_as_one_call_on_the_binned_path_is_the_two_calls(device
         assert torch.equal(out[0], col) and all(v is None or torch.equal(v, out[4][k]) for k, v in g.items())
 
 
+@pytest.mark.parametrize("groups", [2, 3, 7])
+def test_view_groups_on_the_binned_path_change_no_bit(device, groups):
+    """SKS_BIN_GROUPS: the binning kernels run once, the forward's fill + composite launch and the tile backward once per group of
+    views (per-group tile descriptors and class counters); sks_forward_backward then puts group g's backward on the second stream
+    beside group g + 1's forward.  Five views in 2 / 3 / 5 groups (7 asked for: clamped to the views): images, lists and gradients bit
+    for bit those of the single launch, through the two calls and through the one call, with and without the extra terms (background,
+    inverse-depth and feature gradients take the other kernel variants)."""
+    c = util.make_case(seed=35, W=152, H=120, scale_log=3.6, n_skeletons=16, pitch=150.0, n_views=5)   # P = 272: binned path
+    views = R.ViewBatch.from_cameras([cam.to(device) for cam in c.cams])
+    args = (t(c.means, device), t(c.feat, device), t(c.opac, device), t(c.scales, device), t(c.quats, device), None)
+    dL, dLi = t(c.dL_color, device), t(c.dL_inv, device)
+    bg = torch.tensor([0.2, 0.1, 0.3], device=device)
+    bits = _lib.SKS_BIN_GROUPS(groups)
+    col, inv, rad, st = R.forward_views(views, *args)
+    pl0, rg0, nr0 = R.export_lists(st)
+    for extra in (False, True):
+        kw = dict(dL_dinvdepth=dLi, bg=bg, want_dfeatures=True) if extra else {}
+        g = R.backward_views(st, *args, dL, **kw)
+        # two calls, both told the same grouping
+        col2, inv2, rad2, st2 = R.forward_views(views, *args, tune_flags=bits)
+        pl2, rg2, nr2 = R.export_lists(st2)
+        assert torch.equal(col2, col) and torch.equal(inv2, inv) and torch.equal(rad2, rad)
+        assert torch.equal(pl2, pl0) and torch.equal(rg2, rg0) and torch.equal(nr2, nr0)
+        def same(ga, tag):     # (the binned path's feature gradient is the one sum accumulated with float atomics: tolerance)
+            for k, v in g.items():
+                if v is None:
+                    continue
+                if k == "features":
+                    torch.testing.assert_close(ga[k], v, rtol=1e-4, atol=1e-5 * float(v.abs().max()))
+                else:
+                    assert torch.equal(v, ga[k]), (groups, extra, tag, k)
+        g2 = R.backward_views(st2, *args, dL, tune_flags=bits, **kw)
+        same(g2, "two calls")
+        # one call: the groups pipelined over two streams
+        ws = R.Workspace()
+        for _ in range(3):
+            out = R.forward_backward_views(views, *args, dL, workspace=ws, tune_flags=bits, **kw)
+            torch.cuda.synchronize()
+            assert torch.equal(out[0], col) and torch.equal(out[1], inv)
+            same(out[4], "one call")
+
+
 def test_any_number_of_channels_through_the_generic_path(device):
     """"C is fixed per package (17 / 19 / 15) -- keep that, plus accept any C via a generic path".  The kernels
     hold SKS_MAX_CHANNELS = 32 channels of a pixel in registers; a 70-channel feature row goes through as three slices per view
