@@ -1255,6 +1255,76 @@ def test_two_ranks_on_one_gpu_equal_one_rank(device, mode):
         assert np.array_equal(a, b), k
 
 
+# ------------------------------------------------- BASELINE config 4's partition on the device path: eight ranks, one GPU (gloo)
+def _config4_gpu_worker(rank, world, port, mode, ret):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)   # RCCL refuses several ranks on one device
+    from skelsplat_amd.loop import MultiViewLoop, OptEarlyStopping
+    from skelsplat_amd.heatmaps import generate_heatmaps
+    from skelsplat_amd.scene import SyntheticScene, GaussianModel
+    sc = SyntheticScene("panoptic", n_views=31, seed=5, W=192, H=112, device=dev)
+    gm = GaussianModel().create_from_points(sc.pose_3d_init, sc.spatial_lr_scale, 19, scaling=4.2, scene_type="panoptic", device=dev)
+    gm.training_setup()
+    hm = generate_heatmaps(gm._xyz.detach(), gm.get_scaling.detach(), gm._rotation.detach(), torch.tensor(sc.poses_2d, device=dev),
+                           sc.cameras)
+    es = OptEarlyStopping(window_size=4, repeat_tolerance=1.0) if mode == "early_stop" else "no_stopping"
+    loop = MultiViewLoop(gm, sc.cameras, hm, dataset="panoptic", accumulation_steps=31, sparse=mode != "dense", early_stopping=es)
+    assert loop.world == world and loop.exchange == (world > 1) and loop.device_tail
+    n_local = len(loop.local_ids)
+    if world > 1:
+        assert loop.vmax == 4 and n_local == (3 if rank == 7 else 4)      # 4,4,4,4,4,4,4,3
+    loop.run(93)          # three groups -- or, with the criterion, its stop at iteration 8 and the groups enqueued behind it
+    torch.cuda.synchronize()
+    if mode == "early_stop":
+        assert loop.stopped_at == 8 and loop.iteration == 8 and int(loop.counters[0]) == 8, loop.stopped_at
+    if world > 1:
+        mine = [n_local, float(gm._xyz.detach().abs().sum()), loop.iteration]
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        assert sorted(g[0] for g in gathered) == [3, 4, 4, 4, 4, 4, 4, 4]
+        assert all(g[1] == gathered[0][1] and g[2] == gathered[0][2] for g in gathered)     # every rank holds the same parameters
+    if rank == 0:
+        ret.put([x.detach().cpu().numpy() for x in (gm._xyz, gm._scaling, gm._rotation, gm._opacity, loop.accumulated_grads)]
+                + [np.array([loop.stopped_at or 0, loop.iteration])])
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["sparse", "dense", "early_stop"])
+def test_config4_partition_eight_ranks_on_one_gpu_equal_one_rank(device, mode):
+    """BASELINE config 4's partition -- 31 Panoptic-shaped views over EIGHT ranks, shards 4,4,4,4,4,4,4,3, one zero pad row,
+    all_gather, the rank-major optimiser kernel (`shard_world = 8`), with the early-stopping sums in the gathered block -- through
+    the DEVICE path (HIP kernels, device tail), as eight processes sharing this GPU over gloo.  Bit-identical to one process; with
+    the criterion every rank stops after the same number of collectives at the iteration the single process stops at.  (What no
+    test can give here is the timing of eight GPUs.)"""
+    import os
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = 29900 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_config4_gpu_worker, args=(r, 8, port, mode, ret)) for r in range(8)]
+    for p in procs:
+        p.start()
+    eight = ret.get(timeout=600)
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    one_p = ctx.Process(target=_config4_gpu_worker, args=(0, 1, port + 1, mode, ret))
+    one_p.start()
+    one = ret.get(timeout=300)
+    one_p.join(timeout=120)
+    assert one_p.exitcode == 0
+    for k, (a, b) in enumerate(zip(eight, one)):
+        assert np.array_equal(a, b), k
+
+
 def _adam_groups(dev, seed):
     g = torch.Generator().manual_seed(seed)
     shapes = {"xyz": (17, 3), "f_dc": (17, 1, 17), "f_rest": (17, 0, 17), "opacity": (17, 1), "scaling": (17, 3), "rotation": (17, 4),
