@@ -137,7 +137,11 @@ int sks_backward(int V, int P, int C, int W, int H,
  * step 67 -> ~57 us.  aux_stream NULL (or == stream, or the binned path, whose backward starts from what the forward's
  * compositor left per pixel, or more than 400 (view, Gaussian) pairs without SKS_FB_NO_JOIN -- there the backward's wavefronts
  * would cost the forward more than they hide: all 31 Panoptic views): the two calls one after the other.  Arguments as for sks_forward (without the two debug outputs)
- * followed by sks_backward's.  The library keeps two hipEvents per host thread for the hand-over (created by the first call).
+ * followed by sks_backward's.  On the binned path with a second stream and SKS_BIN_GROUPS(n > 1) in `flags`, view group g's
+ * backward runs on aux_stream beside group g + 1's forward (bit-identical; measured SLOWER than the plain sequence on the stress
+ * scene, so it is not the default).  The library keeps a handful of hipEvents per host thread for the hand-overs (created by the
+ * first combined call of a thread, re-created when the thread moves to another device, never destroyed: process-lifetime objects).
+ * After an error behind the hand-over `stream` is made to wait for what aux_stream already holds, whatever fb_flags says.
  * fb_flags: SKS_FB_NO_JOIN = `stream` does NOT wait for the backward at the end: the caller has more to enqueue behind the
  * gradients on aux_stream -- a view-sharded step's collective on the joint gradients, which then also hides under the forward --
  * and makes `stream` wait for aux_stream itself (an event recorded on aux_stream, hipStreamWaitEvent on stream). */

@@ -1,13 +1,13 @@
 #!/bin/bash
-# round 6: the GPU test tier and the driver's bench line, as the driver runs them
+# the GPU test tier and the driver's bench line, as the driver runs them at round end (GPU box):  bash tools/driver_tier.sh
 mkdir -p gpurun_out
-( time timeout 1500 python -m pytest tests -x -q -m gpu ) > gpurun_out/r06_pytest_gpu.log 2>&1
-tail -5 gpurun_out/r06_pytest_gpu.log
-( time python bench.py ) > gpurun_out/r06_bench.json 2> gpurun_out/r06_bench.err
-tail -3 gpurun_out/r06_bench.err
+( time timeout 1500 python -m pytest tests -x -q -m gpu ) > gpurun_out/pytest_gpu.log 2>&1
+tail -5 gpurun_out/pytest_gpu.log
+( time python bench.py ) > gpurun_out/bench.json 2> gpurun_out/bench.err
+tail -3 gpurun_out/bench.err
 python - <<'PY'
 import json
-r = json.load(open("gpurun_out/r06_bench.json"))
+r = json.load(open("gpurun_out/bench.json"))
 def show(d, keys):
     return {k: d.get(k) for k in keys}
 print(show(r, ["value", "ms_per_step"]), r["config"]["form"], r["config"]["autotuned"]["fill_role"])
