@@ -180,15 +180,20 @@ class ApiStep:
         cands, reps, rounds = self.cands or self.R.TUNE_CANDIDATES, 16, 3
         self()          # (the first call records the argument lists the tuner times)
         self()
+        for _ in range(200):     # a fresh process: clocks and Python paths warm before anything is compared (the tuner's measurement is
+            self()               # host wall time over device synchronisations)
         if self.views is None or self.ws._plans.get("fwd") is None:
-            for _ in range(len(cands) * rounds * (2 + reps)):
+            for _ in range(self.R.TUNE_WARM + len(cands) * rounds * (2 + reps)):
                 self()
             return None
-        best, med = self.ws.tune(self, cands, reps, rounds)
+        # (sharded: no conditional confirmation round -- the step holds a collective, every rank issues the same number of steps)
+        best, med = self.ws.tune(self, cands, reps, rounds, confirm=self.exchange is None)
         self.tuned = {"by": "Workspace.tune (skelsplat_amd/rasterizer.py)", "fill_role": self.R.tune_name(best),
                       "fill_passes_per_block": (best & 0xff) or "default (2)",
                       "stores": "plain" if best & self.R.PLAIN_STORES else "non-temporal",
-                      "median_us_by_candidate": {self.R.tune_name(k): round(v, 2) for k, v in med.items()}}
+                      "us_by_candidate": {self.R.tune_name(k): round(v, 2) for k, v in med.items()},
+                      "rule": "each candidate's least disturbed of 3 interleaved rounds; the default stays unless another beats it by > 2 % "
+                              "twice (a confirmation measurement of the two)"}
         return self.tuned
 
     cands = None        # tuner candidates (None: the library's default list)

@@ -248,7 +248,7 @@ void sks_set_error_(const char* msg)  // used by the other translation units of 
 {
     snprintf(g_err, sizeof(g_err), "%s", msg);
 }
-int sks_version(void) { return 10; }
+int sks_version(void) { return 11; }
 
 int sks_scratch_bytes(int V, int P, int C, int W, int H, size_t bin_capacity, size_t* geom, size_t* binning, size_t* accum)
 {
