@@ -121,7 +121,7 @@ class Workspace:
 def _sig(t):
     """What identifies a tensor argument of a recorded call: None (not provided), (pointer, shape) of a contiguous fp32
     ROCm tensor, or False = "take the validating path" (anything else)."""
-    if t is None:
+    if t is None or t.numel() == 0:     # (an empty tensor is the reference's "not provided": GaussianRasterizer hands torch.Tensor([]))
         return None
     if t.dtype is not torch.float32 or not t.is_cuda or not t.is_contiguous():
         return False
@@ -1004,6 +1004,8 @@ def _features_of(sh, colors_precomp, P):
 
 
 _AUTOGRAD_PLANS = {}     # recorded C-ABI argument blocks of the autograd path (forward_views / backward_views `plans`)
+if os.environ.get("SKS_AUTOGRAD_PLANS", "1") == "0":      # A/B runs: every call takes the validating path
+    _AUTOGRAD_PLANS = None
 
 
 class _RasterizeViews(torch.autograd.Function):
