@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""The literal drop-in iteration (render -> fused criterion -> loss.backward() -> skelsplat_amd.optim.Adam every 4th view) with and
+without the autograd path's recorded C-ABI calls:  for P in 0 1; do SKS_AUTOGRAD_PLANS=$P python tools/ab_dropin_plans.py; done
+(run the pair several times in turn on one box: hosts change gear)."""
 import os, sys, time, types
 sys.path.insert(0, os.getcwd())
 import torch
